@@ -1,0 +1,914 @@
+// gs_oracle.cpp — CPU restatement of the reference training step.  TEST INFRASTRUCTURE ONLY.
+//
+// Nothing outside tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this
+// library; the shipped HIP path never links or loads it.
+//
+// PARITY UNPINNED: the reference (osreboot/Gaussian-Splatterer v1.1.0) ships no tests, golden
+// vectors or fixtures, it cannot be compiled here (CUDA + five empty submodules), and the
+// rasterizer arithmetic lives in the un-vendored, un-pinned submodule
+// graphdeco-inria/diff-gaussian-rasterization (.gitmodules:10-12).  This file restates
+//   * the reference's own kernels and step orchestration  (src/Trainer.cu, cited per function), and
+//   * the published algorithm of that rasterizer at the API era fixed by the reference's call
+//     sites (src/Trainer.cu:175-201, :334-360, :378-412),
+// and is pinned only by source-independent checks: fp64 finite differences of the forward
+// against the analytic backward, closed-form known-answer cases and structural invariants
+// (tests/test_oracle_*.py).
+//
+// Arithmetic: every function is a template over Real.  Real=float is the oracle proper (fp32,
+// built with -ffp-contract=off so that no multiply-add is fused); Real=double is used only to
+// validate the analytic backward by finite differences.
+//
+// Matrices are glm column-major float[16]: m[col*4+row]  (glm::value_ptr, src/Trainer.cu:323-324).
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <set>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+constexpr int TILE = 16;  // BLOCK_X = BLOCK_Y = 16
+
+// ---------------------------------------------------------------------------------------------
+// small helpers (SURVEY Appendix A "Helpers")
+// ---------------------------------------------------------------------------------------------
+template <class R> struct V3 { R x, y, z; };
+template <class R> struct V4 { R x, y, z, w; };
+
+template <class R> inline V3<R> transformPoint4x3(const V3<R>& p, const R* m) {
+    return { m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+             m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+             m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] };
+}
+template <class R> inline V4<R> transformPoint4x4(const V3<R>& p, const R* m) {
+    return { m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+             m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+             m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14],
+             m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15] };
+}
+template <class R> inline V3<R> transformVec4x3Transpose(const V3<R>& p, const R* m) {
+    return { m[0] * p.x + m[1] * p.y + m[2] * p.z,
+             m[4] * p.x + m[5] * p.y + m[6] * p.z,
+             m[8] * p.x + m[9] * p.y + m[10] * p.z };
+}
+template <class R> inline R ndc2Pix(R v, int S) { return ((v + R(1.0)) * R(S) - R(1.0)) * R(0.5); }
+
+template <class R> struct SH {
+    static constexpr R C0 = R(0.28209479177387814);
+    static constexpr R C1 = R(0.4886025119029199);
+    static constexpr R C2[5] = { R(1.0925484305920792), R(-1.0925484305920792), R(0.31539156525252005),
+                                 R(-1.0925484305920792), R(0.5462742152960396) };
+    static constexpr R C3[7] = { R(-0.5900435899266435), R(2.890611442640554), R(-0.4570457994644658),
+                                 R(0.3731763325901154), R(-0.4570457994644658), R(1.445305721320277),
+                                 R(-0.5900435899266435) };
+};
+
+inline uint32_t depth_bits(float d) { uint32_t u; std::memcpy(&u, &d, 4); return u; }
+
+// ---------------------------------------------------------------------------------------------
+// Per-view state produced by forward and consumed by backward (the reference's geometry /
+// binning / image scratch chunks, src/Trainer.cu:329-337,399-401).
+// ---------------------------------------------------------------------------------------------
+template <class R> struct ViewState {
+    int P = 0, W = 0, H = 0, gx = 0, gy = 0;
+    std::vector<R> depth, means2D, cov3D, conic_opacity, rgb;
+    std::vector<int32_t> radii;
+    std::vector<uint32_t> tiles_touched, point_offsets, rect;  // rect: minx,miny,maxx,maxy per splat
+    std::vector<uint8_t> clamped;
+    std::vector<uint64_t> keys_unsorted, keys;
+    std::vector<uint32_t> vals_unsorted, point_list;
+    std::vector<uint32_t> ranges;  // 2 per tile
+    std::vector<R> final_T;
+    std::vector<uint32_t> n_contrib;
+    std::vector<float> margin;  // per-pixel fragility: min relative distance to a discrete threshold
+    int R_total = 0;
+};
+
+// A.1 — per-splat preprocess.  Operation order follows glm's mat3 product (column-by-column,
+// k = 0,1,2 summed left to right) so that the HIP kernel can reproduce every bit.
+template <class R>
+void preprocess(int P, int D, int M, const R* means, const R* scales, R mod, const R* rots, const R* opac,
+                const R* shs, const R* view, const R* proj, const R* campos, int W, int H, R tanx, R tany,
+                ViewState<R>& g) {
+    g.P = P; g.W = W; g.H = H;
+    g.gx = (W + TILE - 1) / TILE; g.gy = (H + TILE - 1) / TILE;
+    g.depth.assign(P, 0); g.means2D.assign(2 * (size_t)P, 0); g.cov3D.assign(6 * (size_t)P, 0);
+    g.conic_opacity.assign(4 * (size_t)P, 0); g.rgb.assign(3 * (size_t)P, 0);
+    g.radii.assign(P, 0); g.tiles_touched.assign(P, 0); g.rect.assign(4 * (size_t)P, 0);
+    g.clamped.assign(3 * (size_t)P, 0);
+    const R focal_x = R(W) / (R(2.0) * tanx);
+    const R focal_y = R(H) / (R(2.0) * tany);
+
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        const V3<R> p = { means[3 * i], means[3 * i + 1], means[3 * i + 2] };
+        // frustum test: only the near plane is active upstream
+        const V3<R> pv = transformPoint4x3(p, view);
+        if (pv.z <= R(0.2)) continue;
+        const V4<R> ph = transformPoint4x4(p, proj);
+        const R p_w = R(1.0) / (ph.w + R(0.0000001));
+        const R ppx = ph.x * p_w, ppy = ph.y * p_w;
+
+        // cov3D = (S Rg)^T (S Rg) with Rg filled column-wise, quaternion (r,x,y,z) NOT normalised
+        const R sx = mod * scales[3 * i], sy = mod * scales[3 * i + 1], sz = mod * scales[3 * i + 2];
+        const R r = rots[4 * i], x = rots[4 * i + 1], y = rots[4 * i + 2], z = rots[4 * i + 3];
+        R Rg[3][3];  // [col][row]
+        Rg[0][0] = R(1.0) - R(2.0) * (y * y + z * z); Rg[0][1] = R(2.0) * (x * y - r * z); Rg[0][2] = R(2.0) * (x * z + r * y);
+        Rg[1][0] = R(2.0) * (x * y + r * z); Rg[1][1] = R(1.0) - R(2.0) * (x * x + z * z); Rg[1][2] = R(2.0) * (y * z - r * x);
+        Rg[2][0] = R(2.0) * (x * z - r * y); Rg[2][1] = R(2.0) * (y * z + r * x); Rg[2][2] = R(1.0) - R(2.0) * (x * x + y * y);
+        R Mm[3][3];  // M = S * Rg : M[c][k] = s_k * Rg[c][k]
+        for (int c = 0; c < 3; c++) { Mm[c][0] = sx * Rg[c][0]; Mm[c][1] = sy * Rg[c][1]; Mm[c][2] = sz * Rg[c][2]; }
+        auto sig = [&](int c, int rr) { return Mm[rr][0] * Mm[c][0] + Mm[rr][1] * Mm[c][1] + Mm[rr][2] * Mm[c][2]; };
+        R c3[6] = { sig(0, 0), sig(0, 1), sig(0, 2), sig(1, 1), sig(1, 2), sig(2, 2) };
+        for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)i + k] = c3[k];
+
+        // cov2D (EWA): T = W*J (glm), cov = T^T Vrk^T T, +0.3 low-pass on the diagonal
+        V3<R> t = pv;
+        const R limx = R(1.3) * tanx, limy = R(1.3) * tany;
+        const R txtz = t.x / t.z, tytz = t.y / t.z;
+        t.x = std::min(limx, std::max(-limx, txtz)) * t.z;
+        t.y = std::min(limy, std::max(-limy, tytz)) * t.z;
+        const R J00 = focal_x / t.z, J02 = -(focal_x * t.x) / (t.z * t.z);
+        const R J11 = focal_y / t.z, J12 = -(focal_y * t.y) / (t.z * t.z);
+        R T[2][3];  // T[c][r], c = image axis, r = world axis;  W[k][r] = view[4r+k]
+        for (int rr = 0; rr < 3; rr++) {
+            T[0][rr] = view[4 * rr] * J00 + view[4 * rr + 2] * J02;
+            T[1][rr] = view[4 * rr + 1] * J11 + view[4 * rr + 2] * J12;
+        }
+        const R V[3][3] = { { c3[0], c3[1], c3[2] }, { c3[1], c3[3], c3[4] }, { c3[2], c3[4], c3[5] } };
+        R A[3][2];  // A[k][r] = sum_l T[r][l] * V[l][k]
+        for (int k = 0; k < 3; k++)
+            for (int rr = 0; rr < 2; rr++) A[k][rr] = T[rr][0] * V[0][k] + T[rr][1] * V[1][k] + T[rr][2] * V[2][k];
+        R ca = A[0][0] * T[0][0] + A[1][0] * T[0][1] + A[2][0] * T[0][2];
+        const R cb = A[0][1] * T[0][0] + A[1][1] * T[0][1] + A[2][1] * T[0][2];
+        R cc = A[0][1] * T[1][0] + A[1][1] * T[1][1] + A[2][1] * T[1][2];
+        ca += R(0.3); cc += R(0.3);
+
+        const R det = ca * cc - cb * cb;
+        if (det == R(0.0)) continue;
+        const R det_inv = R(1.0) / det;
+        const R conx = cc * det_inv, cony = -cb * det_inv, conz = ca * det_inv;
+        const R mid = R(0.5) * (ca + cc);
+        const R lambda1 = mid + std::sqrt(std::max(R(0.1), mid * mid - det));
+        const R lambda2 = mid - std::sqrt(std::max(R(0.1), mid * mid - det));
+        const R my_radius = std::ceil(R(3.0) * std::sqrt(std::max(lambda1, lambda2)));
+        const R px = ndc2Pix(ppx, W), py = ndc2Pix(ppy, H);
+        const int max_radius = (int)my_radius;
+        const int rminx = std::min(g.gx, std::max(0, (int)((px - R(max_radius)) / R(TILE))));
+        const int rminy = std::min(g.gy, std::max(0, (int)((py - R(max_radius)) / R(TILE))));
+        const int rmaxx = std::min(g.gx, std::max(0, (int)((px + R(max_radius) + R(TILE - 1)) / R(TILE))));
+        const int rmaxy = std::min(g.gy, std::max(0, (int)((py + R(max_radius) + R(TILE - 1)) / R(TILE))));
+        if ((rmaxx - rminx) * (rmaxy - rminy) == 0) continue;
+
+        // colour from SH (colors_precomp == nullptr, src/Trainer.cu:346)
+        V3<R> dir = { p.x - campos[0], p.y - campos[1], p.z - campos[2] };
+        const R len = std::sqrt(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+        dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+        const R* sh = shs + (size_t)i * M * 3;
+        R res[3];
+        for (int c = 0; c < 3; c++) {
+            R v = SH<R>::C0 * sh[c];
+            if (D > 0) {
+                const R X = dir.x, Y = dir.y, Z = dir.z;
+                v = v - SH<R>::C1 * Y * sh[3 + c] + SH<R>::C1 * Z * sh[6 + c] - SH<R>::C1 * X * sh[9 + c];
+                if (D > 1) {
+                    const R xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+                    v = v + SH<R>::C2[0] * xy * sh[12 + c] + SH<R>::C2[1] * yz * sh[15 + c] +
+                        SH<R>::C2[2] * (R(2.0) * zz - xx - yy) * sh[18 + c] + SH<R>::C2[3] * xz * sh[21 + c] +
+                        SH<R>::C2[4] * (xx - yy) * sh[24 + c];
+                    if (D > 2) {
+                        v = v + SH<R>::C3[0] * Y * (R(3.0) * xx - yy) * sh[27 + c] + SH<R>::C3[1] * xy * Z * sh[30 + c] +
+                            SH<R>::C3[2] * Y * (R(4.0) * zz - xx - yy) * sh[33 + c] +
+                            SH<R>::C3[3] * Z * (R(2.0) * zz - R(3.0) * xx - R(3.0) * yy) * sh[36 + c] +
+                            SH<R>::C3[4] * X * (R(4.0) * zz - xx - yy) * sh[39 + c] + SH<R>::C3[5] * Z * (xx - yy) * sh[42 + c] +
+                            SH<R>::C3[6] * X * (xx - R(3.0) * yy) * sh[45 + c];
+                    }
+                }
+            }
+            v += R(0.5);
+            g.clamped[3 * (size_t)i + c] = (v < R(0.0));
+            res[c] = std::max(v, R(0.0));
+        }
+        for (int c = 0; c < 3; c++) g.rgb[3 * (size_t)i + c] = res[c];
+        g.depth[i] = pv.z;
+        g.radii[i] = (int)my_radius;
+        g.means2D[2 * (size_t)i] = px; g.means2D[2 * (size_t)i + 1] = py;
+        g.conic_opacity[4 * (size_t)i] = conx; g.conic_opacity[4 * (size_t)i + 1] = cony;
+        g.conic_opacity[4 * (size_t)i + 2] = conz; g.conic_opacity[4 * (size_t)i + 3] = opac[i];
+        g.rect[4 * (size_t)i] = rminx; g.rect[4 * (size_t)i + 1] = rminy;
+        g.rect[4 * (size_t)i + 2] = rmaxx; g.rect[4 * (size_t)i + 3] = rmaxy;
+        g.tiles_touched[i] = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx));
+    }
+}
+
+// A.2-A.5 — inclusive scan, key duplication, stable sort by (tile<<32 | depth bits), tile ranges.
+template <class R> void bin_and_sort(ViewState<R>& g) {
+    const int P = g.P;
+    g.point_offsets.assign(P, 0);
+    uint32_t run = 0;
+    for (int i = 0; i < P; i++) { run += g.tiles_touched[i]; g.point_offsets[i] = run; }
+    const size_t Rn = run;
+    g.R_total = (int)Rn;
+    g.keys_unsorted.assign(Rn, 0); g.vals_unsorted.assign(Rn, 0);
+    for (int i = 0; i < P; i++) {
+        if (g.radii[i] <= 0) continue;
+        uint32_t off = (i == 0) ? 0 : g.point_offsets[i - 1];
+        const uint32_t* rc = &g.rect[4 * (size_t)i];
+        for (uint32_t y = rc[1]; y < rc[3]; y++)
+            for (uint32_t x = rc[0]; x < rc[2]; x++) {
+                uint64_t key = (uint64_t)(y * (uint32_t)g.gx + x);
+                key <<= 32;
+                key |= depth_bits((float)g.depth[i]);
+                g.keys_unsorted[off] = key; g.vals_unsorted[off] = (uint32_t)i; off++;
+            }
+    }
+    std::vector<uint32_t> perm(Rn);
+    for (size_t k = 0; k < Rn; k++) perm[k] = (uint32_t)k;
+    std::stable_sort(perm.begin(), perm.end(),
+                     [&](uint32_t a, uint32_t b) { return g.keys_unsorted[a] < g.keys_unsorted[b]; });
+    g.keys.resize(Rn); g.point_list.resize(Rn);
+    for (size_t k = 0; k < Rn; k++) { g.keys[k] = g.keys_unsorted[perm[k]]; g.point_list[k] = g.vals_unsorted[perm[k]]; }
+    const int T = g.gx * g.gy;
+    g.ranges.assign(2 * (size_t)T, 0);
+    for (size_t k = 0; k < Rn; k++) {
+        const uint32_t tile = (uint32_t)(g.keys[k] >> 32);
+        if (k == 0) g.ranges[2 * (size_t)tile] = 0;
+        else {
+            const uint32_t prev = (uint32_t)(g.keys[k - 1] >> 32);
+            if (prev != tile) { g.ranges[2 * (size_t)prev + 1] = (uint32_t)k; g.ranges[2 * (size_t)tile] = (uint32_t)k; }
+        }
+        if (k == Rn - 1) g.ranges[2 * (size_t)tile + 1] = (uint32_t)Rn;
+    }
+}
+
+// A.6 — front-to-back alpha compositing, one pixel at a time, integer pixel centres.
+template <class R> void render_forward(ViewState<R>& g, const R* bg, R* out_color) {
+    const int W = g.W, H = g.H;
+    const size_t N = (size_t)W * H;
+    g.final_T.assign(N, 0); g.n_contrib.assign(N, 0); g.margin.assign(N, 1.0f);
+    const int T = g.gx * g.gy;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < T; tile++) {
+        const int tx = tile % g.gx, ty = tile / g.gx;
+        const uint32_t beg = g.ranges[2 * (size_t)tile], end = g.ranges[2 * (size_t)tile + 1];
+        for (int py = ty * TILE; py < std::min(H, (ty + 1) * TILE); py++)
+            for (int px = tx * TILE; px < std::min(W, (tx + 1) * TILE); px++) {
+                const R pixfx = (R)px, pixfy = (R)py;
+                R Tt = R(1.0), C[3] = { 0, 0, 0 };
+                uint32_t contributor = 0, last = 0;
+                float marg = 1.0f;
+                for (uint32_t k = beg; k < end; k++) {
+                    contributor++;
+                    const uint32_t id = g.point_list[k];
+                    const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+                    const R* co = &g.conic_opacity[4 * (size_t)id];
+                    const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > R(0.0)) continue;
+                    const R alpha = std::min(R(0.99), co[3] * std::exp(power));
+                    marg = std::min(marg, (float)(std::fabs(alpha - R(1.0 / 255.0)) * R(255.0)));
+                    if (alpha < R(1.0) / R(255.0)) continue;
+                    const R test_T = Tt * (R(1.0) - alpha);
+                    marg = std::min(marg, (float)(std::fabs(test_T - R(0.0001)) * R(10000.0)));
+                    if (test_T < R(0.0001)) break;  // done: this entry is NOT applied
+                    for (int c = 0; c < 3; c++) C[c] += g.rgb[3 * (size_t)id + c] * alpha * Tt;
+                    Tt = test_T;
+                    last = contributor;
+                }
+                const size_t pix = (size_t)py * W + px;
+                g.final_T[pix] = Tt; g.n_contrib[pix] = last; g.margin[pix] = marg;
+                for (int c = 0; c < 3; c++) out_color[c * N + pix] = C[c] + Tt * bg[c];
+            }
+    }
+}
+
+// Per-splat outputs of the backward pass, reference buffer shapes (src/Trainer.cu:291-300).
+template <class R> struct Grads {
+    R *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+};
+
+// A.7 — reverse traversal.  The reference sums the per-pixel terms with float atomicAdd in
+// arbitrary order; here each (tile,entry) partial is summed in double in pixel order and the
+// partials are then added per splat in sorted-list order, i.e. the correctly rounded sum of the
+// same fp32 terms.  `abs9` (optional) receives sum|term| per splat for tolerance floors.
+template <class R>
+void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const Grads<R>& o, double* abs9) {
+    const int W = g.W, H = g.H, P = g.P;
+    const size_t N = (size_t)W * H;
+    const size_t Rn = g.point_list.size();
+    std::vector<double> part(Rn * 9, 0.0), partabs(abs9 ? Rn * 9 : 0, 0.0);
+    const int T = g.gx * g.gy;
+    const R ddelx_dx = R(0.5) * R(W), ddely_dy = R(0.5) * R(H);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < T; tile++) {
+        const int tx = tile % g.gx, ty = tile / g.gx;
+        const uint32_t beg = g.ranges[2 * (size_t)tile], end = g.ranges[2 * (size_t)tile + 1];
+        if (end <= beg) continue;
+        for (int py = ty * TILE; py < std::min(H, (ty + 1) * TILE); py++)
+            for (int px = tx * TILE; px < std::min(W, (tx + 1) * TILE); px++) {
+                const size_t pix = (size_t)py * W + px;
+                const R pixfx = (R)px, pixfy = (R)py;
+                const R T_final = g.final_T[pix];
+                R Tt = T_final;
+                const uint32_t last_contributor = g.n_contrib[pix];
+                R accum_rec[3] = { 0, 0, 0 }, last_color[3] = { 0, 0, 0 }, last_alpha = 0;
+                const R dpx[3] = { dL_dpix[pix], dL_dpix[N + pix], dL_dpix[2 * N + pix] };
+                uint32_t contributor = end - beg;
+                for (uint32_t k = end; k-- > beg;) {
+                    contributor--;
+                    if (contributor >= last_contributor) continue;
+                    const uint32_t id = g.point_list[k];
+                    const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+                    const R* co = &g.conic_opacity[4 * (size_t)id];
+                    const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > R(0.0)) continue;
+                    const R G = std::exp(power);
+                    const R alpha = std::min(R(0.99), co[3] * G);
+                    if (alpha < R(1.0) / R(255.0)) continue;
+                    Tt = Tt / (R(1.0) - alpha);
+                    const R dchannel_dcolor = alpha * Tt;
+                    R dL_dalpha = 0;
+                    double* pp = &part[(size_t)k * 9];
+                    double* pa = abs9 ? &partabs[(size_t)k * 9] : nullptr;
+                    for (int c = 0; c < 3; c++) {
+                        const R col = g.rgb[3 * (size_t)id + c];
+                        accum_rec[c] = last_alpha * last_color[c] + (R(1.0) - last_alpha) * accum_rec[c];
+                        last_color[c] = col;
+                        dL_dalpha += (col - accum_rec[c]) * dpx[c];
+                        const R term = dchannel_dcolor * dpx[c];
+                        pp[c] += (double)term; if (pa) pa[c] += std::fabs((double)term);
+                    }
+                    dL_dalpha *= Tt;
+                    last_alpha = alpha;
+                    R bg_dot = 0;
+                    for (int c = 0; c < 3; c++) bg_dot += bg[c] * dpx[c];
+                    dL_dalpha += (-T_final / (R(1.0) - alpha)) * bg_dot;
+                    const R dL_dG = co[3] * dL_dalpha;
+                    const R gdx = G * dx, gdy = G * dy;
+                    const R dG_ddelx = -gdx * co[0] - gdy * co[1];
+                    const R dG_ddely = -gdy * co[2] - gdx * co[1];
+                    const R t3 = dL_dG * dG_ddelx * ddelx_dx, t4 = dL_dG * dG_ddely * ddely_dy;
+                    const R t5 = R(-0.5) * gdx * dx * dL_dG, t6 = R(-0.5) * gdx * dy * dL_dG, t7 = R(-0.5) * gdy * dy * dL_dG;
+                    const R t8 = G * dL_dalpha;
+                    const R tt[6] = { t3, t4, t5, t6, t7, t8 };
+                    for (int q = 0; q < 6; q++) { pp[3 + q] += (double)tt[q]; if (pa) pa[3 + q] += std::fabs((double)tt[q]); }
+                }
+            }
+    }
+    std::vector<double> acc((size_t)P * 9, 0.0);
+    if (abs9) std::fill(abs9, abs9 + (size_t)P * 9, 0.0);
+    for (size_t k = 0; k < Rn; k++) {
+        const uint32_t id = g.point_list[k];
+        for (int q = 0; q < 9; q++) acc[(size_t)id * 9 + q] += part[k * 9 + q];
+        if (abs9) for (int q = 0; q < 9; q++) abs9[(size_t)id * 9 + q] += partabs[k * 9 + q];
+    }
+    for (int i = 0; i < P; i++) {
+        const double* a = &acc[(size_t)i * 9];
+        o.dL_dcolor[3 * (size_t)i] += (R)a[0]; o.dL_dcolor[3 * (size_t)i + 1] += (R)a[1]; o.dL_dcolor[3 * (size_t)i + 2] += (R)a[2];
+        o.dL_dmean2D[3 * (size_t)i] += (R)a[3]; o.dL_dmean2D[3 * (size_t)i + 1] += (R)a[4];
+        o.dL_dconic[4 * (size_t)i] += (R)a[5]; o.dL_dconic[4 * (size_t)i + 1] += (R)a[6]; o.dL_dconic[4 * (size_t)i + 3] += (R)a[7];
+        o.dL_dopacity[i] += (R)a[8];
+    }
+}
+
+// A.8 + A.9 — per-splat backward: conic -> cov2D -> cov3D & mean; mean2D -> mean; colour -> SH &
+// mean; cov3D -> scale & rotation (gradient w.r.t. the unnormalised quaternion).
+template <class R>
+void preprocess_backward(const ViewState<R>& g, int D, int M, const R* means, const R* scales, R mod, const R* rots,
+                         const R* shs, const R* view, const R* proj, const R* campos, R tanx, R tany,
+                         const Grads<R>& o) {
+    const int P = g.P, W = g.W, H = g.H;
+    const R focal_x = R(W) / (R(2.0) * tanx);
+    const R focal_y = R(H) / (R(2.0) * tany);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        if (!(g.radii[i] > 0)) continue;
+        const V3<R> mean = { means[3 * i], means[3 * i + 1], means[3 * i + 2] };
+        // ---- cov2D backward (kernel 1 upstream) ----
+        const R* c3 = &g.cov3D[6 * (size_t)i];
+        const R gcx = o.dL_dconic[4 * (size_t)i], gcy = o.dL_dconic[4 * (size_t)i + 1], gcz = o.dL_dconic[4 * (size_t)i + 3];
+        V3<R> t = transformPoint4x3(mean, view);
+        const R limx = R(1.3) * tanx, limy = R(1.3) * tany;
+        const R txtz = t.x / t.z, tytz = t.y / t.z;
+        t.x = std::min(limx, std::max(-limx, txtz)) * t.z;
+        t.y = std::min(limy, std::max(-limy, tytz)) * t.z;
+        const R x_grad_mul = (txtz < -limx || txtz > limx) ? R(0) : R(1);
+        const R y_grad_mul = (tytz < -limy || tytz > limy) ? R(0) : R(1);
+        const R J00 = focal_x / t.z, J02 = -(focal_x * t.x) / (t.z * t.z);
+        const R J11 = focal_y / t.z, J12 = -(focal_y * t.y) / (t.z * t.z);
+        R T[2][3];
+        for (int rr = 0; rr < 3; rr++) {
+            T[0][rr] = view[4 * rr] * J00 + view[4 * rr + 2] * J02;
+            T[1][rr] = view[4 * rr + 1] * J11 + view[4 * rr + 2] * J12;
+        }
+        const R V[3][3] = { { c3[0], c3[1], c3[2] }, { c3[1], c3[3], c3[4] }, { c3[2], c3[4], c3[5] } };
+        R A[3][2];
+        for (int k = 0; k < 3; k++)
+            for (int rr = 0; rr < 2; rr++) A[k][rr] = T[rr][0] * V[0][k] + T[rr][1] * V[1][k] + T[rr][2] * V[2][k];
+        const R a = A[0][0] * T[0][0] + A[1][0] * T[0][1] + A[2][0] * T[0][2] + R(0.3);
+        const R b = A[0][1] * T[0][0] + A[1][1] * T[0][1] + A[2][1] * T[0][2];
+        const R c = A[0][1] * T[1][0] + A[1][1] * T[1][1] + A[2][1] * T[1][2] + R(0.3);
+        const R denom = a * c - b * b;
+        R dL_da = 0, dL_db = 0, dL_dc = 0;
+        const R denom2inv = R(1.0) / ((denom * denom) + R(0.0000001));
+        R* dcov = &o.dL_dcov3D[6 * (size_t)i];
+        if (denom2inv != R(0)) {
+            dL_da = denom2inv * (-c * c * gcx + R(2) * b * c * gcy + (denom - a * c) * gcz);
+            dL_dc = denom2inv * (-a * a * gcz + R(2) * a * b * gcy + (denom - a * c) * gcx);
+            dL_db = denom2inv * R(2) * (b * c * gcx - (denom + R(2) * b * b) * gcy + a * b * gcz);
+            dcov[0] = T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
+            dcov[3] = T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
+            dcov[5] = T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
+            dcov[1] = R(2) * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + R(2) * T[1][0] * T[1][1] * dL_dc;
+            dcov[2] = R(2) * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + R(2) * T[1][0] * T[1][2] * dL_dc;
+            dcov[4] = R(2) * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + R(2) * T[1][1] * T[1][2] * dL_dc;
+        } else {
+            for (int k = 0; k < 6; k++) dcov[k] = 0;
+        }
+        // dL/dT (rows 0,1), then dL/dJ, then dL/dt, then dL/dmean (assignment, not accumulation)
+        R dT[2][3];
+        for (int k = 0; k < 3; k++) {
+            const R tv0 = T[0][0] * V[k][0] + T[0][1] * V[k][1] + T[0][2] * V[k][2];
+            const R tv1 = T[1][0] * V[k][0] + T[1][1] * V[k][1] + T[1][2] * V[k][2];
+            dT[0][k] = R(2) * tv0 * dL_da + tv1 * dL_db;
+            dT[1][k] = R(2) * tv1 * dL_dc + tv0 * dL_db;
+        }
+        // W[k][r] = view[4r+k]; dL_dJ(c,k) = sum_r W[k][r] * dT[c][r]
+        const R dJ00 = view[0] * dT[0][0] + view[4] * dT[0][1] + view[8] * dT[0][2];
+        const R dJ02 = view[2] * dT[0][0] + view[6] * dT[0][1] + view[10] * dT[0][2];
+        const R dJ11 = view[1] * dT[1][0] + view[5] * dT[1][1] + view[9] * dT[1][2];
+        const R dJ12 = view[2] * dT[1][0] + view[6] * dT[1][1] + view[10] * dT[1][2];
+        const R tz = R(1) / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+        const R dtx = x_grad_mul * -focal_x * tz2 * dJ02;
+        const R dty = y_grad_mul * -focal_y * tz2 * dJ12;
+        const R dtz = -focal_x * tz2 * dJ00 - focal_y * tz2 * dJ11 + (R(2) * focal_x * t.x) * tz3 * dJ02 +
+                      (R(2) * focal_y * t.y) * tz3 * dJ12;
+        V3<R> dmean = transformVec4x3Transpose(V3<R>{ dtx, dty, dtz }, view);
+
+        // ---- kernel 2 upstream: projection of mean2D gradient ----
+        const V4<R> mh = transformPoint4x4(mean, proj);
+        const R m_w = R(1.0) / (mh.w + R(0.0000001));
+        const R mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+        const R mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+        const R g2x = o.dL_dmean2D[3 * (size_t)i], g2y = o.dL_dmean2D[3 * (size_t)i + 1];
+        dmean.x += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        dmean.y += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        dmean.z += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+
+        // ---- SH backward ----
+        {
+            const V3<R> dir_orig = { mean.x - campos[0], mean.y - campos[1], mean.z - campos[2] };
+            const R len = std::sqrt(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+            const R X = dir_orig.x / len, Y = dir_orig.y / len, Z = dir_orig.z / len;
+            const R* sh = shs + (size_t)i * M * 3;
+            R* dsh = o.dL_dsh + (size_t)i * M * 3;
+            R dRGB[3];
+            for (int ch = 0; ch < 3; ch++) dRGB[ch] = o.dL_dcolor[3 * (size_t)i + ch] * (g.clamped[3 * (size_t)i + ch] ? R(0) : R(1));
+            R ddir[3] = { 0, 0, 0 };
+            for (int ch = 0; ch < 3; ch++) {
+                const R dl = dRGB[ch];
+                R dx_ = 0, dy_ = 0, dz_ = 0;
+                dsh[ch] = SH<R>::C0 * dl;
+                if (D > 0) {
+                    dsh[3 + ch] = (-SH<R>::C1 * Y) * dl; dsh[6 + ch] = (SH<R>::C1 * Z) * dl; dsh[9 + ch] = (-SH<R>::C1 * X) * dl;
+                    dx_ = -SH<R>::C1 * sh[9 + ch]; dy_ = -SH<R>::C1 * sh[3 + ch]; dz_ = SH<R>::C1 * sh[6 + ch];
+                    if (D > 1) {
+                        const R xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+                        dsh[12 + ch] = (SH<R>::C2[0] * xy) * dl; dsh[15 + ch] = (SH<R>::C2[1] * yz) * dl;
+                        dsh[18 + ch] = (SH<R>::C2[2] * (R(2) * zz - xx - yy)) * dl; dsh[21 + ch] = (SH<R>::C2[3] * xz) * dl;
+                        dsh[24 + ch] = (SH<R>::C2[4] * (xx - yy)) * dl;
+                        dx_ += SH<R>::C2[0] * Y * sh[12 + ch] + SH<R>::C2[2] * R(2) * -X * sh[18 + ch] + SH<R>::C2[3] * Z * sh[21 + ch] + SH<R>::C2[4] * R(2) * X * sh[24 + ch];
+                        dy_ += SH<R>::C2[0] * X * sh[12 + ch] + SH<R>::C2[1] * Z * sh[15 + ch] + SH<R>::C2[2] * R(2) * -Y * sh[18 + ch] + SH<R>::C2[4] * R(2) * -Y * sh[24 + ch];
+                        dz_ += SH<R>::C2[1] * Y * sh[15 + ch] + SH<R>::C2[2] * R(2) * R(2) * Z * sh[18 + ch] + SH<R>::C2[3] * X * sh[21 + ch];
+                        if (D > 2) {
+                            dsh[27 + ch] = (SH<R>::C3[0] * Y * (R(3) * xx - yy)) * dl;
+                            dsh[30 + ch] = (SH<R>::C3[1] * xy * Z) * dl;
+                            dsh[33 + ch] = (SH<R>::C3[2] * Y * (R(4) * zz - xx - yy)) * dl;
+                            dsh[36 + ch] = (SH<R>::C3[3] * Z * (R(2) * zz - R(3) * xx - R(3) * yy)) * dl;
+                            dsh[39 + ch] = (SH<R>::C3[4] * X * (R(4) * zz - xx - yy)) * dl;
+                            dsh[42 + ch] = (SH<R>::C3[5] * Z * (xx - yy)) * dl;
+                            dsh[45 + ch] = (SH<R>::C3[6] * X * (xx - R(3) * yy)) * dl;
+                            dx_ += SH<R>::C3[0] * sh[27 + ch] * R(3) * R(2) * xy + SH<R>::C3[1] * sh[30 + ch] * yz +
+                                   SH<R>::C3[2] * sh[33 + ch] * -R(2) * xy + SH<R>::C3[3] * sh[36 + ch] * -R(3) * R(2) * xz +
+                                   SH<R>::C3[4] * sh[39 + ch] * (-R(3) * xx + R(4) * zz - yy) + SH<R>::C3[5] * sh[42 + ch] * R(2) * xz +
+                                   SH<R>::C3[6] * sh[45 + ch] * R(3) * (xx - yy);
+                            dy_ += SH<R>::C3[0] * sh[27 + ch] * R(3) * (xx - yy) + SH<R>::C3[1] * sh[30 + ch] * xz +
+                                   SH<R>::C3[2] * sh[33 + ch] * (-R(3) * yy + R(4) * zz - xx) + SH<R>::C3[3] * sh[36 + ch] * -R(3) * R(2) * yz +
+                                   SH<R>::C3[4] * sh[39 + ch] * -R(2) * xy + SH<R>::C3[5] * sh[42 + ch] * -R(2) * yz +
+                                   SH<R>::C3[6] * sh[45 + ch] * -R(3) * R(2) * xy;
+                            dz_ += SH<R>::C3[1] * sh[30 + ch] * xy + SH<R>::C3[2] * sh[33 + ch] * R(4) * R(2) * yz +
+                                   SH<R>::C3[3] * sh[36 + ch] * R(3) * (R(2) * zz - xx - yy) + SH<R>::C3[4] * sh[39 + ch] * R(4) * R(2) * xz +
+                                   SH<R>::C3[5] * sh[42 + ch] * (xx - yy);
+                        }
+                    }
+                }
+                ddir[0] += dx_ * dl; ddir[1] += dy_ * dl; ddir[2] += dz_ * dl;
+            }
+            // through the normalisation (dnormvdv upstream)
+            const R sum2 = dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z;
+            const R invsum32 = R(1.0) / std::sqrt(sum2 * sum2 * sum2);
+            const V3<R>& v = dir_orig;
+            dmean.x += ((+sum2 - v.x * v.x) * ddir[0] - v.y * v.x * ddir[1] - v.z * v.x * ddir[2]) * invsum32;
+            dmean.y += (-v.x * v.y * ddir[0] + (sum2 - v.y * v.y) * ddir[1] - v.z * v.y * ddir[2]) * invsum32;
+            dmean.z += (-v.x * v.z * ddir[0] - v.y * v.z * ddir[1] + (sum2 - v.z * v.z) * ddir[2]) * invsum32;
+        }
+        o.dL_dmean3D[3 * (size_t)i] = dmean.x; o.dL_dmean3D[3 * (size_t)i + 1] = dmean.y; o.dL_dmean3D[3 * (size_t)i + 2] = dmean.z;
+
+        // ---- cov3D backward: Sigma = M^T M, M = S Rg ----
+        {
+            const R sx = mod * scales[3 * i], sy = mod * scales[3 * i + 1], sz = mod * scales[3 * i + 2];
+            const R s[3] = { sx, sy, sz };
+            const R r = rots[4 * i], x = rots[4 * i + 1], y = rots[4 * i + 2], z = rots[4 * i + 3];
+            R Rg[3][3];
+            Rg[0][0] = R(1.0) - R(2.0) * (y * y + z * z); Rg[0][1] = R(2.0) * (x * y - r * z); Rg[0][2] = R(2.0) * (x * z + r * y);
+            Rg[1][0] = R(2.0) * (x * y + r * z); Rg[1][1] = R(1.0) - R(2.0) * (x * x + z * z); Rg[1][2] = R(2.0) * (y * z - r * x);
+            Rg[2][0] = R(2.0) * (x * z - r * y); Rg[2][1] = R(2.0) * (y * z + r * x); Rg[2][2] = R(1.0) - R(2.0) * (x * x + y * y);
+            R Mm[3][3];
+            for (int cc = 0; cc < 3; cc++) for (int k = 0; k < 3; k++) Mm[cc][k] = s[k] * Rg[cc][k];
+            // symmetric dL/dSigma with halved off-diagonals
+            const R dS[3][3] = { { dcov[0], R(0.5) * dcov[1], R(0.5) * dcov[2] },
+                                 { R(0.5) * dcov[1], dcov[3], R(0.5) * dcov[4] },
+                                 { R(0.5) * dcov[2], R(0.5) * dcov[4], dcov[5] } };
+            // dL_dM = 2 * M * dSigma (glm): dM[c][k] = 2 * sum_j M[j][k] * dS[c][j]
+            R dM[3][3];
+            for (int cc = 0; cc < 3; cc++)
+                for (int k = 0; k < 3; k++) dM[cc][k] = R(2.0) * (Mm[0][k] * dS[cc][0] + Mm[1][k] * dS[cc][1] + Mm[2][k] * dS[cc][2]);
+            // Rt[k][c] = Rg[c][k], dMt[k][c] = dM[c][k]; dL_dscale_k = dot(Rt[k], dMt[k])
+            R dMt[3][3];
+            for (int k = 0; k < 3; k++) for (int cc = 0; cc < 3; cc++) dMt[k][cc] = dM[cc][k];
+            for (int k = 0; k < 3; k++)
+                o.dL_dscale[3 * (size_t)i + k] = Rg[0][k] * dMt[k][0] + Rg[1][k] * dMt[k][1] + Rg[2][k] * dMt[k][2];
+            for (int k = 0; k < 3; k++) for (int cc = 0; cc < 3; cc++) dMt[k][cc] *= s[k];
+            R* dq = &o.dL_drot[4 * (size_t)i];
+            dq[0] = R(2) * z * (dMt[0][1] - dMt[1][0]) + R(2) * y * (dMt[2][0] - dMt[0][2]) + R(2) * x * (dMt[1][2] - dMt[2][1]);
+            dq[1] = R(2) * y * (dMt[1][0] + dMt[0][1]) + R(2) * z * (dMt[2][0] + dMt[0][2]) + R(2) * r * (dMt[1][2] - dMt[2][1]) - R(4) * x * (dMt[2][2] + dMt[1][1]);
+            dq[2] = R(2) * x * (dMt[1][0] + dMt[0][1]) + R(2) * r * (dMt[2][0] - dMt[0][2]) + R(2) * z * (dMt[1][2] + dMt[2][1]) - R(4) * y * (dMt[2][2] + dMt[0][0]);
+            dq[3] = R(2) * r * (dMt[0][1] - dMt[1][0]) + R(2) * x * (dMt[2][0] + dMt[0][2]) + R(2) * y * (dMt[1][2] + dMt[2][1]) - R(4) * z * (dMt[1][1] + dMt[0][0]);
+        }
+    }
+}
+
+template <class R> struct State { ViewState<R> v; };
+
+template <class R>
+int forward_impl(State<R>* st, int P, int D, int M, const R* bg, int W, int H, const R* means, const R* shs,
+                 const R* opac, const R* scales, R mod, const R* rots, const R* view, const R* proj, const R* campos,
+                 R tanx, R tany, R* out_color) {
+    preprocess<R>(P, D, M, means, scales, mod, rots, opac, shs, view, proj, campos, W, H, tanx, tany, st->v);
+    bin_and_sort<R>(st->v);
+    render_forward<R>(st->v, bg, out_color);
+    return st->v.R_total;
+}
+
+template <class R>
+void backward_impl(State<R>* st, int D, int M, const R* bg, const R* means, const R* shs, const R* scales, R mod,
+                   const R* rots, const R* view, const R* proj, const R* campos, R tanx, R tany, const R* dL_dpix,
+                   const Grads<R>& o, double* abs9) {
+    render_backward<R>(st->v, bg, dL_dpix, o, abs9);
+    preprocess_backward<R>(st->v, D, M, means, scales, mod, rots, shs, view, proj, campos, tanx, tany, o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// glm restatements used by Camera.cpp / densify (glm 0.9.9 semantics, right-handed, -1..1 depth)
+// ---------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+inline f3 sub3(f3 a, f3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline f3 cross3(f3 a, f3 b) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
+inline f3 norm3(f3 a) { const float inv = 1.0f / std::sqrt(dot3(a, a)); return { a.x * inv, a.y * inv, a.z * inv }; }
+
+// glm::mat3_cast of quat (w,x,y,z), no normalisation; out[col][row]
+inline void quat_to_mat3(float w, float x, float y, float z, float out[3][3]) {
+    const float qxx = x * x, qyy = y * y, qzz = z * z, qxz = x * z, qxy = x * y, qyz = y * z, qwx = w * x, qwy = w * y, qwz = w * z;
+    out[0][0] = 1.0f - 2.0f * (qyy + qzz); out[0][1] = 2.0f * (qxy + qwz); out[0][2] = 2.0f * (qxz - qwy);
+    out[1][0] = 2.0f * (qxy - qwz); out[1][1] = 1.0f - 2.0f * (qxx + qzz); out[1][2] = 2.0f * (qyz + qwx);
+    out[2][0] = 2.0f * (qxz + qwy); out[2][1] = 2.0f * (qyz - qwx); out[2][2] = 1.0f - 2.0f * (qxx + qyy);
+}
+
+}  // namespace
+
+// =============================================================================================
+// C interface (ctypes)
+// =============================================================================================
+extern "C" {
+
+struct orc_state { State<float> f; State<double> d; };
+
+orc_state* orc_state_new() { return new orc_state(); }
+void orc_state_free(orc_state* s) { delete s; }
+
+int orc_num_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+// CudaRasterizer::Rasterizer::forward as called at src/Trainer.cu:334-360 (colors_precomp = cov3D_precomp =
+// nullptr, prefiltered = false).  Returns num_rendered.
+int orc_forward_f32(orc_state* s, int P, int D, int M, const float* bg, int W, int H, const float* means,
+                    const float* shs, const float* opac, const float* scales, float mod, const float* rots,
+                    const float* view, const float* proj, const float* campos, float tanx, float tany,
+                    float* out_color) {
+    return forward_impl<float>(&s->f, P, D, M, bg, W, H, means, shs, opac, scales, mod, rots, view, proj, campos, tanx, tany, out_color);
+}
+int orc_forward_f64(orc_state* s, int P, int D, int M, const double* bg, int W, int H, const double* means,
+                    const double* shs, const double* opac, const double* scales, double mod, const double* rots,
+                    const double* view, const double* proj, const double* campos, double tanx, double tany,
+                    double* out_color) {
+    return forward_impl<double>(&s->d, P, D, M, bg, W, H, means, shs, opac, scales, mod, rots, view, proj, campos, tanx, tany, out_color);
+}
+
+// CudaRasterizer::Rasterizer::backward as called at src/Trainer.cu:378-412.  Output buffers are
+// accumulated into where the reference's are (caller pre-zeroes, src/Trainer.cu:366-375).
+void orc_backward_f32(orc_state* s, int D, int M, const float* bg, const float* means, const float* shs,
+                      const float* scales, float mod, const float* rots, const float* view, const float* proj,
+                      const float* campos, float tanx, float tany, const float* dL_dpix, float* dL_dmean2D,
+                      float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                      float* dL_dsh, float* dL_dscale, float* dL_drot, double* abs9) {
+    Grads<float> o{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
+    backward_impl<float>(&s->f, D, M, bg, means, shs, scales, mod, rots, view, proj, campos, tanx, tany, dL_dpix, o, abs9);
+}
+void orc_backward_f64(orc_state* s, int D, int M, const double* bg, const double* means, const double* shs,
+                      const double* scales, double mod, const double* rots, const double* view, const double* proj,
+                      const double* campos, double tanx, double tany, const double* dL_dpix, double* dL_dmean2D,
+                      double* dL_dconic, double* dL_dopacity, double* dL_dcolor, double* dL_dmean3D, double* dL_dcov3D,
+                      double* dL_dsh, double* dL_dscale, double* dL_drot) {
+    Grads<double> o{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
+    backward_impl<double>(&s->d, D, M, bg, means, shs, scales, mod, rots, view, proj, campos, tanx, tany, dL_dpix, o, nullptr);
+}
+
+// Copy a named piece of the fp32 per-view state out.  Returns bytes written, or -1 (unknown name /
+// dst too small).
+long orc_get(orc_state* s, const char* name, void* dst, long cap_bytes) {
+    const ViewState<float>& g = s->f.v;
+    const std::string n(name);
+    const void* src = nullptr; size_t bytes = 0; bool found = false;
+#define ORC_FIELD(field) if (n == #field) { found = true; src = g.field.data(); bytes = g.field.size() * sizeof(g.field[0]); }
+    ORC_FIELD(depth) ORC_FIELD(means2D) ORC_FIELD(cov3D) ORC_FIELD(conic_opacity) ORC_FIELD(rgb) ORC_FIELD(radii)
+    ORC_FIELD(tiles_touched) ORC_FIELD(point_offsets) ORC_FIELD(rect) ORC_FIELD(clamped) ORC_FIELD(keys_unsorted)
+    ORC_FIELD(keys) ORC_FIELD(vals_unsorted) ORC_FIELD(point_list) ORC_FIELD(ranges) ORC_FIELD(final_T)
+    ORC_FIELD(n_contrib) ORC_FIELD(margin)
+#undef ORC_FIELD
+    if (!found || (long)bytes > cap_bytes) return -1;
+    if (bytes) std::memcpy(dst, src, bytes);
+    return (long)bytes;
+}
+int orc_num_rendered(orc_state* s) { return s->f.v.R_total; }
+
+// ---------------------------------------------------------------------------------------------
+// The reference's own four kernels (src/Trainer.cu:19-101), verbatim semantics.
+// ---------------------------------------------------------------------------------------------
+// imageFloatToInt, src/Trainer.cu:19-29  (x256, clamp, alpha 0xFF)
+void orc_image_float_to_int(const float* src, uint32_t* fb, int w, int h) {
+    const size_t N = (size_t)w * h;
+    for (size_t i = 0; i < N; i++) {
+        auto q = [](float v) { return (uint32_t)std::min(255, std::max(0, (int)(v * 256.0f))); };
+        fb[i] = (q(src[i]) << 0) + (q(src[i + N]) << 8) + (q(src[i + 2 * N]) << 16) + (0xFFu << 24);
+    }
+}
+// imageIntToLoss, src/Trainer.cu:33-44  (truth/255 - render)
+void orc_image_int_to_loss(const uint32_t* truth, const float* rast, float* loss, int w, int h) {
+    const size_t N = (size_t)w * h;
+    for (size_t i = 0; i < N; i++) {
+        const uint32_t t = truth[i];
+        loss[i] = ((float)(t & 0xFF) / 255.0f) - rast[i];
+        loss[i + N] = ((float)((t >> 8) & 0xFF) / 255.0f) - rast[i + N];
+        loss[i + 2 * N] = ((float)((t >> 16) & 0xFF) / 255.0f) - rast[i + 2 * N];
+    }
+}
+// accumulateGradients, src/Trainer.cu:47-77
+void orc_accumulate(float* var, float* aLoc, float* aSh, float* aScale, float* aOpac, float* aRot, const float* gLoc,
+                    const float* gSh, const float* gScale, const float* gOpac, const float* gRot, float samples, int M,
+                    int n) {
+    for (int i = 0; i < n; i++) {
+        var[i] += sqrtf((gLoc[i * 3] * gLoc[i * 3]) + (gLoc[i * 3 + 1] * gLoc[i * 3 + 1]) + (gLoc[i * 3 + 2] * gLoc[i * 3 + 2])) / samples;
+        for (int f = 0; f < 3; f++) aLoc[i * 3 + f] += gLoc[i * 3 + f] / samples;
+        for (int f = 0; f < 3 * M; f++) aSh[(size_t)i * 3 * M + f] += gSh[(size_t)i * 3 * M + f] / samples;
+        for (int f = 0; f < 3; f++) aScale[i * 3 + f] += gScale[i * 3 + f] / samples;
+        aOpac[i] += gOpac[i] / samples;
+        for (int f = 0; f < 4; f++) aRot[i * 4 + f] += gRot[i * 4 + f] / samples;
+    }
+}
+// applyGradients, src/Trainer.cu:81-101
+void orc_apply_sgd(float* loc, float* sh, float* scale, float* opac, float* rot, const float* gLoc, const float* gSh,
+                   const float* gScale, const float* gOpac, const float* gRot, float lr, float lrSh, float lrScale,
+                   float lrOpacity, float lrRotation, float maxScale, int M, int count) {
+    for (int i = 0; i < count; i++) {
+        for (int f = 0; f < 3; f++) loc[i * 3 + f] += gLoc[i * 3 + f] * lr;
+        for (int f = 0; f < M * 3; f++) sh[(size_t)i * 3 * M + f] += gSh[(size_t)i * 3 * M + f] * lrSh;
+        for (int f = 0; f < 3; f++) {
+            scale[i * 3 + f] += gScale[i * 3 + f] * lrScale;
+            scale[i * 3 + f] = std::min(maxScale, std::max(0.0f, scale[i * 3 + f]));
+        }
+        opac[i] = std::min(1.0f, std::max(0.0f, opac[i] + gOpac[i] * lrOpacity));
+        for (int f = 0; f < 4; f++) rot[i * 4 + f] += gRot[i * 4 + f] * lrRotation;
+    }
+}
+// Build-side extension (BASELINE.json "fwd+bwd+Adam"; the reference has no Adam):
+// Adam *ascent* on the averaged residual gradient, followed by the reference's clamps.
+// Layout of m / v: [loc 3P | sh 3MP | scale 3P | opac P | rot 4P], step counter t >= 1.
+void orc_apply_adam(float* loc, float* sh, float* scale, float* opac, float* rot, const float* gLoc, const float* gSh,
+                    const float* gScale, const float* gOpac, const float* gRot, float* m, float* v, int t, float lr,
+                    float lrSh, float lrScale, float lrOpacity, float lrRotation, float maxScale, float b1, float b2,
+                    float eps, int M, int count) {
+    const float bc1 = 1.0f - std::pow(b1, (float)t), bc2 = 1.0f - std::pow(b2, (float)t);
+    auto upd = [&](float& p, float g, float& mm, float& vv, float lrate) {
+        mm = b1 * mm + (1.0f - b1) * g;
+        vv = b2 * vv + (1.0f - b2) * g * g;
+        const float mh = mm / bc1, vh = vv / bc2;
+        p = p + lrate * (mh / (std::sqrt(vh) + eps));
+    };
+    const size_t P = (size_t)count;
+    float *mLoc = m, *mSh = m + 3 * P, *mScale = mSh + 3 * M * P, *mOpac = mScale + 3 * P, *mRot = mOpac + P;
+    float *vLoc = v, *vSh = v + 3 * P, *vScale = vSh + 3 * M * P, *vOpac = vScale + 3 * P, *vRot = vOpac + P;
+    for (size_t i = 0; i < P; i++) {
+        for (int f = 0; f < 3; f++) upd(loc[i * 3 + f], gLoc[i * 3 + f], mLoc[i * 3 + f], vLoc[i * 3 + f], lr);
+        for (int f = 0; f < 3 * M; f++) upd(sh[i * 3 * M + f], gSh[i * 3 * M + f], mSh[i * 3 * M + f], vSh[i * 3 * M + f], lrSh);
+        for (int f = 0; f < 3; f++) {
+            upd(scale[i * 3 + f], gScale[i * 3 + f], mScale[i * 3 + f], vScale[i * 3 + f], lrScale);
+            scale[i * 3 + f] = std::min(maxScale, std::max(0.0f, scale[i * 3 + f]));
+        }
+        upd(opac[i], gOpac[i], mOpac[i], vOpac[i], lrOpacity);
+        opac[i] = std::min(1.0f, std::max(0.0f, opac[i]));
+        for (int f = 0; f < 4; f++) upd(rot[i * 4 + f], gRot[i * 4 + f], mRot[i * 4 + f], vRot[i * 4 + f], lrRotation);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Trainer::train, per-view loop (src/Trainer.cu:303-425): forward, loss, backward, accumulate.
+// views: V records of 40 floats {view[16], projview[16], campos[3], tanfovx, tanfovy, bg[3]}
+// (the values the reference builds at src/Trainer.cu:317-326,355-356).  avg*/var are accumulated
+// into (the caller zeroes them as src/Trainer.cu:304-309 does).  `samples` is S = 2*#cameras.
+// ---------------------------------------------------------------------------------------------
+void orc_train_views(int P, int D, int M, int W, int H, int V, const float* loc, const float* sh, const float* scale,
+                     const float* opac, const float* rot, const float* views, const uint32_t* truths, float samples,
+                     float* var, float* aLoc, float* aSh, float* aScale, float* aOpac, float* aRot, int* num_rendered,
+                     float* out_images) {
+    const size_t N = (size_t)W * H;
+    std::vector<float> rast(3 * N), loss(3 * N);
+    std::vector<float> gLoc(3 * (size_t)P), gSh(3 * (size_t)M * P), gScale(3 * (size_t)P), gOpac(P), gRot(4 * (size_t)P);
+    std::vector<float> gMean2D(3 * (size_t)P), gConic(4 * (size_t)P), gColor(3 * (size_t)P), gCov3D(6 * (size_t)P);
+    orc_state* st = orc_state_new();
+    for (int v = 0; v < V; v++) {
+        const float* vw = views + (size_t)v * 40;
+        const float *view = vw, *projview = vw + 16, *campos = vw + 32, *bg = vw + 37;
+        const float tanx = vw[35], tany = vw[36];
+        const int R = orc_forward_f32(st, P, D, M, bg, W, H, loc, sh, opac, scale, 1.0f, rot, view, projview, campos, tanx, tany, rast.data());
+        if (num_rendered) num_rendered[v] = R;
+        if (out_images) std::memcpy(out_images + (size_t)v * 3 * N, rast.data(), 3 * N * sizeof(float));
+        orc_image_int_to_loss(truths + (size_t)v * N, rast.data(), loss.data(), W, H);
+        auto zero = [](std::vector<float>& a) { std::fill(a.begin(), a.end(), 0.0f); };
+        zero(gLoc); zero(gSh); zero(gScale); zero(gOpac); zero(gRot); zero(gMean2D); zero(gConic); zero(gColor); zero(gCov3D);
+        orc_backward_f32(st, D, M, bg, loc, sh, scale, 1.0f, rot, view, projview, campos, tanx, tany, loss.data(),
+                         gMean2D.data(), gConic.data(), gOpac.data(), gColor.data(), gLoc.data(), gCov3D.data(),
+                         gSh.data(), gScale.data(), gRot.data(), nullptr);
+        orc_accumulate(var, aLoc, aSh, aScale, aOpac, aRot, gLoc.data(), gSh.data(), gScale.data(), gOpac.data(), gRot.data(), samples, M, P);
+    }
+    orc_state_free(st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Densify / prune, src/Trainer.cu:437-542.  The reference iterates std::unordered_set<int>
+// (implementation-defined order); this restatement iterates in ascending splat index.
+// quat_xyzw != 0 models glm's default quaternion member order {x,y,z,w}: glm::quat(r0,r1,r2,r3)
+// is the (w,x,y,z) constructor and memcpy(&rotPre[0]) then writes {r1,r2,r3,r0} back
+// (src/Trainer.cu:463,493-494); quat_xyzw == 0 models GLM_FORCE_QUAT_DATA_WXYZ (no permutation).
+// Arrays are ModelSplatsHost buffers sized to `capacity`; returns the new count.
+// ---------------------------------------------------------------------------------------------
+int orc_densify(float* loc, float* sh, float* scale, float* opac, float* rot, int count, int capacity, int M,
+                const float* var, const float* gradLoc, float cullOpacity, float cullSize, float densifyVariance,
+                float splitSize, float splitDistance, float splitScale, float cloneDistance, int quat_xyzw) {
+    std::set<int> toSplit, toClone, toRemove;
+    auto len3 = [](float a, float b, float c) { return std::sqrt(a * a + b * b + c * c); };
+    for (int i = 0; i < count; i++) {
+        const float sizeMag = len3(scale[i * 3], scale[i * 3 + 1], scale[i * 3 + 2]);
+        if (opac[i] <= cullOpacity || sizeMag < cullSize) toRemove.insert(i);
+        else if (var[i] - len3(gradLoc[i * 3], gradLoc[i * 3 + 1], gradLoc[i * 3 + 2]) > densifyVariance) {
+            if (sizeMag > splitSize) toSplit.insert(i); else toClone.insert(i);
+        }
+    }
+    auto copy = [&](int to, int from) {  // ModelSplatsHost::copy, src/ModelSplatsHost.cpp:79-91
+        std::memcpy(&loc[to * 3], &loc[from * 3], 12);
+        for (int k = 0; k < M * 3; k++) sh[(size_t)to * 3 * M + k] = sh[(size_t)from * 3 * M + k];
+        std::memcpy(&scale[to * 3], &scale[from * 3], 12);
+        opac[to] = opac[from];
+        std::memcpy(&rot[to * 4], &rot[from * 4], 16);
+    };
+    for (int i : toSplit) {
+        if (count >= capacity) continue;
+        const float lp[3] = { loc[i * 3], loc[i * 3 + 1], loc[i * 3 + 2] };
+        const float sp[3] = { scale[i * 3], scale[i * 3 + 1], scale[i * 3 + 2] };
+        const float qw = rot[i * 4], qx = rot[i * 4 + 1], qy = rot[i * 4 + 2], qz = rot[i * 4 + 3];
+        float so[4] = { sp[0], sp[1], sp[2], 1.0f };
+        if (sp[0] > sp[1] && sp[0] > sp[2]) { so[1] *= 0.0f; so[2] *= 0.0f; }
+        else if (sp[1] > sp[2]) { so[0] *= 0.0f; so[2] *= 0.0f; }
+        else { so[0] *= 0.0f; so[1] *= 0.0f; }
+        float Rm[3][3]; quat_to_mat3(qw, qx, qy, qz, Rm);
+        // mat4(quat) * vec4: columns weighted by components, w stays 1
+        const float ox = Rm[0][0] * so[0] + Rm[1][0] * so[1] + Rm[2][0] * so[2] + 0.0f * so[3];
+        const float oy = Rm[0][1] * so[0] + Rm[1][1] * so[1] + Rm[2][1] * so[2] + 0.0f * so[3];
+        const float oz = Rm[0][2] * so[0] + Rm[1][2] * so[1] + Rm[2][2] * so[2] + 0.0f * so[3];
+        const float ow = 0.0f * so[0] + 0.0f * so[1] + 0.0f * so[2] + 1.0f * so[3];
+        const float off[3] = { ox / ow, oy / ow, oz / ow };
+        float n1[3], n2[3], sn[3];
+        for (int k = 0; k < 3; k++) {
+            n1[k] = lp[k] + off[k] * splitDistance * 0.5f;
+            n2[k] = lp[k] - off[k] * splitDistance * 0.5f;
+            sn[k] = sp[k] * splitScale;
+        }
+        const int i2 = count; count++;
+        copy(i2, i);
+        std::memcpy(&loc[i * 3], n1, 12); std::memcpy(&loc[i2 * 3], n2, 12);
+        std::memcpy(&scale[i * 3], sn, 12); std::memcpy(&scale[i2 * 3], sn, 12);
+        const float qmem_xyzw[4] = { qx, qy, qz, qw }, qmem_wxyz[4] = { qw, qx, qy, qz };
+        const float* qm = quat_xyzw ? qmem_xyzw : qmem_wxyz;
+        std::memcpy(&rot[i * 4], qm, 16); std::memcpy(&rot[i2 * 4], qm, 16);
+    }
+    for (int i : toClone) {
+        if (count >= capacity) continue;
+        float l[3] = { loc[i * 3], loc[i * 3 + 1], loc[i * 3 + 2] };
+        const float sc[3] = { scale[i * 3], scale[i * 3 + 1], scale[i * 3 + 2] };
+        const float qw = rot[i * 4], qx = rot[i * 4 + 1], qy = rot[i * 4 + 2], qz = rot[i * 4 + 3];
+        const f3 dirG = norm3(f3{ gradLoc[i * 3], gradLoc[i * 3 + 1], gradLoc[i * 3 + 2] });
+        float Rm[3][3]; quat_to_mat3(qw, qx, qy, qz, Rm);
+        const float ox = Rm[0][0] * sc[0] + Rm[1][0] * sc[1] + Rm[2][0] * sc[2] + 0.0f * 1.0f;
+        const float oy = Rm[0][1] * sc[0] + Rm[1][1] * sc[1] + Rm[2][1] * sc[2] + 0.0f * 1.0f;
+        const float oz = Rm[0][2] * sc[0] + Rm[1][2] * sc[1] + Rm[2][2] * sc[2] + 0.0f * 1.0f;
+        const float ow = 0.0f * sc[0] + 0.0f * sc[1] + 0.0f * sc[2] + 1.0f * 1.0f;
+        l[0] += (ox / ow) * dirG.x * cloneDistance;
+        l[1] += (oy / ow) * dirG.y * cloneDistance;
+        l[2] += (oz / ow) * dirG.z * cloneDistance;
+        const int i2 = count; count++;
+        copy(i2, i);
+        std::memcpy(&loc[i2 * 3], l, 12);
+    }
+    if (!toRemove.empty()) {
+        int keep = 0;
+        for (int scan = 0; scan < count; scan++)
+            if (!toRemove.count(scan)) { if (keep != scan) copy(keep, scan); keep++; }
+        count -= (int)toRemove.size();
+    }
+    return count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Camera.cpp restatements
+// ---------------------------------------------------------------------------------------------
+// getFibonacciSphere, src/Camera.cpp:9-27
+void orc_fibonacci_sphere(int count, float distance, float* out_xyz) {
+    const float goldenRatio = (1.0f + sqrtf(5.0f)) / 2.0f;
+    const float angleStep = 2.0f * (float)3.1415926535897932384626433832795 * goldenRatio;
+    for (int i = 0; i < count; i++) {
+        const float t = (float)i / (float)count;
+        const float angle1 = acosf(1.0f - 2.0f * t);
+        const float angle2 = angleStep * (float)i;
+        out_xyz[3 * i] = sinf(angle1) * cosf(angle2) * distance;
+        out_xyz[3 * i + 1] = sinf(angle1) * sinf(angle2) * distance;
+        out_xyz[3 * i + 2] = cosf(angle1) * distance;
+    }
+}
+// Camera::getView, src/Camera.cpp:79-82: -glm::lookAt(location, target, up=(0,1,0)) (lookAtRH)
+void orc_camera_view(const float* loc, const float* target, float* out16) {
+    const f3 eye = { loc[0], loc[1], loc[2] }, center = { target[0], target[1], target[2] }, up = { 0.0f, 1.0f, 0.0f };
+    const f3 f = norm3(sub3(center, eye));
+    const f3 s = norm3(cross3(f, up));
+    const f3 u = cross3(s, f);
+    float m[16] = { 0 };
+    m[15] = 1.0f;
+    m[0] = s.x; m[4] = s.y; m[8] = s.z;
+    m[1] = u.x; m[5] = u.y; m[9] = u.z;
+    m[2] = -f.x; m[6] = -f.y; m[10] = -f.z;
+    m[12] = -dot3(s, eye); m[13] = -dot3(u, eye); m[14] = dot3(f, eye);
+    for (int k = 0; k < 16; k++) out16[k] = -m[k];
+}
+// Camera::getProjection, src/Camera.cpp:84-86: glm::perspective(radians(fovY), aspect, 0.1, 100) (RH, NO)
+void orc_camera_proj(float fovDegY, float aspect, float* out16) {
+    const float fovy = fovDegY * 0.01745329251994329576923690768489f;
+    const float zNear = 0.1f, zFar = 100.0f;
+    const float tanHalfFovy = std::tan(fovy / 2.0f);
+    for (int k = 0; k < 16; k++) out16[k] = 0.0f;
+    out16[0] = 1.0f / (aspect * tanHalfFovy);
+    out16[5] = 1.0f / (tanHalfFovy);
+    out16[10] = -(zFar + zNear) / (zFar - zNear);
+    out16[11] = -1.0f;
+    out16[14] = -(2.0f * zFar * zNear) / (zFar - zNear);
+}
+// glm mat4 * mat4 (column-major): out = a * b
+void orc_mat4_mul(const float* a, const float* b, float* out16) {
+    float r[16];
+    for (int c = 0; c < 4; c++)
+        for (int rr = 0; rr < 4; rr++)
+            r[c * 4 + rr] = a[0 * 4 + rr] * b[c * 4 + 0] + a[1 * 4 + rr] * b[c * 4 + 1] + a[2 * 4 + rr] * b[c * 4 + 2] + a[3 * 4 + rr] * b[c * 4 + 3];
+    std::memcpy(out16, r, sizeof(r));
+}
+
+}  // extern "C"
