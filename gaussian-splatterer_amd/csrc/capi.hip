@@ -1,0 +1,869 @@
+// capi.hip — the C-ABI of include/gsplat.h: model, trainer, rasterizer seam, RCCL communicator.
+// Host orchestration only; every arithmetic step is a HIP kernel in k_*.hip (densify excepted,
+// which the reference also runs on the CPU).  There is no CPU fallback: without a HIP device the
+// entry points fail with GS_ERR_NO_DEVICE / GS_ERR_HIP.
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "gs_internal.h"
+
+namespace gs {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return GS_OK;
+        if (p) { GS_HIP(hipFree(p)); p = nullptr; cap = 0; }
+        bytes = round_up_sz(bytes, 256);
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GS_ERR_OUT_OF_MEMORY; }
+        cap = bytes;
+        return GS_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+static int effective_degree(int sh_degree, int M, int* D_out) {
+    const int D = sh_degree > 3 ? 3 : (sh_degree < 0 ? 0 : sh_degree);  // the rasterizer treats every degree > 2 as 3
+    if (M < 1 || (D + 1) * (D + 1) > M) {
+        set_error("SH degree %d needs %d coefficients but the model carries %d", sh_degree, (D + 1) * (D + 1), M);
+        return GS_ERR_DIMENSIONS;
+    }
+    *D_out = D;
+    return GS_OK;
+}
+
+static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t Rcap, float mod) {
+    Dims d;
+    d.P = P; d.Pa = Pa; d.D = D; d.M = M; d.W = W; d.H = H; d.N = W * H;
+    d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
+    d.V = V; d.Rcap = Rcap; d.mod = mod;
+    return d;
+}
+
+// Per-view scratch owned by the library (trainer / preview).  One allocation per array family,
+// grow-only, sized for V views at once: with 288 GB of HBM every view of a step keeps its own
+// state and each stage is ONE launch over all views.
+struct ScratchSet {
+    DevBuf views, geom, tiles, offsets, zero_block, tile_end, bins, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp;
+    int V = 0, Pa = 0, T = 0, N = 0;
+    uint32_t Rcap = 0;
+    Scratch s{};
+    size_t zero_bytes = 0;
+
+    int ensure(int P, int V_, int W, int H, uint32_t Rcap_) {
+        Pa = std::max(64, round_up(P, 64));
+        V = V_; N = W * H;
+        T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+        Rcap = std::max<uint32_t>(Rcap_, 1024);
+        const size_t v = (size_t)std::max(V, 1);
+        GS_TRY(views.ensure(v * sizeof(gs_view)));
+        GS_TRY(geom.ensure(v * Pa * sizeof(GeomRec)));
+        GS_TRY(tiles.ensure(v * Pa * 4));
+        GS_TRY(offsets.ensure(v * Pa * 4));
+        // zero block: tile_count | tile_cursor | flags | loss   (cleared by one memset per step)
+        zero_bytes = v * T * 4 * 2 + v * 16 + v * 4;
+        GS_TRY(zero_block.ensure(zero_bytes));
+        GS_TRY(tile_end.ensure(v * T * 4));
+        GS_TRY(bins.ensure(v * Rcap * 8));
+        GS_TRY(ids.ensure(v * Rcap * 4));
+        GS_TRY(plist.ensure(v * Rcap * 4));
+        GS_TRY(slist.ensure(v * Rcap * 4));
+        GS_TRY(G.ensure(v * Rcap * G_STRIDE * 4));
+        GS_TRY(color.ensure(v * 3 * N * 4));
+        GS_TRY(finalT.ensure(v * N * 4));
+        GS_TRY(ncontrib.ensure(v * N * 4));
+        GS_TRY(scan_tmp.ensure((scan_partials_count(Pa, (int)v) + scan_partials_count(T, (int)v) + 64) * 4));
+        s.views = views.as<gs_view>();
+        s.geom = geom.as<GeomRec>();
+        s.tiles_touched = tiles.as<uint32_t>();
+        s.point_offsets = offsets.as<uint32_t>();
+        s.tile_count = zero_block.as<uint32_t>();
+        s.tile_cursor = s.tile_count + v * T;
+        s.flags = s.tile_cursor + v * T;
+        s.loss = reinterpret_cast<float*>(s.flags + v * 4);
+        s.tile_end = tile_end.as<uint32_t>();
+        s.bins = bins.as<uint64_t>();
+        s.id_of_slot = ids.as<uint32_t>();
+        s.point_list = plist.as<uint32_t>();
+        s.slot_list = slist.as<uint32_t>();
+        s.G = G.as<float>();
+        s.out_color = color.as<float>();
+        s.final_T = finalT.as<float>();
+        s.n_contrib = ncontrib.as<uint32_t>();
+        s.truth = nullptr;
+        s.dL_dpix = nullptr;
+        return GS_OK;
+    }
+    void release() {
+        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &zero_block, &tile_end, &bins, &ids, &plist, &slist, &G, &color,
+                           &finalT, &ncontrib, &scan_tmp })
+            b->release();
+    }
+};
+
+// projection + the two scans (everything that does not need the binning arena)
+static int stage_project(const Dims& d, const float* params, const Scratch& s, uint32_t* scan_tmp, hipStream_t st) {
+    GS_TRY(launch_preprocess(d, params, s, st));
+    GS_TRY(launch_scan_u32(s.tiles_touched, s.point_offsets, d.P, d.Pa, d.V, scan_tmp, st));
+    GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.V, scan_tmp + scan_partials_count(d.Pa, d.V), st));
+    return GS_OK;
+}
+static int stage_bin_render(const Dims& d, const Scratch& s, hipStream_t st) {
+    GS_TRY(launch_scatter(d, s, st));
+    GS_TRY(launch_tile_sort(d, s, st));
+    GS_TRY(launch_render_forward(d, s, st));
+    return GS_OK;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+// =============================================================================================
+// misc
+// =============================================================================================
+extern "C" const char* gs_last_error(void) { return g_err; }
+extern "C" const char* gs_status_string(int s) {
+    switch (s) {
+        case GS_OK: return "ok";
+        case GS_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case GS_ERR_HIP: return "HIP runtime error";
+        case GS_ERR_NO_TRUTH: return "Can't run training iteration, no truth data available!";
+        case GS_ERR_CAPACITY: return "Model ran out of capacity!";
+        case GS_ERR_BOUNDS: return "Can't copy splat in model, incorrect bounds and/or no capacity!";
+        case GS_ERR_DIMENSIONS: return "Inconsistent feature dimensions supplied when creating a host model!";
+        case GS_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case GS_ERR_NO_MODEL: return "trainer has no model";
+        case GS_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+        default: return "internal error";
+    }
+}
+extern "C" int gs_version(int* a, int* b, int* c) {
+    if (a) *a = GS_VERSION_MAJOR;
+    if (b) *b = GS_VERSION_MINOR;
+    if (c) *c = GS_VERSION_PATCH;
+    return GS_OK;
+}
+extern "C" int gs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+static int require_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        set_error("no HIP device visible; libgsplat_mi355 has no CPU path");
+        return GS_ERR_NO_DEVICE;
+    }
+    return GS_OK;
+}
+extern "C" int gs_device_malloc(void** p, size_t bytes) {
+    if (!p) return GS_ERR_INVALID_ARGUMENT;
+    GS_TRY(require_device());
+    GS_HIP(hipMalloc(p, bytes ? bytes : 1));
+    return GS_OK;
+}
+extern "C" int gs_device_free(void* p) { GS_HIP(hipFree(p)); return GS_OK; }
+extern "C" int gs_memcpy_h2d(void* d, const void* h, size_t n) { if (n) GS_HIP(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return GS_OK; }
+extern "C" int gs_memcpy_d2h(void* h, const void* d, size_t n) { if (n) GS_HIP(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return GS_OK; }
+extern "C" int gs_memset_d(void* d, int v, size_t n) { if (n) GS_HIP(hipMemset(d, v, n)); return GS_OK; }
+extern "C" int gs_device_synchronize(void) { GS_HIP(hipDeviceSynchronize()); return GS_OK; }
+
+extern "C" int gs_hyper_defaults(gs_hyper* h) {
+    if (!h) return GS_ERR_INVALID_ARGUMENT;
+    h->lr_location = 0.00005f; h->lr_sh = 0.0001f; h->lr_scale = 0.00002f; h->lr_opacity = 0.0001f; h->lr_rotation = 0.000025f;
+    h->scale_max = 0.3f;
+    h->cull_opacity = 0.005f; h->cull_size = 0.004f; h->densify_variance = 2.0f;
+    h->split_size = 0.04f; h->split_distance = 1.5f; h->split_scale = 0.8f; h->clone_distance = 1.6f;
+    h->update_rule = GS_UPDATE_SGD_CLAMP;
+    h->adam_beta1 = 0.9f; h->adam_beta2 = 0.999f; h->adam_eps = 1e-15f;
+    h->quat_layout = GS_QUAT_XYZW;
+    return GS_OK;
+}
+
+// =============================================================================================
+// model
+// =============================================================================================
+static int model_alloc(int capacity, int sh_degree, int sh_coeffs, int count, gs_model** out) {
+    gs_model* m = new gs_model();
+    m->capacity = capacity; m->sh_degree = sh_degree; m->sh_coeffs = sh_coeffs; m->count = count;
+    if (hipGetDevice(&m->device) != hipSuccess) { delete m; set_error("hipGetDevice failed"); return GS_ERR_HIP; }
+    m->Pa = std::max(64, round_up(count, 64));
+    const size_t bytes = (size_t)(11 + 3 * sh_coeffs) * m->Pa * sizeof(float);
+    hipError_t e = hipMalloc((void**)&m->planes, bytes);
+    if (e != hipSuccess) { delete m; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GS_ERR_OUT_OF_MEMORY; }
+    e = hipMemset(m->planes, 0, bytes);
+    if (e != hipSuccess) { (void)hipFree(m->planes); delete m; set_error("hipMemset failed: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
+    *out = m;
+    return GS_OK;
+}
+
+extern "C" int gs_model_create(int capacity, int sh_degree, int sh_coeffs, int count, const float* loc, const float* sh,
+                               const float* scale, const float* opac, const float* rot, gs_model** out) {
+    if (!out || capacity < 0 || count < 0 || sh_coeffs < 1) { set_error("gs_model_create: bad arguments"); return GS_ERR_INVALID_ARGUMENT; }
+    if (count > capacity) { set_error("Model ran out of capacity! (count %d > capacity %d)", count, capacity); return GS_ERR_CAPACITY; }
+    if (count > 0 && (!loc || !sh || !scale || !opac || !rot)) {
+        set_error("Inconsistent feature dimensions supplied when creating a host model! (null array)");
+        return GS_ERR_DIMENSIONS;
+    }
+    GS_TRY(require_device());
+    gs_model* m = nullptr;
+    GS_TRY(model_alloc(capacity, sh_degree, sh_coeffs, count, &m));
+    if (count > 0) {
+        // stage the reference-layout arrays and transpose to planes on the device
+        const size_t nf = (size_t)count * (11 + 3 * sh_coeffs);
+        float* stage = nullptr;
+        hipError_t e = hipMalloc((void**)&stage, nf * sizeof(float));
+        if (e != hipSuccess) { gs_model_destroy(m); set_error("hipMalloc staging failed: %s", hipGetErrorString(e)); return GS_ERR_OUT_OF_MEMORY; }
+        float* dl = stage; float* dsh = dl + 3 * (size_t)count; float* dsc = dsh + 3 * (size_t)sh_coeffs * count;
+        float* dop = dsc + 3 * (size_t)count; float* dr = dop + count;
+        int rc = GS_OK;
+        auto cp = [&](float* d, const float* h, size_t n) { if (rc == GS_OK && hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice) != hipSuccess) rc = GS_ERR_HIP; };
+        cp(dl, loc, 3 * (size_t)count); cp(dsh, sh, 3 * (size_t)sh_coeffs * count); cp(dsc, scale, 3 * (size_t)count);
+        cp(dop, opac, count); cp(dr, rot, 4 * (size_t)count);
+        if (rc == GS_OK) rc = launch_aos_to_soa(count, m->Pa, sh_coeffs, dl, dsh, dsc, dop, dr, m->planes, 0);
+        if (rc == GS_OK && hipDeviceSynchronize() != hipSuccess) rc = GS_ERR_HIP;
+        (void)hipFree(stage);
+        if (rc != GS_OK) { gs_model_destroy(m); if (rc == GS_ERR_HIP) set_error("model upload failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
+    }
+    *out = m;
+    return GS_OK;
+}
+
+extern "C" int gs_model_clone(const gs_model* src, gs_model** out) {
+    if (!src || !out) return GS_ERR_INVALID_ARGUMENT;
+    gs_model* m = nullptr;
+    GS_TRY(model_alloc(src->capacity, src->sh_degree, src->sh_coeffs, src->count, &m));
+    const size_t bytes = (size_t)(11 + 3 * src->sh_coeffs) * src->Pa * sizeof(float);
+    hipError_t e = hipMemcpy(m->planes, src->planes, bytes, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { gs_model_destroy(m); set_error("clone copy failed: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
+    *out = m;
+    return GS_OK;
+}
+
+extern "C" int gs_model_download(const gs_model* m, float* loc, float* sh, float* scale, float* opac, float* rot) {
+    if (!m) return GS_ERR_INVALID_ARGUMENT;
+    const int count = m->count, M = m->sh_coeffs;
+    if (count == 0) return GS_OK;
+    if (!loc || !sh || !scale || !opac || !rot) { set_error("gs_model_download: null destination"); return GS_ERR_INVALID_ARGUMENT; }
+    const size_t nf = (size_t)count * (11 + 3 * M);
+    float* stage = nullptr;
+    GS_HIP(hipMalloc((void**)&stage, nf * sizeof(float)));
+    float* dl = stage; float* dsh = dl + 3 * (size_t)count; float* dsc = dsh + 3 * (size_t)M * count;
+    float* dop = dsc + 3 * (size_t)count; float* dr = dop + count;
+    int rc = launch_soa_to_aos(count, m->Pa, M, m->planes, dl, dsh, dsc, dop, dr, 0);
+    auto cp = [&](float* h, const float* d, size_t n) { if (rc == GS_OK && hipMemcpy(h, d, n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = GS_ERR_HIP; };
+    cp(loc, dl, 3 * (size_t)count); cp(sh, dsh, 3 * (size_t)M * count); cp(scale, dsc, 3 * (size_t)count);
+    cp(opac, dop, count); cp(rot, dr, 4 * (size_t)count);
+    (void)hipFree(stage);
+    if (rc == GS_ERR_HIP) set_error("model download failed: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+extern "C" int gs_model_info(const gs_model* m, int* capacity, int* sh_degree, int* sh_coeffs, int* count) {
+    if (!m) return GS_ERR_INVALID_ARGUMENT;
+    if (capacity) *capacity = m->capacity;
+    if (sh_degree) *sh_degree = m->sh_degree;
+    if (sh_coeffs) *sh_coeffs = m->sh_coeffs;
+    if (count) *count = m->count;
+    return GS_OK;
+}
+
+extern "C" int gs_model_destroy(gs_model* m) {
+    if (!m) return GS_OK;
+    if (m->planes) (void)hipFree(m->planes);
+    delete m;
+    return GS_OK;
+}
+
+// =============================================================================================
+// trainer
+// =============================================================================================
+struct gs_trainer {
+    int device = 0, W = 0, H = 0;
+    hipStream_t stream = nullptr;
+    gs_model* model = nullptr;
+    int V = 0, total_samples = 0;
+    std::vector<gs_view> h_views;
+    DevBuf truth;                 // [V][N] u32
+    DevBuf grad, adam_m, adam_v;  // [(12+3M)][Pa], [(11+3M)][Pa] x2
+    int grad_Pa = 0, grad_M = 0, adam_t = 0;
+    bool adam_valid = false;
+    ScratchSet train, preview;
+    uint32_t* h_flags = nullptr;  // pinned, [V][4] + loss[V]
+    size_t h_flags_cap = 0;
+    uint32_t Rcap = 0;
+    gs_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    gs_step_stats last{};
+    bool accumulated = false;
+};
+
+extern "C" int gs_trainer_create(int width, int height, gs_trainer** out) {
+    if (!out || width <= 0 || height <= 0 || width > 65535 * TILE || height > 65535 * TILE) {
+        set_error("gs_trainer_create: bad resolution %dx%d", width, height);
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    GS_TRY(require_device());
+    gs_trainer* t = new gs_trainer();
+    t->W = width; t->H = height;
+    if (hipGetDevice(&t->device) != hipSuccess || hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete t; set_error("stream creation failed: %s", hipGetErrorString(hipGetLastError())); return GS_ERR_HIP;
+    }
+    // placeholder model so the trainer is never model-less (src/Trainer.cu:111-112)
+    int rc = gs_model_create(0, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &t->model);
+    if (rc != GS_OK) { (void)hipStreamDestroy(t->stream); delete t; return rc; }
+    *out = t;
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_destroy(gs_trainer* t) {
+    if (!t) return GS_OK;
+    (void)hipStreamSynchronize(t->stream);
+    gs_model_destroy(t->model);
+    t->truth.release(); t->grad.release(); t->adam_m.release(); t->adam_v.release();
+    t->train.release(); t->preview.release();
+    if (t->h_flags) (void)hipHostFree(t->h_flags);
+    (void)hipStreamDestroy(t->stream);
+    delete t;
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_set_model(gs_trainer* t, gs_model* m) {
+    if (!t || !m) return GS_ERR_INVALID_ARGUMENT;
+    if (m->device != t->device) { set_error("model lives on device %d, trainer on %d", m->device, t->device); return GS_ERR_INVALID_ARGUMENT; }
+    GS_HIP(hipStreamSynchronize(t->stream));
+    if (t->model != m) gs_model_destroy(t->model);
+    t->model = m;
+    t->adam_valid = false; t->adam_t = 0; t->accumulated = false;
+    return GS_OK;
+}
+extern "C" gs_model* gs_trainer_get_model(gs_trainer* t) { return t ? t->model : nullptr; }
+
+extern "C" int gs_trainer_set_views(gs_trainer* t, int n_views, const gs_view* views, const uint32_t* const* truth,
+                                    int truth_on_device, int total_samples) {
+    if (!t || n_views < 0 || (n_views > 0 && (!views || !truth)) || total_samples < n_views) {
+        set_error("gs_trainer_set_views: bad arguments");
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    GS_HIP(hipStreamSynchronize(t->stream));
+    const size_t N = (size_t)t->W * t->H;
+    GS_TRY(t->truth.ensure(std::max<size_t>(1, (size_t)n_views * N * 4)));
+    for (int v = 0; v < n_views; v++) {
+        if (!truth[v]) { set_error("gs_trainer_set_views: truth image %d is null", v); return GS_ERR_INVALID_ARGUMENT; }
+        GS_HIP(hipMemcpy(t->truth.as<uint32_t>() + (size_t)v * N, truth[v], N * 4,
+                         truth_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    }
+    t->h_views.assign(views, views + n_views);
+    t->V = n_views;
+    t->total_samples = total_samples;
+    t->accumulated = false;
+    return GS_OK;
+}
+
+static int trainer_dims(gs_trainer* t, Dims* d) {
+    int D = 0;
+    GS_TRY(effective_degree(t->model->sh_degree, t->model->sh_coeffs, &D));
+    *d = make_dims(t->model->count, t->model->Pa, D, t->model->sh_coeffs, t->W, t->H, t->V, t->Rcap, 1.0f);
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    if (t->V == 0) { set_error("Can't run training iteration, no truth data available!"); return GS_ERR_NO_TRUTH; }
+    if (!t->model) return GS_ERR_NO_MODEL;
+    GS_HIP(hipSetDevice(t->device));
+    gs_model* m = t->model;
+    const int P = m->count, M = m->sh_coeffs, V = t->V;
+    const Planes pl{ M };
+    gs_step_stats st{};
+    st.count_before = st.count_after = P; st.views = V;
+    // gradient planes (+ var), sized to the model's plane stride
+    GS_TRY(t->grad.ensure((size_t)(pl.count() + 1) * m->Pa * 4));
+    t->grad_Pa = m->Pa; t->grad_M = M;
+    if (t->Rcap == 0) t->Rcap = (uint32_t)std::max<long long>(1 << 20, 16LL * P);
+    if (t->h_flags_cap < (size_t)V * 20) {
+        if (t->h_flags) (void)hipHostFree(t->h_flags);
+        t->h_flags = nullptr;
+        GS_HIP(hipHostMalloc((void**)&t->h_flags, (size_t)V * 20));
+        t->h_flags_cap = (size_t)V * 20;
+    }
+    for (;;) {
+        Dims d;
+        GS_TRY(trainer_dims(t, &d));
+        GS_TRY(t->train.ensure(P, V, t->W, t->H, t->Rcap));
+        d.Rcap = t->train.Rcap;
+        Scratch s = t->train.s;
+        s.truth = t->truth.as<uint32_t>();
+        GS_HIP(hipMemcpyAsync((void*)s.views, t->h_views.data(), (size_t)V * sizeof(gs_view), hipMemcpyHostToDevice, t->stream));
+        GS_HIP(hipMemsetAsync(t->train.zero_block.p, 0, t->train.zero_bytes, t->stream));
+        if (P > 0) {
+            GS_TRY(stage_project(d, m->planes, s, t->train.scan_tmp.as<uint32_t>(), t->stream));
+            GS_TRY(stage_bin_render(d, s, t->stream));
+            GS_TRY(launch_render_backward(d, s, t->stream));
+            GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), t->stream));
+        } else {
+            GS_TRY(launch_render_forward(d, s, t->stream));
+        }
+        GS_HIP(hipMemcpyAsync(t->h_flags, s.flags, (size_t)V * 20, hipMemcpyDeviceToHost, t->stream));
+        GS_HIP(hipStreamSynchronize(t->stream));
+        bool overflow = false;
+        uint32_t need = 0;
+        st.num_rendered = 0; st.max_tile_list = 0;
+        for (int v = 0; v < V; v++) {
+            if (t->h_flags[v * 4 + 0] & 1u) overflow = true;
+            need = std::max(need, t->h_flags[v * 4 + 2]);
+            st.num_rendered += t->h_flags[v * 4 + 2];
+            st.max_tile_list = std::max(st.max_tile_list, (int)t->h_flags[v * 4 + 1]);
+        }
+        if (!overflow) {
+            const float* hl = reinterpret_cast<const float*>(t->h_flags + (size_t)V * 4);
+            double L = 0;
+            for (int v = 0; v < V; v++) L += hl[v];
+            st.loss = (float)L;
+            break;
+        }
+        t->Rcap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)need + need / 4 + 1024);
+        st.arena_regrows++;
+        if (st.arena_regrows > 8) { set_error("binning arena failed to converge"); return GS_ERR_INTERNAL; }
+    }
+    t->last = st;
+    t->accumulated = true;
+    if (stats) *stats = st;
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_grad_buffer(gs_trainer* t, float** p, size_t* n) {
+    if (!t || !t->model) return GS_ERR_INVALID_ARGUMENT;
+    const Planes pl{ t->model->sh_coeffs };
+    GS_TRY(t->grad.ensure((size_t)(pl.count() + 1) * t->model->Pa * 4));
+    if (p) *p = t->grad.as<float>();
+    if (n) *n = (size_t)(pl.count() + 1) * t->model->Pa;
+    return GS_OK;
+}
+
+static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) {
+    gs_model* m = t->model;
+    const int M = m->sh_coeffs, cap = m->capacity, count = m->count;
+    GS_HIP(hipStreamSynchronize(t->stream));
+    std::vector<float> loc((size_t)cap * 3), sh((size_t)cap * 3 * M), scale((size_t)cap * 3), opac((size_t)cap), rot((size_t)cap * 4);
+    GS_TRY(gs_model_download(m, loc.data(), sh.data(), scale.data(), opac.data(), rot.data()));
+    const Planes pl{ M };
+    std::vector<float> var((size_t)count), gl((size_t)count * 3), plane((size_t)count);
+    const float* g = t->grad.as<float>();
+    GS_HIP(hipMemcpy(var.data(), g + (size_t)pl.var() * t->grad_Pa, (size_t)count * 4, hipMemcpyDeviceToHost));
+    for (int c = 0; c < 3; c++) {
+        GS_HIP(hipMemcpy(plane.data(), g + (size_t)pl.loc(c) * t->grad_Pa, (size_t)count * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < count; i++) gl[3 * (size_t)i + c] = plane[i];
+    }
+    const int n2 = densify_host(loc.data(), sh.data(), scale.data(), opac.data(), rot.data(), count, cap, M, var.data(), gl.data(), *h);
+    gs_model* fresh = nullptr;
+    GS_TRY(gs_model_create(cap, m->sh_degree, M, n2, loc.data(), sh.data(), scale.data(), opac.data(), rot.data(), &fresh));
+    gs_model_destroy(t->model);
+    t->model = fresh;
+    t->adam_valid = false; t->adam_t = 0;  // optimizer state does not survive re-indexing
+    st->count_after = n2;
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, gs_step_stats* stats) {
+    if (!t || !h) return GS_ERR_INVALID_ARGUMENT;
+    if (!t->accumulated) { set_error("gs_trainer_apply called without gs_trainer_accumulate"); return GS_ERR_INVALID_ARGUMENT; }
+    GS_HIP(hipSetDevice(t->device));
+    gs_model* m = t->model;
+    const Planes pl{ m->sh_coeffs };
+    gs_step_stats st = t->last;
+    if (h->update_rule == GS_UPDATE_ADAM) {
+        const size_t bytes = (size_t)pl.count() * m->Pa * 4;
+        if (!t->adam_valid) {
+            GS_TRY(t->adam_m.ensure(bytes)); GS_TRY(t->adam_v.ensure(bytes));
+            GS_HIP(hipMemsetAsync(t->adam_m.p, 0, bytes, t->stream));
+            GS_HIP(hipMemsetAsync(t->adam_v.p, 0, bytes, t->stream));
+            t->adam_valid = true; t->adam_t = 0;
+        }
+        t->adam_t++;
+    } else if (h->update_rule != GS_UPDATE_SGD_CLAMP) {
+        set_error("unknown update rule %d", h->update_rule);
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    GS_TRY(launch_update(pl, m->count, m->Pa, m->planes, t->grad.as<float>(), t->adam_m.as<float>(), t->adam_v.as<float>(),
+                         t->adam_t, *h, t->stream));
+    t->accumulated = false;
+    if (densify) GS_TRY(trainer_densify(t, h, &st));
+    if (stats) { GS_HIP(hipStreamSynchronize(t->stream)); *stats = st; }
+    t->last = st;
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs_step_stats* stats) {
+    if (!t || !h) return GS_ERR_INVALID_ARGUMENT;
+    GS_TRY(gs_trainer_accumulate(t, nullptr));
+    if (t->allreduce) {
+        float* buf = nullptr; size_t n = 0;
+        GS_TRY(gs_trainer_grad_buffer(t, &buf, &n));
+        const int rc = t->allreduce(buf, n, (void*)t->stream, t->allreduce_user);
+        if (rc != 0) { set_error("all-reduce hook failed with %d", rc); return GS_ERR_INTERNAL; }
+    }
+    return gs_trainer_apply(t, h, densify, stats);
+}
+
+extern "C" int gs_trainer_set_allreduce(gs_trainer* t, gs_allreduce_fn fn, void* user) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    t->allreduce = fn; t->allreduce_user = user;
+    return GS_OK;
+}
+extern "C" int gs_trainer_get_stream(gs_trainer* t, void** s) {
+    if (!t || !s) return GS_ERR_INVALID_ARGUMENT;
+    *s = (void*)t->stream;
+    return GS_OK;
+}
+extern "C" int gs_trainer_synchronize(gs_trainer* t) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    GS_HIP(hipStreamSynchronize(t->stream));
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_read_image(gs_trainer* t, int view, float* host_chw) {
+    if (!t || !host_chw || view < 0 || view >= t->V || !t->train.s.out_color) return GS_ERR_INVALID_ARGUMENT;
+    GS_HIP(hipStreamSynchronize(t->stream));
+    const size_t N = (size_t)t->W * t->H;
+    GS_HIP(hipMemcpy(host_chw, t->train.s.out_color + (size_t)view * 3 * N, 3 * N * 4, hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_render(gs_trainer* t, uint32_t* fb, int fb_on_device, int w, int h, float splat_scale, const gs_view* view) {
+    if (!t || !fb || !view || w <= 0 || h <= 0) return GS_ERR_INVALID_ARGUMENT;
+    if (!t->model) return GS_ERR_NO_MODEL;
+    GS_HIP(hipSetDevice(t->device));
+    gs_model* m = t->model;
+    int D = 0;
+    GS_TRY(effective_degree(m->sh_degree, m->sh_coeffs, &D));
+    uint32_t rcap = std::max<uint32_t>(t->preview.Rcap, (uint32_t)std::max<long long>(1 << 20, 16LL * m->count));
+    DevBuf fbdev;
+    for (int attempt = 0;; attempt++) {
+        GS_TRY(t->preview.ensure(m->count, 1, w, h, rcap));
+        Dims d = make_dims(m->count, m->Pa, D, m->sh_coeffs, w, h, 1, t->preview.Rcap, splat_scale);
+        Scratch s = t->preview.s;
+        GS_HIP(hipMemcpyAsync((void*)s.views, view, sizeof(gs_view), hipMemcpyHostToDevice, t->stream));
+        GS_HIP(hipMemsetAsync(t->preview.zero_block.p, 0, t->preview.zero_bytes, t->stream));
+        if (m->count > 0) {
+            GS_TRY(stage_project(d, m->planes, s, t->preview.scan_tmp.as<uint32_t>(), t->stream));
+            GS_TRY(stage_bin_render(d, s, t->stream));
+        } else {
+            GS_TRY(launch_render_forward(d, s, t->stream));
+        }
+        uint32_t flags[4];
+        GS_HIP(hipMemcpyAsync(flags, s.flags, 16, hipMemcpyDeviceToHost, t->stream));
+        GS_HIP(hipStreamSynchronize(t->stream));
+        if (!(flags[0] & 1u)) break;
+        if (attempt > 8) { set_error("preview arena failed to converge"); return GS_ERR_INTERNAL; }
+        rcap = flags[2] + flags[2] / 4 + 1024;
+    }
+    uint32_t* target = fb;
+    const size_t N = (size_t)w * h;
+    if (!fb_on_device) { GS_TRY(fbdev.ensure(N * 4)); target = fbdev.as<uint32_t>(); }
+    int rc = launch_image_float_to_int(t->preview.s.out_color, target, w, h, t->stream);
+    if (rc == GS_OK && hipStreamSynchronize(t->stream) != hipSuccess) rc = GS_ERR_HIP;  // cudaDeviceSynchronize, src/Trainer.cu:215
+    if (rc == GS_OK && !fb_on_device && hipMemcpy(fb, target, N * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = GS_ERR_HIP;
+    fbdev.release();
+    if (rc == GS_ERR_HIP) set_error("render failed: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+// =============================================================================================
+// image kernels as entry points
+// =============================================================================================
+extern "C" int gs_image_float_to_int(const float* src, uint32_t* fb, int w, int h) {
+    GS_TRY(launch_image_float_to_int(src, fb, w, h, 0));
+    GS_HIP(hipDeviceSynchronize());
+    return GS_OK;
+}
+extern "C" int gs_image_int_to_loss(const uint32_t* truth, const float* rast, float* loss, int w, int h) {
+    GS_TRY(launch_image_int_to_loss(truth, rast, loss, w, h, 0));
+    GS_HIP(hipDeviceSynchronize());
+    return GS_OK;
+}
+
+// =============================================================================================
+// rasterizer seam
+// =============================================================================================
+namespace {
+struct Field { const char* name; size_t off, bytes; };
+inline size_t al(size_t x) { return round_up_sz(x, 256); }
+
+struct GeomLayout { size_t record, tiles, offsets, scan_tmp, view, flags, planes, total; int Pa; };
+GeomLayout geom_layout(int P, int M) {
+    GeomLayout L; L.Pa = std::max(64, round_up(P, 64));
+    size_t o = 0;
+    L.record = o; o = al(o + (size_t)L.Pa * sizeof(GeomRec));
+    L.tiles = o; o = al(o + (size_t)L.Pa * 4);
+    L.offsets = o; o = al(o + (size_t)L.Pa * 4);
+    L.scan_tmp = o; o = al(o + (scan_partials_count(L.Pa, 1) + 64) * 4);
+    L.view = o; o = al(o + sizeof(gs_view));
+    L.flags = o; o = al(o + 32);
+    L.planes = o; o = al(o + (size_t)(11 + 3 * M) * L.Pa * 4);
+    L.total = o;
+    return L;
+}
+struct ImageLayout { size_t zero, tile_count, tile_cursor, tile_end, ranges, final_T, n_contrib, scan_tmp, total; int T; size_t zero_bytes; };
+ImageLayout image_layout(int W, int H) {
+    ImageLayout L; const size_t N = (size_t)W * H;
+    L.T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    size_t o = 0;
+    L.zero = o; L.tile_count = o; o += (size_t)L.T * 4; L.tile_cursor = o; o += (size_t)L.T * 4; L.zero_bytes = o; o = al(o);
+    L.tile_end = o; o = al(o + (size_t)L.T * 4);
+    L.ranges = o; o = al(o + (size_t)L.T * 8);
+    L.final_T = o; o = al(o + N * 4);
+    L.n_contrib = o; o = al(o + N * 4);
+    L.scan_tmp = o; o = al(o + (scan_partials_count(L.T, 1) + 64) * 4);
+    L.total = o;
+    return L;
+}
+struct BinLayout { size_t bins, ids, plist, slist, G, total; uint32_t Rcap; };
+BinLayout bin_layout(int R) {
+    BinLayout L; L.Rcap = (uint32_t)std::max(R, 1);
+    size_t o = 0;
+    L.bins = o; o = al(o + (size_t)L.Rcap * 8);
+    L.ids = o; o = al(o + (size_t)L.Rcap * 4);
+    L.plist = o; o = al(o + (size_t)L.Rcap * 4);
+    L.slist = o; o = al(o + (size_t)L.Rcap * 4);
+    L.G = o; o = al(o + (size_t)L.Rcap * G_STRIDE * 4);
+    L.total = o;
+    return L;
+}
+Scratch seam_scratch(char* geom, const GeomLayout& g, char* img, const ImageLayout& im, char* bin, const BinLayout* b) {
+    Scratch s{};
+    s.views = reinterpret_cast<const gs_view*>(geom + g.view);
+    s.geom = reinterpret_cast<GeomRec*>(geom + g.record);
+    s.tiles_touched = reinterpret_cast<uint32_t*>(geom + g.tiles);
+    s.point_offsets = reinterpret_cast<uint32_t*>(geom + g.offsets);
+    s.flags = reinterpret_cast<uint32_t*>(geom + g.flags);
+    s.tile_count = reinterpret_cast<uint32_t*>(img + im.tile_count);
+    s.tile_cursor = reinterpret_cast<uint32_t*>(img + im.tile_cursor);
+    s.tile_end = reinterpret_cast<uint32_t*>(img + im.tile_end);
+    s.final_T = reinterpret_cast<float*>(img + im.final_T);
+    s.n_contrib = reinterpret_cast<uint32_t*>(img + im.n_contrib);
+    if (bin && b) {
+        s.bins = reinterpret_cast<uint64_t*>(bin + b->bins);
+        s.id_of_slot = reinterpret_cast<uint32_t*>(bin + b->ids);
+        s.point_list = reinterpret_cast<uint32_t*>(bin + b->plist);
+        s.slot_list = reinterpret_cast<uint32_t*>(bin + b->slist);
+        s.G = reinterpret_cast<float*>(bin + b->G);
+    }
+    return s;
+}
+}  // namespace
+
+extern "C" int gs_raster_chunk_field(const char* chunk, const char* field, int P, int width, int height, int R,
+                                     size_t* offset, size_t* bytes) {
+    if (!chunk || !field || !offset || !bytes) return GS_ERR_INVALID_ARGUMENT;
+    const std::string c(chunk), f(field);
+    if (c == "geometry") {
+        const GeomLayout L = geom_layout(P, 1);
+        if (f == "record") { *offset = L.record; *bytes = (size_t)P * sizeof(GeomRec); return GS_OK; }
+        if (f == "tiles_touched") { *offset = L.tiles; *bytes = (size_t)P * 4; return GS_OK; }
+        if (f == "point_offsets") { *offset = L.offsets; *bytes = (size_t)P * 4; return GS_OK; }
+    } else if (c == "image") {
+        const ImageLayout L = image_layout(width, height);
+        const size_t N = (size_t)width * height;
+        if (f == "ranges") { *offset = L.ranges; *bytes = (size_t)L.T * 8; return GS_OK; }
+        if (f == "final_T") { *offset = L.final_T; *bytes = N * 4; return GS_OK; }
+        if (f == "n_contrib") { *offset = L.n_contrib; *bytes = N * 4; return GS_OK; }
+    } else if (c == "binning") {
+        const BinLayout L = bin_layout(R);
+        if (f == "point_list") { *offset = L.plist; *bytes = (size_t)R * 4; return GS_OK; }
+        if (f == "point_list_slots") { *offset = L.slist; *bytes = (size_t)R * 4; return GS_OK; }
+    }
+    set_error("gs_raster_chunk_field: unknown %s/%s", chunk, field);
+    return GS_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_user, gs_alloc_fn binning_alloc,
+                                    void* binning_user, gs_alloc_fn image_alloc, void* image_user, int P, int D_in, int M,
+                                    const float* background, int width, int height, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities, const float* scales,
+                                    float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                    float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
+                                    int* num_rendered) {
+    (void)debug;
+    if (!geometry_alloc || !binning_alloc || !image_alloc || P < 0 || width <= 0 || height <= 0 || !out_color || !background ||
+        !viewmatrix || !projmatrix || !cam_pos || (P > 0 && (!means3D || !shs || !opacities || !scales || !rotations))) {
+        set_error("gs_rasterize_forward: bad arguments");
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    if (colors_precomp || cov3D_precomp || radii || prefiltered) {
+        set_error("gs_rasterize_forward: colors_precomp / cov3D_precomp / radii / prefiltered are not used by the reference and not supported");
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    GS_TRY(require_device());
+    int D = 0;
+    GS_TRY(effective_degree(D_in, M, &D));
+    const GeomLayout gl = geom_layout(P, M);
+    const ImageLayout il = image_layout(width, height);
+    char* geom = geometry_alloc(gl.total, geometry_user);
+    char* img = image_alloc(il.total, image_user);
+    if (!geom || !img) { set_error("allocator callback returned null"); return GS_ERR_OUT_OF_MEMORY; }
+    hipStream_t st = 0;
+    Scratch s = seam_scratch(geom, gl, img, il, nullptr, nullptr);
+    s.out_color = out_color;
+    // view block assembled on the device from the caller's device pointers
+    char* vb = geom + gl.view;
+    GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, view), viewmatrix, 64, hipMemcpyDeviceToDevice, st));
+    GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, projview), projmatrix, 64, hipMemcpyDeviceToDevice, st));
+    GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, campos), cam_pos, 12, hipMemcpyDeviceToDevice, st));
+    const float tf[2] = { tan_fovx, tan_fovy };
+    GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, tan_fovx), tf, 8, hipMemcpyHostToDevice, st));
+    GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, bg), background, 12, hipMemcpyDeviceToDevice, st));
+    GS_HIP(hipMemsetAsync(img + il.zero, 0, il.zero_bytes, st));
+    GS_HIP(hipMemsetAsync(geom + gl.flags, 0, 32, st));
+    float* planes = reinterpret_cast<float*>(geom + gl.planes);
+    GS_TRY(launch_aos_to_soa(P, gl.Pa, M, means3D, shs, scales, opacities, rotations, planes, st));
+    Dims d = make_dims(P, gl.Pa, D, M, width, height, 1, 1, scale_modifier);
+    int R = 0;
+    if (P > 0) {
+        GS_TRY(stage_project(d, planes, s, reinterpret_cast<uint32_t*>(geom + gl.scan_tmp), st));
+        // the reference reads num_rendered back here too (a device->host sync)
+        uint32_t r32 = 0;
+        GS_HIP(hipMemcpyAsync(&r32, s.point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        R = (int)r32;
+    }
+    const BinLayout bl = bin_layout(R);
+    char* bin = binning_alloc(bl.total, binning_user);
+    if (!bin) { set_error("binning allocator returned null"); return GS_ERR_OUT_OF_MEMORY; }
+    s = seam_scratch(geom, gl, img, il, bin, &bl);
+    s.out_color = out_color;
+    d.Rcap = bl.Rcap;
+    if (P > 0) GS_TRY(stage_bin_render(d, s, st));
+    else GS_TRY(launch_render_forward(d, s, st));
+    GS_TRY(launch_ranges(d, s, reinterpret_cast<uint32_t*>(img + il.ranges), st));
+    GS_HIP(hipStreamSynchronize(st));
+    if (num_rendered) *num_rendered = R;
+    return GS_OK;
+}
+
+extern "C" int gs_rasterize_backward(int P, int D_in, int M, int R, const float* background, int width, int height,
+                                     const float* means3D, const float* shs, const float* colors_precomp,
+                                     const float* scales, float scale_modifier, const float* rotations,
+                                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                     const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                                     char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                                     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                                     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                                     int debug) {
+    (void)debug; (void)background; (void)viewmatrix; (void)projmatrix; (void)campos; (void)tan_fovx; (void)tan_fovy;
+    (void)means3D; (void)shs; (void)scales; (void)rotations;  // the geometry chunk already holds all of them
+    if (P < 0 || R < 0 || !geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !dL_dmean2D || !dL_dconic ||
+        !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dsh || !dL_dscale || !dL_drot) {
+        set_error("gs_rasterize_backward: bad arguments");
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    if (colors_precomp || cov3D_precomp || radii) {
+        set_error("gs_rasterize_backward: colors_precomp / cov3D_precomp / radii must be NULL as at the reference call site");
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    int D = 0;
+    GS_TRY(effective_degree(D_in, M, &D));
+    if (P == 0) return GS_OK;
+    const GeomLayout gl = geom_layout(P, M);
+    const ImageLayout il = image_layout(width, height);
+    const BinLayout bl = bin_layout(R);
+    Scratch s = seam_scratch(geom_buffer, gl, image_buffer, il, binning_buffer, &bl);
+    s.dL_dpix = dL_dpix;
+    Dims d = make_dims(P, gl.Pa, D, M, width, height, 1, bl.Rcap, scale_modifier);
+    hipStream_t st = 0;
+    GS_TRY(launch_render_backward(d, s, st));
+    SeamGrads g{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
+    GS_TRY(launch_splat_backward_seam(d, reinterpret_cast<const float*>(geom_buffer + gl.planes), s, g, st));
+    GS_HIP(hipStreamSynchronize(st));
+    return GS_OK;
+}
+
+// =============================================================================================
+// RCCL communicator (librccl resolved lazily so that single-GPU users never load it)
+// =============================================================================================
+namespace {
+struct RcclId { char internal[128]; };
+typedef int (*fn_get_id)(RcclId*);
+typedef int (*fn_init_rank)(void**, int, RcclId, int);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+typedef const char* (*fn_errstr)(int);
+struct Rccl {
+    void* lib = nullptr;
+    fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_allreduce allreduce = nullptr; fn_destroy destroy = nullptr;
+    fn_errstr errstr = nullptr;
+} g_rccl;
+int rccl_load() {
+    if (g_rccl.lib) return GS_OK;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { set_error("cannot load librccl: %s", dlerror()); return GS_ERR_INTERNAL; }
+    g_rccl.get_id = (fn_get_id)dlsym(lib, "ncclGetUniqueId");
+    g_rccl.init_rank = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
+    g_rccl.allreduce = (fn_allreduce)dlsym(lib, "ncclAllReduce");
+    g_rccl.destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
+    g_rccl.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.allreduce || !g_rccl.destroy) { set_error("librccl lacks expected symbols"); return GS_ERR_INTERNAL; }
+    g_rccl.lib = lib;
+    return GS_OK;
+}
+}  // namespace
+
+struct gs_comm { void* comm = nullptr; int rank = 0, n_ranks = 1; };
+
+extern "C" int gs_comm_unique_id(char id[GS_COMM_ID_BYTES]) {
+    if (!id) return GS_ERR_INVALID_ARGUMENT;
+    GS_TRY(rccl_load());
+    RcclId u;
+    const int rc = g_rccl.get_id(&u);
+    if (rc != 0) { set_error("ncclGetUniqueId failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?"); return GS_ERR_INTERNAL; }
+    memcpy(id, u.internal, GS_COMM_ID_BYTES);
+    return GS_OK;
+}
+extern "C" int gs_comm_create(const char id[GS_COMM_ID_BYTES], int rank, int n_ranks, gs_comm** out) {
+    if (!id || !out || rank < 0 || n_ranks < 1 || rank >= n_ranks) return GS_ERR_INVALID_ARGUMENT;
+    GS_TRY(rccl_load());
+    RcclId u;
+    memcpy(u.internal, id, GS_COMM_ID_BYTES);
+    gs_comm* c = new gs_comm();
+    c->rank = rank; c->n_ranks = n_ranks;
+    const int rc = g_rccl.init_rank(&c->comm, n_ranks, u, rank);
+    if (rc != 0) { delete c; set_error("ncclCommInitRank failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?"); return GS_ERR_INTERNAL; }
+    *out = c;
+    return GS_OK;
+}
+extern "C" int gs_comm_destroy(gs_comm* c) {
+    if (!c) return GS_OK;
+    if (c->comm && g_rccl.destroy) g_rccl.destroy(c->comm);
+    delete c;
+    return GS_OK;
+}
+static int rccl_hook(float* buf, size_t n, void* stream, void* user) {
+    gs_comm* c = static_cast<gs_comm*>(user);
+    // ncclFloat32 = 7, ncclSum = 0
+    return g_rccl.allreduce(buf, buf, n, 7, 0, c->comm, (hipStream_t)stream);
+}
+extern "C" int gs_trainer_attach_comm(gs_trainer* t, gs_comm* c) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    if (!c) return gs_trainer_set_allreduce(t, nullptr, nullptr);
+    return gs_trainer_set_allreduce(t, rccl_hook, c);
+}

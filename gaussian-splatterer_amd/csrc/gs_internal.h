@@ -1,0 +1,136 @@
+// gs_internal.h — shared declarations of libgsplat_mi355.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/gsplat.h"
+
+namespace gs {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define GS_HIP(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            gs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return GS_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+#define GS_TRY(expr)            \
+    do {                        \
+        int s__ = (expr);       \
+        if (s__ != GS_OK) return s__; \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// layout constants
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE = 16;           // 16x16-pixel tiles (upstream BLOCK_X/BLOCK_Y)
+constexpr int WG = 256;            // workgroup = 4 wave64
+constexpr int G_STRIDE = 12;       // floats per (splat,tile) gradient slot (9 used, 48-byte rows)
+constexpr int SORT_LDS_CAP = 4096; // entries a tile sorts in LDS; longer lists take the global path
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// Parameter planes of the SoA model, reference order (loc, sh, scale, opacity, rot); the gradient
+// buffer appends one `var` plane.  plane p of splat i lives at base[p * stride + i].
+struct Planes {
+    int M;
+    __host__ __device__ int loc(int c) const { return c; }
+    __host__ __device__ int sh(int k, int c) const { return 3 + k * 3 + c; }
+    __host__ __device__ int scale(int c) const { return 3 + 3 * M + c; }
+    __host__ __device__ int opac() const { return 6 + 3 * M; }
+    __host__ __device__ int rot(int c) const { return 7 + 3 * M + c; }
+    __host__ __device__ int count() const { return 11 + 3 * M; }
+    __host__ __device__ int var() const { return 11 + 3 * M; }  // only in gradient buffers
+};
+
+// 64-byte per-(view,splat) record written by preprocess, gathered by the render kernels.
+struct alignas(16) GeomRec {
+    float x, y, conA, conB;        // means2D, conic.x, conic.y
+    float conC, opacity, r, g;     // conic.z, opacity, rgb.r, rgb.g
+    float b, hx, hy, depth;        // rgb.b, cull half-extents (alpha >= 1/255 box), view depth
+    int radius;                    // 0 = culled
+    uint32_t flags;                // bits 0..2: clamped r,g,b
+    uint32_t rect_min, rect_max;   // x | y << 16
+};
+static_assert(sizeof(GeomRec) == 64, "GeomRec must be one 64-byte line");
+
+struct Dims {
+    int P;        // splats
+    int Pa;       // plane stride (multiple of 64)
+    int D;        // active SH degree 0..3
+    int M;        // SH coefficients per channel (plane count)
+    int W, H, N;  // image
+    int gx, gy, T;
+    int V;        // views in this launch
+    uint32_t Rcap;  // entries per view the binning arena holds
+    float mod;    // scale modifier
+};
+
+// Device pointers of the per-view scratch; every array is [V][...] with the strides in Dims.
+struct Scratch {
+    const gs_view* views;      // [V]
+    GeomRec* geom;             // [V][Pa]
+    uint32_t* tiles_touched;   // [V][Pa]
+    uint32_t* point_offsets;   // [V][Pa]  inclusive scan of tiles_touched
+    uint32_t* tile_count;      // [V][T]
+    uint32_t* tile_end;        // [V][T]   inclusive scan of tile_count
+    uint32_t* tile_cursor;     // [V][T]
+    uint64_t* bins;            // [V][Rcap]  depth_bits << 32 | slot
+    uint32_t* id_of_slot;      // [V][Rcap]
+    uint32_t* point_list;      // [V][Rcap]  sorted splat ids
+    uint32_t* slot_list;       // [V][Rcap]  sorted slots
+    float* G;                  // [V][Rcap][G_STRIDE]
+    float* out_color;          // [V][3][N]
+    float* final_T;            // [V][N]
+    uint32_t* n_contrib;       // [V][N]
+    const uint32_t* truth;     // [V][N] or null
+    const float* dL_dpix;      // [V][3][N] or null (then loss = truth/255 - colour is fused)
+    uint32_t* flags;           // [V][4]: 0 overflow, 1 max tile list
+    float* loss;               // [V] sum of residual^2 (only when truth != null)
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernel launchers (one translation unit each)
+// ---------------------------------------------------------------------------------------------
+int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st);
+int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int batch, uint32_t* partials, hipStream_t st);
+size_t scan_partials_count(int n, int batch);
+int launch_scatter(const Dims& d, const Scratch& s, hipStream_t st);
+int launch_tile_sort(const Dims& d, const Scratch& s, hipStream_t st);
+int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t st);
+int launch_render_backward(const Dims& d, const Scratch& s, hipStream_t st);
+// Trainer form: loops the views, writes the averaged-gradient planes (incl. var) once.
+int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad_planes, hipStream_t st);
+// Seam form: one view, reference-shaped AoS outputs with the reference's += / = discipline.
+struct SeamGrads { float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot; };
+int launch_splat_backward_seam(const Dims& d, const float* params, const Scratch& s, const SeamGrads& g, hipStream_t st);
+int launch_update(const Planes& pl, int P, int Pa, float* params, float* grads, float* adam_m, float* adam_v, int adam_t,
+                  const gs_hyper& h, hipStream_t st);
+int launch_aos_to_soa(int P, int Pa, int M, const float* loc, const float* sh, const float* scale, const float* opac,
+                      const float* rot, float* planes, hipStream_t st);
+int launch_soa_to_aos(int P, int Pa, int M, const float* planes, float* loc, float* sh, float* scale, float* opac,
+                      float* rot, hipStream_t st);
+int launch_image_float_to_int(const float* src, uint32_t* fb, int w, int h, hipStream_t st);
+int launch_image_int_to_loss(const uint32_t* truth, const float* rast, float* loss, int w, int h, hipStream_t st);
+int launch_ranges(const Dims& d, const Scratch& s, uint32_t* ranges, hipStream_t st);
+
+// host-side densify (the reference does this on the CPU too, src/Trainer.cu:433-542)
+int densify_host(float* loc, float* sh, float* scale, float* opac, float* rot, int count, int capacity, int M,
+                 const float* var, const float* grad_loc, const gs_hyper& h);
+
+}  // namespace gs
+
+struct gs_model {
+    int capacity = 0, sh_degree = 0, sh_coeffs = 0, count = 0;
+    int device = 0;
+    int Pa = 0;            // plane stride of `planes`
+    float* planes = nullptr;  // [11+3M][Pa] device
+};

@@ -1,0 +1,195 @@
+// k_preprocess.hip — per-(view,splat) projection: frustum cull, cov3D, EWA cov2D, conic, radius,
+// tile rect, SH colour; per-tile counting.  Replaces the preprocess stage of
+// CudaRasterizer::Rasterizer::forward (reference call site src/Trainer.cu:334-360; algorithm
+// SURVEY.md Appendix A.1).  One thread per splat, blockIdx.y = view; SoA parameter planes give
+// 256-byte coalesced wave loads.  Built with -ffp-contract=off: every fp32 operation here is an
+// individually rounded IEEE operation in the same order as oracle/gs_oracle.cpp::preprocess, so
+// depth, radius and tile rectangle (and therefore the sorted tile lists) are bit-identical.
+#include "gs_internal.h"
+
+namespace gs {
+
+__device__ __constant__ float SH_C0 = 0.28209479177387814f;
+__device__ __constant__ float SH_C1 = 0.4886025119029199f;
+__device__ __constant__ float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                           -1.0925484305920792f, 0.5462742152960396f };
+__device__ __constant__ float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                           0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                           -0.5900435899266435f };
+
+template <int D>
+__global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restrict__ params, Scratch s) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    const int v = blockIdx.y;
+    if (i >= d.P) return;
+    const gs_view& vp = s.views[v];
+    const Planes pl{ d.M };
+    const size_t st = (size_t)d.Pa;
+    GeomRec* rec = s.geom + (size_t)v * st + i;
+    uint32_t* tt = s.tiles_touched + (size_t)v * st + i;
+
+    const float px_ = params[pl.loc(0) * st + i], py_ = params[pl.loc(1) * st + i], pz_ = params[pl.loc(2) * st + i];
+    const float* vm = vp.view;
+    const float* pm = vp.projview;
+    // p_view (transformPoint4x3), near-plane cull
+    const float pvx = vm[0] * px_ + vm[4] * py_ + vm[8] * pz_ + vm[12];
+    const float pvy = vm[1] * px_ + vm[5] * py_ + vm[9] * pz_ + vm[13];
+    const float pvz = vm[2] * px_ + vm[6] * py_ + vm[10] * pz_ + vm[14];
+    bool visible = !(pvz <= 0.2f);
+
+    float conx = 0, cony = 0, conz = 0, pix_x = 0, pix_y = 0, my_radius = 0;
+    int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
+    if (visible) {
+        const float phx = pm[0] * px_ + pm[4] * py_ + pm[8] * pz_ + pm[12];
+        const float phy = pm[1] * px_ + pm[5] * py_ + pm[9] * pz_ + pm[13];
+        const float phw = pm[3] * px_ + pm[7] * py_ + pm[11] * pz_ + pm[15];
+        const float p_w = 1.0f / (phw + 0.0000001f);
+        const float ppx = phx * p_w, ppy = phy * p_w;
+
+        const float sx = d.mod * params[pl.scale(0) * st + i], sy = d.mod * params[pl.scale(1) * st + i],
+                    sz = d.mod * params[pl.scale(2) * st + i];
+        const float r = params[pl.rot(0) * st + i], x = params[pl.rot(1) * st + i], y = params[pl.rot(2) * st + i],
+                    z = params[pl.rot(3) * st + i];
+        float Rg[3][3];
+        Rg[0][0] = 1.0f - 2.0f * (y * y + z * z); Rg[0][1] = 2.0f * (x * y - r * z); Rg[0][2] = 2.0f * (x * z + r * y);
+        Rg[1][0] = 2.0f * (x * y + r * z); Rg[1][1] = 1.0f - 2.0f * (x * x + z * z); Rg[1][2] = 2.0f * (y * z - r * x);
+        Rg[2][0] = 2.0f * (x * z - r * y); Rg[2][1] = 2.0f * (y * z + r * x); Rg[2][2] = 1.0f - 2.0f * (x * x + y * y);
+        float Mm[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { Mm[c][0] = sx * Rg[c][0]; Mm[c][1] = sy * Rg[c][1]; Mm[c][2] = sz * Rg[c][2]; }
+#define GS_SIG(c, rr) (Mm[rr][0] * Mm[c][0] + Mm[rr][1] * Mm[c][1] + Mm[rr][2] * Mm[c][2])
+        const float c30 = GS_SIG(0, 0), c31 = GS_SIG(0, 1), c32 = GS_SIG(0, 2), c33 = GS_SIG(1, 1), c34 = GS_SIG(1, 2),
+                    c35 = GS_SIG(2, 2);
+#undef GS_SIG
+        const float focal_x = (float)d.W / (2.0f * vp.tan_fovx);
+        const float focal_y = (float)d.H / (2.0f * vp.tan_fovy);
+        const float limx = 1.3f * vp.tan_fovx, limy = 1.3f * vp.tan_fovy;
+        const float txtz = pvx / pvz, tytz = pvy / pvz;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * pvz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * pvz;
+        const float tz = pvz;
+        const float J00 = focal_x / tz, J02 = -(focal_x * tx) / (tz * tz);
+        const float J11 = focal_y / tz, J12 = -(focal_y * ty) / (tz * tz);
+        float T[2][3];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            T[0][rr] = vm[4 * rr] * J00 + vm[4 * rr + 2] * J02;
+            T[1][rr] = vm[4 * rr + 1] * J11 + vm[4 * rr + 2] * J12;
+        }
+        const float V[3][3] = { { c30, c31, c32 }, { c31, c33, c34 }, { c32, c34, c35 } };
+        float A[3][2];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) A[k][rr] = T[rr][0] * V[0][k] + T[rr][1] * V[1][k] + T[rr][2] * V[2][k];
+        float ca = A[0][0] * T[0][0] + A[1][0] * T[0][1] + A[2][0] * T[0][2];
+        const float cb = A[0][1] * T[0][0] + A[1][1] * T[0][1] + A[2][1] * T[0][2];
+        float cc = A[0][1] * T[1][0] + A[1][1] * T[1][1] + A[2][1] * T[1][2];
+        ca += 0.3f; cc += 0.3f;
+        const float det = ca * cc - cb * cb;
+        if (det == 0.0f) visible = false;
+        else {
+            const float det_inv = 1.0f / det;
+            conx = cc * det_inv; cony = -cb * det_inv; conz = ca * det_inv;
+            const float mid = 0.5f * (ca + cc);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            my_radius = ceilf(3.0f * sqrtf(fmaxf(lambda1, lambda2)));
+            pix_x = ((ppx + 1.0f) * (float)d.W - 1.0f) * 0.5f;
+            pix_y = ((ppy + 1.0f) * (float)d.H - 1.0f) * 0.5f;
+            const int max_radius = (int)my_radius;
+            rminx = min(d.gx, max(0, (int)((pix_x - (float)max_radius) / (float)TILE)));
+            rminy = min(d.gy, max(0, (int)((pix_y - (float)max_radius) / (float)TILE)));
+            rmaxx = min(d.gx, max(0, (int)((pix_x + (float)max_radius + (float)(TILE - 1)) / (float)TILE)));
+            rmaxy = min(d.gy, max(0, (int)((pix_y + (float)max_radius + (float)(TILE - 1)) / (float)TILE)));
+            if ((rmaxx - rminx) * (rmaxy - rminy) == 0) visible = false;
+        }
+    }
+    if (!visible) {
+        rec->radius = 0;
+        *tt = 0;
+        return;
+    }
+
+    // colour from SH
+    float dx = px_ - vp.campos[0], dy = py_ - vp.campos[1], dz = pz_ - vp.campos[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx = dx / len; dy = dy / len; dz = dz / len;
+    float res[3];
+    uint32_t flags = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float val = SH_C0 * params[pl.sh(0, c) * st + i];
+        if (D > 0) {
+            const float X = dx, Y = dy, Z = dz;
+            val = val - SH_C1 * Y * params[pl.sh(1, c) * st + i] + SH_C1 * Z * params[pl.sh(2, c) * st + i] -
+                  SH_C1 * X * params[pl.sh(3, c) * st + i];
+            if (D > 1) {
+                const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+                val = val + SH_C2[0] * xy * params[pl.sh(4, c) * st + i] + SH_C2[1] * yz * params[pl.sh(5, c) * st + i] +
+                      SH_C2[2] * (2.0f * zz - xx - yy) * params[pl.sh(6, c) * st + i] +
+                      SH_C2[3] * xz * params[pl.sh(7, c) * st + i] + SH_C2[4] * (xx - yy) * params[pl.sh(8, c) * st + i];
+                if (D > 2) {
+                    val = val + SH_C3[0] * Y * (3.0f * xx - yy) * params[pl.sh(9, c) * st + i] +
+                          SH_C3[1] * xy * Z * params[pl.sh(10, c) * st + i] +
+                          SH_C3[2] * Y * (4.0f * zz - xx - yy) * params[pl.sh(11, c) * st + i] +
+                          SH_C3[3] * Z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * params[pl.sh(12, c) * st + i] +
+                          SH_C3[4] * X * (4.0f * zz - xx - yy) * params[pl.sh(13, c) * st + i] +
+                          SH_C3[5] * Z * (xx - yy) * params[pl.sh(14, c) * st + i] +
+                          SH_C3[6] * X * (xx - 3.0f * yy) * params[pl.sh(15, c) * st + i];
+                }
+            }
+        }
+        val += 0.5f;
+        if (val < 0.0f) flags |= (1u << c);
+        res[c] = fmaxf(val, 0.0f);
+    }
+
+    // Cull box: pixels outside |d| <= (hx,hy) provably have alpha < 1/255 (skipped by the blend
+    // anyway).  Conservative margins cover the fp32 error of conic / log / sqrt; non positive-definite
+    // conics disable culling.
+    const float opacity = params[pl.opac() * st + i];
+    float hx, hy;
+    if (!(opacity >= 0.0039f)) {  // 1/255 = 0.003921...: alpha <= opacity can never reach it
+        hx = -1.0f; hy = -1.0f;
+    } else {
+        const float tau = fmaxf(0.0f, __logf(255.0f * opacity)) * 1.01f + 0.01f;
+        const float dc = conx * conz - cony * cony;
+        if (dc > 0.0f && conx > 0.0f && conz > 0.0f && dc < 3.0e38f) {
+            hx = sqrtf(2.0f * tau * conz / dc) * 1.01f + 0.5f;
+            hy = sqrtf(2.0f * tau * conx / dc) * 1.01f + 0.5f;
+            if (!(hx == hx) || !(hy == hy)) { hx = 3.0e38f; hy = 3.0e38f; }
+        } else {
+            hx = 3.0e38f; hy = 3.0e38f;
+        }
+    }
+
+    GeomRec g;
+    g.x = pix_x; g.y = pix_y; g.conA = conx; g.conB = cony;
+    g.conC = conz; g.opacity = opacity; g.r = res[0]; g.g = res[1];
+    g.b = res[2]; g.hx = hx; g.hy = hy; g.depth = pvz;
+    g.radius = (int)my_radius; g.flags = flags;
+    g.rect_min = (uint32_t)rminx | ((uint32_t)rminy << 16);
+    g.rect_max = (uint32_t)rmaxx | ((uint32_t)rmaxy << 16);
+    *rec = g;
+    *tt = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx));
+
+    uint32_t* tc = s.tile_count + (size_t)v * d.T;
+    for (int ty = rminy; ty < rmaxy; ty++)
+        for (int tx = rminx; tx < rmaxx; tx++) atomicAdd(&tc[ty * d.gx + tx], 1u);
+}
+
+int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st) {
+    if (d.P == 0 || d.V == 0) return GS_OK;
+    dim3 grid((d.P + WG - 1) / WG, d.V);
+    switch (d.D) {
+        case 0: hipLaunchKernelGGL(k_preprocess<0>, grid, dim3(WG), 0, st, d, params, s); break;
+        case 1: hipLaunchKernelGGL(k_preprocess<1>, grid, dim3(WG), 0, st, d, params, s); break;
+        case 2: hipLaunchKernelGGL(k_preprocess<2>, grid, dim3(WG), 0, st, d, params, s); break;
+        default: hipLaunchKernelGGL(k_preprocess<3>, grid, dim3(WG), 0, st, d, params, s); break;
+    }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs

@@ -1,0 +1,346 @@
+// k_splat_bwd.hip — per-splat backward: conic -> cov2D -> cov3D & mean (EWA Jacobian), mean2D ->
+// mean (projection), colour -> SH & mean (view direction), cov3D -> scale & rotation.
+// Replaces computeCov2DCUDA + preprocessCUDA inside CudaRasterizer::Rasterizer::backward
+// (reference call site src/Trainer.cu:378-412) and, in the trainer
+// form, fuses the reference's nine cudaMemsets (src/Trainer.cu:366-375) and accumulateGradients
+// (src/Trainer.cu:47-77): one thread owns one splat, walks the views in the reference's order,
+// sums that splat's (splat,tile) gradient rows (contiguous slots, fixed order), and writes every
+// averaged-gradient plane exactly once per step — no per-view read-modify-write, no atomics.
+#include "gs_internal.h"
+
+namespace gs {
+
+namespace {
+constexpr float C0 = 0.28209479177387814f;
+constexpr float C1 = 0.4886025119029199f;
+constexpr float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+constexpr float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                C3_6 = -0.5900435899266435f;
+}  // namespace
+
+template <int D> struct SplatOut {
+    static constexpr int NC = (D + 1) * (D + 1);
+    float mean[3], scale[3], rot[4], cov3D[6];
+    float sh[NC][3];
+};
+
+// in: mean, s = mod*scale, quaternion (r,x,y,z), sh[NC][3], view, clamp flags, the pixel-stage sums
+// (colour 3, mean2D 2, conic x/y/w 3).  Mirrors oracle/gs_oracle.cpp::preprocess_backward.
+template <int D>
+__device__ inline void splat_backward_core(const gs_view& vp, int W, int H, const float mean[3], const float s[3],
+                                           const float q[4], const float (*sh)[3], uint32_t clamp_flags,
+                                           const float dcolor[3], float g2x, float g2y, float gcx, float gcy, float gcz,
+                                           SplatOut<D>& o) {
+    const float* view = vp.view;
+    const float* proj = vp.projview;
+    const float focal_x = (float)W / (2.0f * vp.tan_fovx);
+    const float focal_y = (float)H / (2.0f * vp.tan_fovy);
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    float Rg[3][3];
+    Rg[0][0] = 1.0f - 2.0f * (y * y + z * z); Rg[0][1] = 2.0f * (x * y - r * z); Rg[0][2] = 2.0f * (x * z + r * y);
+    Rg[1][0] = 2.0f * (x * y + r * z); Rg[1][1] = 1.0f - 2.0f * (x * x + z * z); Rg[1][2] = 2.0f * (y * z - r * x);
+    Rg[2][0] = 2.0f * (x * z - r * y); Rg[2][1] = 2.0f * (y * z + r * x); Rg[2][2] = 1.0f - 2.0f * (x * x + y * y);
+    float Mm[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) Mm[c][k] = s[k] * Rg[c][k];
+#define GS_SIG(c, rr) (Mm[rr][0] * Mm[c][0] + Mm[rr][1] * Mm[c][1] + Mm[rr][2] * Mm[c][2])
+    const float c3[6] = { GS_SIG(0, 0), GS_SIG(0, 1), GS_SIG(0, 2), GS_SIG(1, 1), GS_SIG(1, 2), GS_SIG(2, 2) };
+#undef GS_SIG
+
+    // ---- cov2D backward ----
+    float tx = view[0] * mean[0] + view[4] * mean[1] + view[8] * mean[2] + view[12];
+    float ty = view[1] * mean[0] + view[5] * mean[1] + view[9] * mean[2] + view[13];
+    const float tz_ = view[2] * mean[0] + view[6] * mean[1] + view[10] * mean[2] + view[14];
+    const float limx = 1.3f * vp.tan_fovx, limy = 1.3f * vp.tan_fovy;
+    const float txtz = tx / tz_, tytz = ty / tz_;
+    tx = fminf(limx, fmaxf(-limx, txtz)) * tz_;
+    ty = fminf(limy, fmaxf(-limy, tytz)) * tz_;
+    const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+    const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+    const float J00 = focal_x / tz_, J02 = -(focal_x * tx) / (tz_ * tz_);
+    const float J11 = focal_y / tz_, J12 = -(focal_y * ty) / (tz_ * tz_);
+    float T[2][3];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+        T[0][rr] = view[4 * rr] * J00 + view[4 * rr + 2] * J02;
+        T[1][rr] = view[4 * rr + 1] * J11 + view[4 * rr + 2] * J12;
+    }
+    const float V[3][3] = { { c3[0], c3[1], c3[2] }, { c3[1], c3[3], c3[4] }, { c3[2], c3[4], c3[5] } };
+    float A[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) A[k][rr] = T[rr][0] * V[0][k] + T[rr][1] * V[1][k] + T[rr][2] * V[2][k];
+    const float a = A[0][0] * T[0][0] + A[1][0] * T[0][1] + A[2][0] * T[0][2] + 0.3f;
+    const float b = A[0][1] * T[0][0] + A[1][1] * T[0][1] + A[2][1] * T[0][2];
+    const float c = A[0][1] * T[1][0] + A[1][1] * T[1][1] + A[2][1] * T[1][2] + 0.3f;
+    const float denom = a * c - b * b;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float* dcov = o.cov3D;
+    if (denom2inv != 0.0f) {
+        dL_da = denom2inv * (-c * c * gcx + 2.0f * b * c * gcy + (denom - a * c) * gcz);
+        dL_dc = denom2inv * (-a * a * gcz + 2.0f * a * b * gcy + (denom - a * c) * gcx);
+        dL_db = denom2inv * 2.0f * (b * c * gcx - (denom + 2.0f * b * b) * gcy + a * b * gcz);
+        dcov[0] = T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
+        dcov[3] = T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
+        dcov[5] = T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
+        dcov[1] = 2.0f * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + 2.0f * T[1][0] * T[1][1] * dL_dc;
+        dcov[2] = 2.0f * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + 2.0f * T[1][0] * T[1][2] * dL_dc;
+        dcov[4] = 2.0f * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2.0f * T[1][1] * T[1][2] * dL_dc;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) dcov[k] = 0.0f;
+    }
+    float dT[2][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float tv0 = T[0][0] * V[k][0] + T[0][1] * V[k][1] + T[0][2] * V[k][2];
+        const float tv1 = T[1][0] * V[k][0] + T[1][1] * V[k][1] + T[1][2] * V[k][2];
+        dT[0][k] = 2.0f * tv0 * dL_da + tv1 * dL_db;
+        dT[1][k] = 2.0f * tv1 * dL_dc + tv0 * dL_db;
+    }
+    const float dJ00 = view[0] * dT[0][0] + view[4] * dT[0][1] + view[8] * dT[0][2];
+    const float dJ02 = view[2] * dT[0][0] + view[6] * dT[0][1] + view[10] * dT[0][2];
+    const float dJ11 = view[1] * dT[1][0] + view[5] * dT[1][1] + view[9] * dT[1][2];
+    const float dJ12 = view[2] * dT[1][0] + view[6] * dT[1][1] + view[10] * dT[1][2];
+    const float tz = 1.0f / tz_, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = x_grad_mul * -focal_x * tz2 * dJ02;
+    const float dty = y_grad_mul * -focal_y * tz2 * dJ12;
+    const float dtz = -focal_x * tz2 * dJ00 - focal_y * tz2 * dJ11 + (2.0f * focal_x * tx) * tz3 * dJ02 +
+                      (2.0f * focal_y * ty) * tz3 * dJ12;
+    float dmx = view[0] * dtx + view[1] * dty + view[2] * dtz;
+    float dmy = view[4] * dtx + view[5] * dty + view[6] * dtz;
+    float dmz = view[8] * dtx + view[9] * dty + view[10] * dtz;
+
+    // ---- projection of the mean2D gradient ----
+    {
+        const float mhw = proj[3] * mean[0] + proj[7] * mean[1] + proj[11] * mean[2] + proj[15];
+        const float m_w = 1.0f / (mhw + 0.0000001f);
+        const float mul1 = (proj[0] * mean[0] + proj[4] * mean[1] + proj[8] * mean[2] + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mean[0] + proj[5] * mean[1] + proj[9] * mean[2] + proj[13]) * m_w * m_w;
+        dmx += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        dmy += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        dmz += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+    }
+
+    // ---- SH backward ----
+    {
+        const float ox = mean[0] - vp.campos[0], oy = mean[1] - vp.campos[1], oz = mean[2] - vp.campos[2];
+        const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+        const float X = ox / len, Y = oy / len, Z = oz / len;
+        float ddx = 0, ddy = 0, ddz = 0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float dl = dcolor[ch] * (((clamp_flags >> ch) & 1u) ? 0.0f : 1.0f);
+            float dx_ = 0, dy_ = 0, dz_ = 0;
+            o.sh[0][ch] = C0 * dl;
+            if constexpr (D > 0) {
+                o.sh[1][ch] = (-C1 * Y) * dl; o.sh[2][ch] = (C1 * Z) * dl; o.sh[3][ch] = (-C1 * X) * dl;
+                dx_ = -C1 * sh[3][ch]; dy_ = -C1 * sh[1][ch]; dz_ = C1 * sh[2][ch];
+            }
+            if constexpr (D > 1) {
+                const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+                o.sh[4][ch] = (C2_0 * xy) * dl; o.sh[5][ch] = (C2_1 * yz) * dl;
+                o.sh[6][ch] = (C2_2 * (2.0f * zz - xx - yy)) * dl; o.sh[7][ch] = (C2_3 * xz) * dl;
+                o.sh[8][ch] = (C2_4 * (xx - yy)) * dl;
+                dx_ += C2_0 * Y * sh[4][ch] + C2_2 * 2.0f * -X * sh[6][ch] + C2_3 * Z * sh[7][ch] + C2_4 * 2.0f * X * sh[8][ch];
+                dy_ += C2_0 * X * sh[4][ch] + C2_1 * Z * sh[5][ch] + C2_2 * 2.0f * -Y * sh[6][ch] + C2_4 * 2.0f * -Y * sh[8][ch];
+                dz_ += C2_1 * Y * sh[5][ch] + C2_2 * 2.0f * 2.0f * Z * sh[6][ch] + C2_3 * X * sh[7][ch];
+                if constexpr (D > 2) {
+                    o.sh[9][ch] = (C3_0 * Y * (3.0f * xx - yy)) * dl;
+                    o.sh[10][ch] = (C3_1 * xy * Z) * dl;
+                    o.sh[11][ch] = (C3_2 * Y * (4.0f * zz - xx - yy)) * dl;
+                    o.sh[12][ch] = (C3_3 * Z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * dl;
+                    o.sh[13][ch] = (C3_4 * X * (4.0f * zz - xx - yy)) * dl;
+                    o.sh[14][ch] = (C3_5 * Z * (xx - yy)) * dl;
+                    o.sh[15][ch] = (C3_6 * X * (xx - 3.0f * yy)) * dl;
+                    dx_ += C3_0 * sh[9][ch] * 3.0f * 2.0f * xy + C3_1 * sh[10][ch] * yz + C3_2 * sh[11][ch] * -2.0f * xy +
+                           C3_3 * sh[12][ch] * -3.0f * 2.0f * xz + C3_4 * sh[13][ch] * (-3.0f * xx + 4.0f * zz - yy) +
+                           C3_5 * sh[14][ch] * 2.0f * xz + C3_6 * sh[15][ch] * 3.0f * (xx - yy);
+                    dy_ += C3_0 * sh[9][ch] * 3.0f * (xx - yy) + C3_1 * sh[10][ch] * xz +
+                           C3_2 * sh[11][ch] * (-3.0f * yy + 4.0f * zz - xx) + C3_3 * sh[12][ch] * -3.0f * 2.0f * yz +
+                           C3_4 * sh[13][ch] * -2.0f * xy + C3_5 * sh[14][ch] * -2.0f * yz + C3_6 * sh[15][ch] * -3.0f * 2.0f * xy;
+                    dz_ += C3_1 * sh[10][ch] * xy + C3_2 * sh[11][ch] * 4.0f * 2.0f * yz +
+                           C3_3 * sh[12][ch] * 3.0f * (2.0f * zz - xx - yy) + C3_4 * sh[13][ch] * 4.0f * 2.0f * xz +
+                           C3_5 * sh[14][ch] * (xx - yy);
+                }
+            }
+            ddx += dx_ * dl; ddy += dy_ * dl; ddz += dz_ * dl;
+        }
+        const float sum2 = ox * ox + oy * oy + oz * oz;
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dmx += ((+sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+        dmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+        dmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+    }
+    o.mean[0] = dmx; o.mean[1] = dmy; o.mean[2] = dmz;
+
+    // ---- cov3D -> scale, rotation ----
+    {
+        const float dS[3][3] = { { dcov[0], 0.5f * dcov[1], 0.5f * dcov[2] },
+                                 { 0.5f * dcov[1], dcov[3], 0.5f * dcov[4] },
+                                 { 0.5f * dcov[2], 0.5f * dcov[4], dcov[5] } };
+        float dMt[3][3];  // dMt[k][c] = dM[c][k],  dM[c][k] = 2 * sum_j M[j][k] * dS[c][j]
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) dMt[k][cc] = 2.0f * (Mm[0][k] * dS[cc][0] + Mm[1][k] * dS[cc][1] + Mm[2][k] * dS[cc][2]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) o.scale[k] = Rg[0][k] * dMt[k][0] + Rg[1][k] * dMt[k][1] + Rg[2][k] * dMt[k][2];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) dMt[k][cc] *= s[k];
+        o.rot[0] = 2.0f * z * (dMt[0][1] - dMt[1][0]) + 2.0f * y * (dMt[2][0] - dMt[0][2]) + 2.0f * x * (dMt[1][2] - dMt[2][1]);
+        o.rot[1] = 2.0f * y * (dMt[1][0] + dMt[0][1]) + 2.0f * z * (dMt[2][0] + dMt[0][2]) + 2.0f * r * (dMt[1][2] - dMt[2][1]) - 4.0f * x * (dMt[2][2] + dMt[1][1]);
+        o.rot[2] = 2.0f * x * (dMt[1][0] + dMt[0][1]) + 2.0f * r * (dMt[2][0] - dMt[0][2]) + 2.0f * z * (dMt[1][2] + dMt[2][1]) - 4.0f * y * (dMt[2][2] + dMt[0][0]);
+        o.rot[3] = 2.0f * r * (dMt[0][1] - dMt[1][0]) + 2.0f * x * (dMt[2][0] + dMt[0][2]) + 2.0f * y * (dMt[1][2] + dMt[2][1]) - 4.0f * z * (dMt[1][1] + dMt[0][0]);
+    }
+}
+
+// Sum the nine pixel-stage partials of splat i over its `tiles` slots, ascending slot order.
+__device__ inline void gather_rows(const float* __restrict__ Gv, uint32_t first, uint32_t tiles, float sum[9]) {
+#pragma unroll
+    for (int q = 0; q < 9; q++) sum[q] = 0.0f;
+    for (uint32_t k = 0; k < tiles; k++) {
+        const float4* row = reinterpret_cast<const float4*>(Gv + (size_t)(first + k) * G_STRIDE);
+        const float4 a = row[0], b = row[1];
+        const float c = reinterpret_cast<const float*>(row)[8];
+        sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w;
+        sum[4] += b.x; sum[5] += b.y; sum[6] += b.z; sum[7] += b.w; sum[8] += c;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(WG) void k_splat_bwd_avg(Dims d, const float* __restrict__ params, Scratch s, float samples,
+                                                      float* __restrict__ grad) {
+    constexpr int NC = (D + 1) * (D + 1);
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= d.P) return;
+    const Planes pl{ d.M };
+    const size_t st = (size_t)d.Pa;
+    float mean[3], sc[3], q[4], sh[NC][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { mean[c] = params[pl.loc(c) * st + i]; sc[c] = d.mod * params[pl.scale(c) * st + i]; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = params[pl.rot(c) * st + i];
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) sh[k][c] = params[pl.sh(k, c) * st + i];
+
+    float var = 0.0f, aLoc[3] = { 0, 0, 0 }, aScale[3] = { 0, 0, 0 }, aRot[4] = { 0, 0, 0, 0 }, aOpac = 0.0f, aSh[NC][3];
+#pragma unroll
+    for (int k = 0; k < NC; k++) aSh[k][0] = aSh[k][1] = aSh[k][2] = 0.0f;
+
+    for (int v = 0; v < d.V; v++) {
+        if (s.flags[v * 4 + 0] & 1u) continue;
+        const GeomRec* rec = s.geom + (size_t)v * st + i;
+        if (!(rec->radius > 0)) continue;  // culled in this view: all nine reference buffers stay zero
+        const uint32_t tiles = s.tiles_touched[(size_t)v * st + i];
+        const uint32_t first = s.point_offsets[(size_t)v * st + i] - tiles;
+        float sum[9];
+        gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, first, tiles, sum);
+        SplatOut<D> o;
+        splat_backward_core<D>(s.views[v], d.W, d.H, mean, sc, q, sh, rec->flags, sum, sum[3], sum[4], sum[5], sum[6], sum[7], o);
+        // accumulateGradients, src/Trainer.cu:51-76 (division by `samples`, view order)
+        var += sqrtf((o.mean[0] * o.mean[0]) + (o.mean[1] * o.mean[1]) + (o.mean[2] * o.mean[2])) / samples;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { aLoc[c] += o.mean[c] / samples; aScale[c] += o.scale[c] / samples; }
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) aSh[k][c] += o.sh[k][c] / samples;
+        aOpac += sum[8] / samples;
+#pragma unroll
+        for (int c = 0; c < 4; c++) aRot[c] += o.rot[c] / samples;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { grad[pl.loc(c) * st + i] = aLoc[c]; grad[pl.scale(c) * st + i] = aScale[c]; }
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = aSh[k][c];
+    for (int k = NC; k < d.M; k++)
+        for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = 0.0f;
+    grad[pl.opac() * st + i] = aOpac;
+#pragma unroll
+    for (int c = 0; c < 4; c++) grad[pl.rot(c) * st + i] = aRot[c];
+    grad[pl.var() * st + i] = var;
+}
+
+int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, hipStream_t stream) {
+    if (d.P == 0) return GS_OK;
+    dim3 grid((d.P + WG - 1) / WG);
+    switch (d.D) {
+        case 0: hipLaunchKernelGGL(k_splat_bwd_avg<0>, grid, dim3(WG), 0, stream, d, params, s, samples, grad); break;
+        case 1: hipLaunchKernelGGL(k_splat_bwd_avg<1>, grid, dim3(WG), 0, stream, d, params, s, samples, grad); break;
+        case 2: hipLaunchKernelGGL(k_splat_bwd_avg<2>, grid, dim3(WG), 0, stream, d, params, s, samples, grad); break;
+        default: hipLaunchKernelGGL(k_splat_bwd_avg<3>, grid, dim3(WG), 0, stream, d, params, s, samples, grad); break;
+    }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// Seam form: view 0 only, reference-shaped AoS outputs.  Pixel-stage buffers are accumulated into
+// (the reference's atomicAdd targets), the per-splat results are assigned, culled splats untouched.
+template <int D>
+__global__ __launch_bounds__(WG) void k_splat_bwd_seam(Dims d, const float* __restrict__ params, Scratch s, SeamGrads g) {
+    constexpr int NC = (D + 1) * (D + 1);
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= d.P) return;
+    const GeomRec* rec = s.geom + i;
+    if (!(rec->radius > 0)) return;
+    const Planes pl{ d.M };
+    const size_t st = (size_t)d.Pa;
+    float mean[3], sc[3], q[4], sh[NC][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { mean[c] = params[pl.loc(c) * st + i]; sc[c] = d.mod * params[pl.scale(c) * st + i]; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = params[pl.rot(c) * st + i];
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) sh[k][c] = params[pl.sh(k, c) * st + i];
+    const uint32_t tiles = s.tiles_touched[i];
+    const uint32_t first = s.point_offsets[i] - tiles;
+    float sum[9];
+    gather_rows(s.G, first, tiles, sum);
+    float dcolor[3];
+    for (int c = 0; c < 3; c++) { dcolor[c] = g.dL_dcolor[3 * (size_t)i + c] + sum[c]; g.dL_dcolor[3 * (size_t)i + c] = dcolor[c]; }
+    const float g2x = g.dL_dmean2D[3 * (size_t)i] + sum[3], g2y = g.dL_dmean2D[3 * (size_t)i + 1] + sum[4];
+    g.dL_dmean2D[3 * (size_t)i] = g2x; g.dL_dmean2D[3 * (size_t)i + 1] = g2y;
+    const float gcx = g.dL_dconic[4 * (size_t)i] + sum[5], gcy = g.dL_dconic[4 * (size_t)i + 1] + sum[6],
+                gcz = g.dL_dconic[4 * (size_t)i + 3] + sum[7];
+    g.dL_dconic[4 * (size_t)i] = gcx; g.dL_dconic[4 * (size_t)i + 1] = gcy; g.dL_dconic[4 * (size_t)i + 3] = gcz;
+    g.dL_dopacity[i] += sum[8];
+    SplatOut<D> o;
+    splat_backward_core<D>(s.views[0], d.W, d.H, mean, sc, q, sh, rec->flags, dcolor, g2x, g2y, gcx, gcy, gcz, o);
+    for (int c = 0; c < 3; c++) { g.dL_dmean3D[3 * (size_t)i + c] = o.mean[c]; g.dL_dscale[3 * (size_t)i + c] = o.scale[c]; }
+    for (int c = 0; c < 6; c++) g.dL_dcov3D[6 * (size_t)i + c] = o.cov3D[c];
+    for (int c = 0; c < 4; c++) g.dL_drot[4 * (size_t)i + c] = o.rot[c];
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) g.dL_dsh[((size_t)i * d.M + k) * 3 + c] = o.sh[k][c];
+}
+
+int launch_splat_backward_seam(const Dims& d, const float* params, const Scratch& s, const SeamGrads& g, hipStream_t stream) {
+    if (d.P == 0) return GS_OK;
+    dim3 grid((d.P + WG - 1) / WG);
+    switch (d.D) {
+        case 0: hipLaunchKernelGGL(k_splat_bwd_seam<0>, grid, dim3(WG), 0, stream, d, params, s, g); break;
+        case 1: hipLaunchKernelGGL(k_splat_bwd_seam<1>, grid, dim3(WG), 0, stream, d, params, s, g); break;
+        case 2: hipLaunchKernelGGL(k_splat_bwd_seam<2>, grid, dim3(WG), 0, stream, d, params, s, g); break;
+        default: hipLaunchKernelGGL(k_splat_bwd_seam<3>, grid, dim3(WG), 0, stream, d, params, s, g); break;
+    }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs

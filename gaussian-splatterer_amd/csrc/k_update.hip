@@ -1,0 +1,149 @@
+// k_update.hip — parameter update, layout transposes and the reference's two image kernels.
+//   update      : applyGradients (src/Trainer.cu:81-101) as one launch over the SoA planes, rule
+//                 GS_UPDATE_SGD_CLAMP = the reference; GS_UPDATE_ADAM = Adam ascent + the same clamps.
+//   aos<->soa   : ModelSplatsHost layout (src/ModelSplatsHost.h:16-20) <-> plane-major device layout.
+//   image ops   : imageFloatToInt (src/Trainer.cu:19-29), imageIntToLoss (src/Trainer.cu:33-44).
+// All HBM-bound elementwise work: plane-major SoA makes every wave access 256 contiguous bytes.
+#include "gs_internal.h"
+
+namespace gs {
+
+struct UpdateArgs {
+    float lr_loc, lr_sh, lr_scale, lr_opac, lr_rot, scale_max;
+    int rule;
+    float b1, b2, eps, bc1, bc2;
+    int M;
+};
+
+__global__ __launch_bounds__(WG) void k_update(UpdateArgs u, int P, int Pa, float* __restrict__ params,
+                                               const float* __restrict__ grads, float* __restrict__ am,
+                                               float* __restrict__ av) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    const int p = blockIdx.y;
+    if (i >= P) return;
+    const Planes pl{ u.M };
+    // plane group -> learning rate / clamp
+    float lr; int kind;  // 0 plain, 1 scale clamp, 2 opacity clamp
+    if (p < 3) { lr = u.lr_loc; kind = 0; }
+    else if (p < pl.scale(0)) { lr = u.lr_sh; kind = 0; }
+    else if (p < pl.opac()) { lr = u.lr_scale; kind = 1; }
+    else if (p == pl.opac()) { lr = u.lr_opac; kind = 2; }
+    else { lr = u.lr_rot; kind = 0; }
+    const size_t idx = (size_t)p * Pa + i;
+    const float g = grads[idx];
+    float x = params[idx];
+    if (u.rule == GS_UPDATE_ADAM) {
+        float m = am[idx], v = av[idx];
+        m = u.b1 * m + (1.0f - u.b1) * g;
+        v = u.b2 * v + (1.0f - u.b2) * g * g;
+        am[idx] = m; av[idx] = v;
+        const float mh = m / u.bc1, vh = v / u.bc2;
+        x = x + lr * (mh / (sqrtf(vh) + u.eps));
+    } else {
+        x = x + g * lr;
+    }
+    if (kind == 1) x = fminf(u.scale_max, fmaxf(0.0f, x));
+    else if (kind == 2) x = fminf(1.0f, fmaxf(0.0f, x));
+    params[idx] = x;
+}
+
+int launch_update(const Planes& pl, int P, int Pa, float* params, float* grads, float* adam_m, float* adam_v, int adam_t,
+                  const gs_hyper& h, hipStream_t st) {
+    if (P == 0) return GS_OK;
+    UpdateArgs u;
+    u.lr_loc = h.lr_location; u.lr_sh = h.lr_sh; u.lr_scale = h.lr_scale; u.lr_opac = h.lr_opacity; u.lr_rot = h.lr_rotation;
+    u.scale_max = h.scale_max; u.rule = h.update_rule; u.b1 = h.adam_beta1; u.b2 = h.adam_beta2; u.eps = h.adam_eps;
+    u.bc1 = 1.0f - powf(h.adam_beta1, (float)adam_t);
+    u.bc2 = 1.0f - powf(h.adam_beta2, (float)adam_t);
+    u.M = pl.M;
+    hipLaunchKernelGGL(k_update, dim3((P + WG - 1) / WG, pl.count()), dim3(WG), 0, st, u, P, Pa, params,
+                       (const float*)grads, adam_m, adam_v);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+__global__ __launch_bounds__(WG) void k_aos_to_soa(int P, int Pa, int M, const float* __restrict__ loc,
+                                                   const float* __restrict__ sh, const float* __restrict__ scale,
+                                                   const float* __restrict__ opac, const float* __restrict__ rot,
+                                                   float* __restrict__ planes) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= P) return;
+    const Planes pl{ M };
+    const size_t st = (size_t)Pa;
+    for (int c = 0; c < 3; c++) {
+        planes[pl.loc(c) * st + i] = loc[3 * (size_t)i + c];
+        planes[pl.scale(c) * st + i] = scale[3 * (size_t)i + c];
+    }
+    for (int k = 0; k < 3 * M; k++) planes[(3 + k) * st + i] = sh[(size_t)i * 3 * M + k];
+    planes[pl.opac() * st + i] = opac[i];
+    for (int c = 0; c < 4; c++) planes[pl.rot(c) * st + i] = rot[4 * (size_t)i + c];
+}
+
+__global__ __launch_bounds__(WG) void k_soa_to_aos(int P, int Pa, int M, const float* __restrict__ planes,
+                                                   float* __restrict__ loc, float* __restrict__ sh,
+                                                   float* __restrict__ scale, float* __restrict__ opac,
+                                                   float* __restrict__ rot) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= P) return;
+    const Planes pl{ M };
+    const size_t st = (size_t)Pa;
+    for (int c = 0; c < 3; c++) {
+        loc[3 * (size_t)i + c] = planes[pl.loc(c) * st + i];
+        scale[3 * (size_t)i + c] = planes[pl.scale(c) * st + i];
+    }
+    for (int k = 0; k < 3 * M; k++) sh[(size_t)i * 3 * M + k] = planes[(3 + k) * st + i];
+    opac[i] = planes[pl.opac() * st + i];
+    for (int c = 0; c < 4; c++) rot[4 * (size_t)i + c] = planes[pl.rot(c) * st + i];
+}
+
+int launch_aos_to_soa(int P, int Pa, int M, const float* loc, const float* sh, const float* scale, const float* opac,
+                      const float* rot, float* planes, hipStream_t st) {
+    if (P == 0) return GS_OK;
+    hipLaunchKernelGGL(k_aos_to_soa, dim3((P + WG - 1) / WG), dim3(WG), 0, st, P, Pa, M, loc, sh, scale, opac, rot, planes);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+int launch_soa_to_aos(int P, int Pa, int M, const float* planes, float* loc, float* sh, float* scale, float* opac,
+                      float* rot, hipStream_t st) {
+    if (P == 0) return GS_OK;
+    hipLaunchKernelGGL(k_soa_to_aos, dim3((P + WG - 1) / WG), dim3(WG), 0, st, P, Pa, M, planes, loc, sh, scale, opac, rot);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// imageFloatToInt, src/Trainer.cu:19-29: x256 (not x255), clamp to [0,255], opaque alpha
+__global__ __launch_bounds__(WG) void k_image_float_to_int(const float* __restrict__ src, uint32_t* __restrict__ fb, int n) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = (uint32_t)min(255, max(0, (int)(src[i] * 256.0f)));
+    const uint32_t g = (uint32_t)min(255, max(0, (int)(src[i + (size_t)n] * 256.0f)));
+    const uint32_t b = (uint32_t)min(255, max(0, (int)(src[i + 2 * (size_t)n] * 256.0f)));
+    fb[i] = (r << 0) + (g << 8) + (b << 16) + (0xFFu << 24);
+}
+// imageIntToLoss, src/Trainer.cu:33-44
+__global__ __launch_bounds__(WG) void k_image_int_to_loss(const uint32_t* __restrict__ truth, const float* __restrict__ rast,
+                                                          float* __restrict__ loss, int n) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = truth[i];
+    loss[i] = ((float)(t & 0xFF) / 255.0f) - rast[i];
+    loss[i + (size_t)n] = ((float)((t >> 8) & 0xFF) / 255.0f) - rast[i + (size_t)n];
+    loss[i + 2 * (size_t)n] = ((float)((t >> 16) & 0xFF) / 255.0f) - rast[i + 2 * (size_t)n];
+}
+
+int launch_image_float_to_int(const float* src, uint32_t* fb, int w, int h, hipStream_t st) {
+    const int n = w * h;
+    if (n == 0) return GS_OK;
+    hipLaunchKernelGGL(k_image_float_to_int, dim3((n + WG - 1) / WG), dim3(WG), 0, st, src, fb, n);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+int launch_image_int_to_loss(const uint32_t* truth, const float* rast, float* loss, int w, int h, hipStream_t st) {
+    const int n = w * h;
+    if (n == 0) return GS_OK;
+    hipLaunchKernelGGL(k_image_int_to_loss, dim3((n + WG - 1) / WG), dim3(WG), 0, st, truth, rast, loss, n);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs

@@ -1,0 +1,247 @@
+/* gsplat.h — C-ABI of libgsplat_mi355.so: the Gaussian-splat training step of
+ * osreboot/Gaussian-Splatterer (reference v1.1.0) as hand-written HIP for MI355X (gfx950).
+ *
+ * Boundary.  The reference exposes this path as three C++ classes
+ *     ModelSplatsHost    src/ModelSplatsHost.h:8-39
+ *     ModelSplatsDevice  src/ModelSplatsDevice.h:5-30
+ *     Trainer            src/Trainer.cuh:10-75
+ * and consumes, underneath, CudaRasterizer::Rasterizer::forward / ::backward (call sites
+ * src/Trainer.cu:175-201, :334-360, :378-412).  Every entry point below names the reference
+ * interface it replaces.  include/gsplat_shim.hpp re-creates the three classes on top of this
+ * header; INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *   - every function returns a gs_status (0 = OK, negative = error); gs_last_error() gives the
+ *     thread-local message.  No C++ exception crosses this ABI.  The reference's explicit throws
+ *     map to GS_ERR_NO_TRUTH (src/Trainer.cu:253), GS_ERR_DIMENSIONS (src/ModelSplatsHost.cpp:39-42),
+ *     GS_ERR_CAPACITY (:66), GS_ERR_BOUNDS (:80-82).
+ *   - host splat arrays use the reference layout (src/ModelSplatsHost.h:16-20): flat fp32,
+ *     locations[3P], shs[3*M*P] (sh[(i*M + s)*3 + c]), scales[3P], opacities[P], rotations[4P]
+ *     (element 0 = real part).  On the device the library keeps them SoA.
+ *   - matrices are glm column-major float[16] (glm::value_ptr, src/Trainer.cu:323-324).
+ *   - handles are not thread-safe; one caller thread per trainer (the reference's wx UI thread).
+ *   - all device work of a trainer is enqueued on one HIP stream; calls return after enqueue unless
+ *     stated otherwise.
+ */
+#ifndef GSPLAT_H
+#define GSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_VERSION_MAJOR 0
+#define GS_VERSION_MINOR 1
+#define GS_VERSION_PATCH 0
+
+typedef enum gs_status {
+    GS_OK = 0,
+    GS_ERR_INVALID_ARGUMENT = -1,
+    GS_ERR_HIP = -2,          /* a HIP runtime call failed; message carries hipGetErrorString */
+    GS_ERR_NO_TRUTH = -3,     /* "Can't run training iteration, no truth data available!" src/Trainer.cu:253 */
+    GS_ERR_CAPACITY = -4,     /* "Model ran out of capacity!" src/ModelSplatsHost.cpp:66 */
+    GS_ERR_BOUNDS = -5,       /* "Can't copy splat in model, incorrect bounds..." src/ModelSplatsHost.cpp:80-82 */
+    GS_ERR_DIMENSIONS = -6,   /* "Inconsistent feature dimensions..." src/ModelSplatsHost.cpp:39-42 */
+    GS_ERR_OUT_OF_MEMORY = -7,
+    GS_ERR_NO_MODEL = -8,
+    GS_ERR_NO_DEVICE = -9,    /* no gfx950 device / HIP runtime unusable: there is no CPU fallback */
+    GS_ERR_INTERNAL = -10
+} gs_status;
+
+const char* gs_last_error(void);
+const char* gs_status_string(int status);
+int gs_version(int* major, int* minor, int* patch);
+/* Number of visible HIP devices (0 when none); never fails. */
+int gs_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Raw device-memory helpers (current HIP device).  They exist so that C / ctypes callers and the
+ * parity tests can stage buffers for the device-pointer entry points without another runtime.
+ * ------------------------------------------------------------------------------------------ */
+int gs_device_malloc(void** ptr, size_t bytes);
+int gs_device_free(void* ptr);
+int gs_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int gs_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int gs_memset_d(void* dst_dev, int value, size_t bytes);
+int gs_device_synchronize(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Splat model  (replaces class ModelSplatsDevice, src/ModelSplatsDevice.h:5-30)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gs_model gs_model;
+
+/* ModelSplatsDevice(const ModelSplatsHost&), src/ModelSplatsDevice.cpp:24-40.  `count` splats are
+ * uploaded; capacity / sh_degree / sh_coeffs are carried as metadata exactly like the reference.
+ * count == 0 is legal (Trainer's placeholder model, src/Trainer.cu:112). */
+int gs_model_create(int capacity, int sh_degree, int sh_coeffs, int count, const float* locations,
+                    const float* shs, const float* scales, const float* opacities, const float* rotations,
+                    gs_model** out);
+/* ModelSplatsDevice(const ModelSplatsDevice&), src/ModelSplatsDevice.cpp:6-22 (device-to-device clone). */
+int gs_model_clone(const gs_model* src, gs_model** out);
+/* ModelSplatsHost(const ModelSplatsDevice&), src/ModelSplatsHost.cpp:16-26: copies `count` splats to
+ * host arrays in the reference layout.  Synchronous. */
+int gs_model_download(const gs_model* model, float* locations, float* shs, float* scales, float* opacities,
+                      float* rotations);
+/* public fields capacity / shDegree / shCoeffs / count, src/ModelSplatsDevice.h:8-12. */
+int gs_model_info(const gs_model* model, int* capacity, int* sh_degree, int* sh_coeffs, int* count);
+/* ~ModelSplatsDevice, src/ModelSplatsDevice.cpp:42-48. */
+int gs_model_destroy(gs_model* model);
+
+/* ------------------------------------------------------------------------------------------
+ * Trainer  (replaces class Trainer, src/Trainer.cuh:10-75)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gs_trainer gs_trainer;
+
+/* One (camera, background) pass.  The values the reference builds per pass at
+ * src/Trainer.cu:317-326 (bg, view = -lookAt, projview = perspective * view, camera position) and
+ * :355-356 (tan_fovx = tan_fovy = tan(radians(fovDegY)/2)).  40 floats, no padding. */
+typedef struct gs_view {
+    float view[16];
+    float projview[16];
+    float campos[3];
+    float tan_fovx;
+    float tan_fovy;
+    float bg[3];
+} gs_view;
+
+enum { GS_UPDATE_SGD_CLAMP = 0, /* applyGradients, src/Trainer.cu:81-101 — the reference rule */
+       GS_UPDATE_ADAM = 1       /* BASELINE.json extension: Adam ascent, then the same clamps */ };
+enum { GS_QUAT_XYZW = 1, /* glm default member order: densify split permutes the stored quaternion
+                            (src/Trainer.cu:463,493-494) */
+       GS_QUAT_WXYZ = 0 };
+
+/* Run-time hyper-parameters read on every call like Trainer::train reads Project
+ * (src/Project.h:26-41; used at src/Trainer.cu:430-431,451-454,478-481,511). */
+typedef struct gs_hyper {
+    float lr_location, lr_sh, lr_scale, lr_opacity, lr_rotation; /* Project.h:26-30 */
+    float scale_max;                                             /* paramScaleMax, Project.h:32 */
+    float cull_opacity, cull_size, densify_variance;             /* Project.h:34-36 */
+    float split_size, split_distance, split_scale, clone_distance; /* Project.h:38-41 */
+    int update_rule;                                             /* GS_UPDATE_* */
+    float adam_beta1, adam_beta2, adam_eps;
+    int quat_layout;                                             /* GS_QUAT_* (densify only) */
+} gs_hyper;
+/* Project's defaults (src/Project.h:26-41), SGD_CLAMP, beta 0.9/0.999, eps 1e-15, GS_QUAT_XYZW. */
+int gs_hyper_defaults(gs_hyper* out);
+
+typedef struct gs_step_stats {
+    int count_before, count_after; /* model->count around the step */
+    int views;                     /* local passes executed */
+    long long num_rendered;        /* sum over local views of the rasterizer's num_rendered (R) */
+    int max_tile_list;             /* longest per-tile list seen this step */
+    int arena_regrows;             /* times the binning arena had to grow and the step was replayed */
+    float loss;                    /* sum over local views and pixels of residual^2 (diagnostic) */
+} gs_step_stats;
+
+/* Trainer::Trainer(), src/Trainer.cu:103-113.  width/height replace the compile-time
+ * RENDER_RESOLUTION_X/Y (src/Config.h:13-14).  Binds to the current HIP device. */
+int gs_trainer_create(int width, int height, gs_trainer** out);
+/* Trainer::~Trainer(), src/Trainer.cu:115-146 (also destroys the owned model). */
+int gs_trainer_destroy(gs_trainer* trainer);
+/* The `delete trainer->model; trainer->model = new ModelSplatsDevice(host);` idiom
+ * (src/ui/UiFrame.cpp:157-158,173-174,261-262,448-449).  The trainer takes ownership of `model`
+ * and destroys the previous one.  Optimizer state (Adam) is reset. */
+int gs_trainer_set_model(gs_trainer* trainer, gs_model* model);
+/* public member Trainer::model, src/Trainer.cuh:50 (borrowed pointer; owned by the trainer). */
+gs_model* gs_trainer_get_model(gs_trainer* trainer);
+/* Replaces Trainer::captureTruths (src/Trainer.cu:218-250), whose OptiX renderer is out of scope:
+ * the caller supplies the passes this process owns and their truth images (RGBA8, R in the low
+ * byte, width*height each; src/rtx/RtxDevice.cu:100).  `truth[i]` is a host pointer, or a device
+ * pointer when truth_on_device != 0; images are copied.  `total_samples` is S, the number of
+ * passes of the whole iteration over ALL processes (2 * #cameras, src/Trainer.cu:419): equal to
+ * n_views on one GPU, larger when views are sharded. */
+int gs_trainer_set_views(gs_trainer* trainer, int n_views, const gs_view* views, const uint32_t* const* truth,
+                         int truth_on_device, int total_samples);
+/* Trainer::train(Project&, bool densify), src/Trainer.cu:252-543: all local passes (forward, loss,
+ * backward, gradient averaging), the collective hook if one is installed, the parameter update,
+ * and densify/prune when `densify` != 0.  The caller increments its own Project::iterations
+ * (src/Trainer.cu:255).  Synchronises with the device once (arena check) and fully when
+ * densify != 0 or stats != NULL. */
+int gs_trainer_step(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs_step_stats* stats);
+
+/* The same step split at the point where data-parallel ranks exchange gradients:
+ *   gs_trainer_accumulate : src/Trainer.cu:303-425 for the local passes
+ *   gs_trainer_grad_buffer: the averaged-gradient buffer [loc 3 | sh 3M | scale 3 | opacity 1 |
+ *                           rot 4 | var 1] planes x plane stride floats, contiguous, fp32 (device)
+ *   gs_trainer_apply      : src/Trainer.cu:427-542 (update, optional densify) */
+int gs_trainer_accumulate(gs_trainer* trainer, gs_step_stats* stats);
+int gs_trainer_grad_buffer(gs_trainer* trainer, float** device_ptr, size_t* n_floats);
+int gs_trainer_apply(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs_step_stats* stats);
+
+/* Collective hook called by gs_trainer_step between accumulate and apply: must sum `n_floats`
+ * fp32 values at `device_buf` in place over all ranks, enqueued on `hip_stream`.  Return 0 on success. */
+typedef int (*gs_allreduce_fn)(float* device_buf, size_t n_floats, void* hip_stream, void* user);
+int gs_trainer_set_allreduce(gs_trainer* trainer, gs_allreduce_fn fn, void* user);
+/* The HIP stream (hipStream_t) all of this trainer's work is enqueued on. */
+int gs_trainer_get_stream(gs_trainer* trainer, void** hip_stream);
+int gs_trainer_synchronize(gs_trainer* trainer);
+
+/* Trainer::render(uint32_t* frameBuffer, int sizeX, int sizeY, float splatScale, const Camera&),
+ * src/Trainer.cu:148-216: forward only, RGBA8 out via imageFloatToInt (:19-29).  `view->bg` is
+ * honoured (the reference passes black, :151); `view->tan_fovx` carries the reference's
+ * tan(radians(sizeX*fovY/sizeY)/2) (:196).  Synchronous like the reference (:215). */
+int gs_trainer_render(gs_trainer* trainer, uint32_t* framebuffer, int fb_on_device, int size_x, int size_y,
+                      float splat_scale, const gs_view* view);
+/* Diagnostics for tests: copy pass `view_index`'s last rendered float image [3][H][W] to host. */
+int gs_trainer_read_image(gs_trainer* trainer, int view_index, float* host_chw);
+
+/* ------------------------------------------------------------------------------------------
+ * Native RCCL communicator for the hook above (one process per GPU, xGMI within a node).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gs_comm gs_comm;
+#define GS_COMM_ID_BYTES 128
+int gs_comm_unique_id(char id[GS_COMM_ID_BYTES]);                 /* ncclGetUniqueId on one rank */
+int gs_comm_create(const char id[GS_COMM_ID_BYTES], int rank, int n_ranks, gs_comm** out); /* ncclCommInitRank */
+int gs_comm_destroy(gs_comm* comm);
+/* Installs an RCCL sum all-reduce of the gradient buffer as the trainer's collective hook. */
+int gs_trainer_attach_comm(gs_trainer* trainer, gs_comm* comm);
+
+/* ------------------------------------------------------------------------------------------
+ * Inner seam: the rasterizer pair the reference calls.  Same argument order as
+ * CudaRasterizer::Rasterizer::forward (26 args, src/Trainer.cu:175-201 / :334-360) and ::backward
+ * (34 args, src/Trainer.cu:378-412); std::function allocators become (fn, user) pairs.  All data
+ * pointers are DEVICE pointers in the reference (AoS) layout.  colors_precomp, cov3D_precomp and
+ * radii must be NULL and prefiltered 0, as at every reference call site.  The three chunks are
+ * opaque; gs_raster_chunk_field() locates arrays inside them for inspection.  Synchronous.
+ * ------------------------------------------------------------------------------------------ */
+typedef char* (*gs_alloc_fn)(size_t bytes, void* user);
+
+int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_user, gs_alloc_fn binning_alloc,
+                         void* binning_user, gs_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                         const float* background, int width, int height, const float* means3D, const float* shs,
+                         const float* colors_precomp, const float* opacities, const float* scales,
+                         float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                         float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
+                         int* num_rendered);
+
+int gs_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                          const float* means3D, const float* shs, const float* colors_precomp,
+                          const float* scales, float scale_modifier, const float* rotations,
+                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                          const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                          char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                          float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                          float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                          int debug);
+
+/* Byte offset and size of a named array inside one of the three chunks.  chunk: "geometry",
+ * "binning" or "image".  Geometry fields: "record" (64-byte per-splat records: means2D, conic,
+ * opacity, rgb, cull box, depth, radius, clamp flags, tile rect), "tiles_touched", "point_offsets".
+ * Binning fields: "point_list" (u32[R], the sorted splat ids), "point_list_slots".
+ * Image fields: "ranges" (u32x2 per tile), "final_T", "n_contrib". */
+int gs_raster_chunk_field(const char* chunk, const char* field, int P, int width, int height, int R,
+                          size_t* offset, size_t* bytes);
+
+/* The reference's two image kernels as device entry points (device pointers; synchronous):
+ * imageFloatToInt src/Trainer.cu:19-29 and imageIntToLoss src/Trainer.cu:33-44. */
+int gs_image_float_to_int(const float* source_chw, uint32_t* framebuffer, int w, int h);
+int gs_image_int_to_loss(const uint32_t* truth, const float* rasterized_chw, float* loss_chw, int w, int h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_H */

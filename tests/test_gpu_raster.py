@@ -1,0 +1,205 @@
+"""GPU parity at the rasterizer seam: gs_rasterize_forward / gs_rasterize_backward (HIP, through the
+C-ABI) against the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): tile / sort indices bit-exact; pixels and gradients <= 1e-4 relative.
+The projection stage is bit-exact by construction (same fp32 operation order, no FMA contraction), so
+every per-splat geometry field is compared with ==.  The blend differs from the oracle only through
+exp() (hardware v_exp_f32 vs libm): pixels that sit within 1e-3 relative of one of the blend's
+discrete thresholds (alpha = 1/255, T = 1e-4) are reported by the oracle (`margin`) and excluded from
+the per-pixel comparisons; everything else must meet 1e-4."""
+import numpy as np
+import pytest
+
+import util
+from util import REC_DTYPE, SeamRaster, assert_close_rel, make_scene, oracle_forward, view_parts
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # P,   M, D, W,   H,   seed
+    (1000, 4, 1, 256, 256, 0x5EED0001),   # BASELINE cfg1
+    (800, 1, 0, 250, 130, 11),            # SH degree 0, ragged size (not multiples of 16)
+    (600, 9, 2, 96, 160, 12),
+    (500, 16, 3, 128, 128, 13),
+]
+
+
+def _check_forward(orc, s, D, M, vp, W, H, mod=1.0, min_solid=0.99):
+    sr = SeamRaster()
+    out, R = sr.forward(s, D, M, vp, W, H, mod)
+    r, oout, oR = oracle_forward(orc, s, D, M, vp, W, H, mod)
+    assert R == oR
+    P = s["opac"].size
+    rec = sr.field("geometry", "record", np.uint8).view(REC_DTYPE)
+    radii = r.get("radii")
+    vis = radii > 0
+    assert np.array_equal(np.where(vis, rec["radius"], 0), radii)
+    assert np.array_equal(sr.field("geometry", "tiles_touched", np.uint32), r.get("tiles_touched"))
+    assert np.array_equal(sr.field("geometry", "point_offsets", np.uint32), r.get("point_offsets"))
+    if vis.any():
+        m2 = r.get("means2D").reshape(P, 2)
+        co = r.get("conic_opacity").reshape(P, 4)
+        rgb = r.get("rgb").reshape(P, 3)
+        # bit-exact geometry state
+        for name, got, want in [("means2D.x", rec["x"], m2[:, 0]), ("means2D.y", rec["y"], m2[:, 1]),
+                                ("conic.x", rec["conA"], co[:, 0]), ("conic.y", rec["conB"], co[:, 1]),
+                                ("conic.z", rec["conC"], co[:, 2]), ("opacity", rec["opacity"], co[:, 3]),
+                                ("rgb.r", rec["r"], rgb[:, 0]), ("rgb.g", rec["g"], rgb[:, 1]), ("rgb.b", rec["b"], rgb[:, 2]),
+                                ("depth", rec["depth"], r.get("depth"))]:
+            assert np.array_equal(got[vis].view(np.uint32), want[vis].view(np.uint32)), name
+        cl = r.get("clamped").reshape(P, 3)
+        flags = cl[:, 0].astype(np.uint32) | (cl[:, 1].astype(np.uint32) << 1) | (cl[:, 2].astype(np.uint32) << 2)
+        assert np.array_equal(rec["flags"][vis], flags[vis])
+        rect = r.get("rect").reshape(P, 4)
+        assert np.array_equal(rec["rect_min"][vis], (rect[:, 0] | (rect[:, 1] << 16))[vis])
+        assert np.array_equal(rec["rect_max"][vis], (rect[:, 2] | (rect[:, 3] << 16))[vis])
+    # bit-exact sorted lists and tile ranges
+    assert np.array_equal(sr.field("binning", "point_list", np.uint32), r.get("point_list"))
+    assert np.array_equal(sr.field("image", "ranges", np.uint32), r.get("ranges"))
+    # pixels
+    margin = r.get("margin")
+    solid = margin > 1e-3
+    assert solid.mean() > min_solid
+    ncon = sr.field("image", "n_contrib", np.uint32)
+    assert np.array_equal(ncon[solid], r.get("n_contrib")[solid])
+    fT = sr.field("image", "final_T", np.float32)
+    assert_close_rel("final_T", fT[solid], r.get("final_T")[solid], rtol=1e-4, floor=1e-4)
+    for c in range(3):
+        assert_close_rel(f"out_color[{c}]", out[c].reshape(-1)[solid], oout[c].reshape(-1)[solid], rtol=1e-4, floor=1e-3)
+    # fragile pixels may flip one threshold decision: bounded by one blend term
+    assert np.abs(out - oout).max() <= 0.02
+    return sr, r, out, oout
+
+
+@pytest.mark.parametrize("P,M,D,W,H,seed", CASES)
+def test_forward_parity(orc, P, M, D, W, H, seed):
+    s, cams, views = make_scene(P, M, seed, W, H, n_cams=2)
+    for v in (0, 3):  # white background camera 0, black background camera 1
+        _check_forward(orc, s, D, M, view_parts(views[v]), W, H)
+
+
+@pytest.mark.parametrize("P,M,D,W,H,seed", CASES)
+def test_backward_parity(orc, P, M, D, W, H, seed):
+    s, cams, views = make_scene(P, M, seed, W, H, n_cams=2)
+    vp = view_parts(views[1])
+    sr, r, out, oout = _check_forward(orc, s, D, M, vp, W, H)
+    rng = np.random.default_rng(seed)
+    dpix = rng.uniform(-1, 1, (3, H, W)).astype(np.float32)
+    g = sr.backward(dpix)
+    og = r.backward(dpix, want_abs=True)
+    abs9 = og["abs9"]  # per splat sum|term| of the nine pixel-stage sums
+    # pixel-stage sums: error budget is relative to sum|term| (fp32 summation), 1e-4 of it
+    idx = {"dL_dcolor": ([0, 1, 2], 3, [0, 1, 2]), "dL_dmean2D": ([3, 4], 3, [0, 1]), "dL_dconic": ([5, 6, 7], 4, [0, 1, 3]),
+           "dL_dopacity": ([8], 1, [0])}
+    for name, (qs, stride, cols) in idx.items():
+        got = g[name].reshape(P, stride)
+        want = og[name].reshape(P, stride)
+        for q, c in zip(qs, cols):
+            tol = 1e-4 * np.maximum(abs9[:, q], 1e-3 * abs9[:, q].max() + 1e-30)
+            bad = np.abs(got[:, c].astype(np.float64) - want[:, c]) > tol
+            assert bad.mean() <= 0.002, (name, c, int(bad.sum()))
+    # per-splat chain outputs: 1e-4 relative to the array scale
+    for name in ["dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"]:
+        assert_close_rel(name, g[name], og[name], rtol=1e-4, floor=None, max_bad_frac=0.002)
+    # culled splats: all nine buffers exactly zero (src/Trainer.cu:366-375 + radii>0 guard)
+    culled = r.get("radii") <= 0
+    if culled.any():
+        for name, stride in [("dL_dmean3D", 3), ("dL_dscale", 3), ("dL_drot", 4), ("dL_dopacity", 1)]:
+            assert not g[name].reshape(P, stride)[culled].any()
+
+
+def test_backward_accumulates_into_pixel_stage_buffers(orc):
+    """The reference's backward atomically ADDS into dL_dmean2D / dL_dconic / dL_dcolor / dL_dopacity
+    (hence the memsets at src/Trainer.cu:366-375) and ASSIGNS the per-splat results."""
+    P, M, D, W, H = 300, 4, 1, 64, 64
+    s, cams, views = make_scene(P, M, 5, W, H)
+    vp = view_parts(views[0])
+    sr = SeamRaster()
+    sr.forward(s, D, M, vp, W, H)
+    dpix = np.random.default_rng(0).uniform(-1, 1, (3, H, W)).astype(np.float32)
+    g0 = sr.backward(dpix)
+    g1 = sr.backward(dpix, prefill={"dL_dopacity": 2.0, "dL_dscale": 5.0})
+    vis = sr.field("geometry", "record", np.uint8).view(REC_DTYPE)["radius"] > 0
+    assert np.allclose(g1["dL_dopacity"][vis], g0["dL_dopacity"][vis] + 2.0, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(g1["dL_dscale"].reshape(P, 3)[vis], g0["dL_dscale"].reshape(P, 3)[vis])  # assigned
+    assert np.all(g1["dL_dscale"].reshape(P, 3)[~vis] == 5.0)  # untouched for culled splats
+
+
+def test_backward_bitwise_reproducible():
+    P, M, D, W, H = 2000, 4, 1, 128, 128
+    s, cams, views = make_scene(P, M, 21, W, H)
+    vp = view_parts(views[0])
+    dpix = np.random.default_rng(1).uniform(-1, 1, (3, H, W)).astype(np.float32)
+    res = []
+    for _ in range(2):
+        sr = SeamRaster()
+        sr.forward(s, D, M, vp, W, H)
+        res.append(sr.backward(dpix))
+    for k in res[0]:
+        assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
+
+
+def test_empty_and_all_culled(orc):
+    W, H, M, D = 48, 40, 4, 1
+    s, cams, views = make_scene(10, M, 3, W, H)
+    vp = view_parts(views[0])
+    # P = 0: image is the background
+    empty = {k: (v[:0] if hasattr(v, "shape") else v) for k, v in s.items()}
+    sr = SeamRaster()
+    out, R = sr.forward(empty, D, M, vp, W, H)
+    assert R == 0 and np.all(out == 1.0)
+    # every splat behind the camera
+    behind = dict(s)
+    behind["loc"] = (np.tile(vp["campos"], 10) * 3.0).astype(np.float32)
+    out, R = SeamRaster().forward(behind, D, M, vp, W, H)
+    assert R == 0 and np.all(out == 1.0)
+
+
+def test_long_tile_lists_take_the_spill_path(orc):
+    """> 4096 entries in one tile: the sort leaves LDS for the global scratch path; lists stay bit-exact."""
+    P, M, D, W, H = 6000, 1, 0, 32, 32
+    s = util.gs.synth.random_splats(P, M, 99)
+    s["loc"] = (s["loc"] * 0.05).astype(np.float32)  # everything projects into the same few tiles
+    s["opac"] = (s["opac"] * 0.02).astype(np.float32)
+    cams = util.gs.camera.get_cameras(1, 10.0, 20.0)
+    vp = view_parts(util.gs.camera.train_views(cams, W, H)[0])
+    sr, r, out, oout = _check_forward(orc, s, D, M, vp, W, H, min_solid=0.9)
+    ranges = r.get("ranges").reshape(-1, 2)
+    assert (ranges[:, 1] - ranges[:, 0]).max() > 4096
+    dpix = np.ones((3, H, W), np.float32)
+    g = sr.backward(dpix)
+    og = r.backward(dpix)
+    assert_close_rel("dL_dopacity", g["dL_dopacity"], og["dL_dopacity"], rtol=1e-4, max_bad_frac=0.002)
+
+
+def test_elongated_splats_cull_box_is_conservative(orc):
+    """Needle-shaped and huge splats stress the alpha>=1/255 cull box: results must not change."""
+    P, M, D, W, H = 400, 4, 1, 160, 96
+    s, cams, views = make_scene(P, M, 31, W, H)
+    rng = np.random.default_rng(4)
+    sc = s["scale"].reshape(P, 3)
+    sc[:, 0] *= rng.choice([1.0, 30.0, 80.0], P).astype(np.float32)
+    sc[:, 2] *= rng.choice([1.0, 0.02], P).astype(np.float32)
+    s["opac"] = rng.choice([0.002, 0.004, 0.01, 0.5, 1.0], P).astype(np.float32)
+    vp = view_parts(views[0])
+    sr, r, out, oout = _check_forward(orc, s, D, M, vp, W, H)
+    dpix = rng.uniform(-1, 1, (3, H, W)).astype(np.float32)
+    g, og = sr.backward(dpix), r.backward(dpix)
+    for name in ["dL_dmean3D", "dL_dscale", "dL_drot", "dL_dopacity", "dL_dsh"]:
+        assert_close_rel(name, g[name], og[name], rtol=1e-4, max_bad_frac=0.01)
+
+
+def test_scale_modifier_and_image_kernels(orc):
+    P, M, D, W, H = 500, 4, 1, 64, 80
+    s, cams, views = make_scene(P, M, 8, W, H)
+    vp = view_parts(views[1])
+    sr, r, out, oout = _check_forward(orc, s, D, M, vp, W, H, mod=1.7)
+    from gsplat_amd import capi
+    dout = capi.DeviceBuffer.from_numpy(out)
+    fb = capi.DeviceBuffer(W * H * 4)
+    capi.check(capi.lib().gs_image_float_to_int(dout.ptr, fb.ptr, W, H))
+    assert np.array_equal(fb.to_numpy(np.uint32), orc.image_float_to_int(out, W, H))
+    loss = capi.DeviceBuffer(3 * W * H * 4)
+    capi.check(capi.lib().gs_image_int_to_loss(fb.ptr, dout.ptr, loss.ptr, W, H))
+    assert np.array_equal(loss.to_numpy(np.float32).view(np.uint32),
+                          orc.image_int_to_loss(fb.to_numpy(np.uint32), out, W, H).view(np.uint32))

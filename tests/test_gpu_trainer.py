@@ -1,0 +1,194 @@
+"""GPU parity of the whole step (Trainer::train, src/Trainer.cu:252-543) through the C-ABI / Python
+mirror against the oracle's restatement of the same step, plus preview render, densify, model
+round trips and the reference's error behaviour."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gsplat_amd as gs
+from gsplat_amd import capi
+from util import assert_close_rel, view_parts
+
+pytestmark = pytest.mark.gpu
+
+
+def _truths(orc, P2, M, seed, cams, W, H):
+    """Truth images as SURVEY §8d prescribes: quantised render of a second random splat set."""
+    t = gs.synth.random_splats(P2, M, seed)
+    views = gs.camera.train_views(cams, W, H)
+    Cn = len(cams)
+    fw, fb = [], []
+    for v in range(2 * Cn):
+        vp = view_parts(views[v])
+        r = orc.Rasterizer(np.float32)
+        out, _ = r.forward(t["D"], M, vp["bg"], W, H, t["loc"], t["sh"], t["opac"], t["scale"], 1.0, t["rot"], vp["view"],
+                           vp["proj"], vp["campos"], vp["tanx"], vp["tany"])
+        (fw if v < Cn else fb).append(orc.image_float_to_int(out, W, H))
+    return fw, fb
+
+
+def _setup(orc, P, M, n_cams, W, H, seed):
+    s = gs.synth.random_splats(P, M, seed)
+    cams = gs.camera.get_cameras(n_cams)
+    fw, fb = _truths(orc, max(P // 2, 1), M, seed + 1000, cams, W, H)
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = s["D"]
+    tr = gs.Trainer(W, H)
+    tr.model = gs.ModelSplatsDevice(host)
+    tr.captureTruths(cams, fw, fb)
+    return s, cams, fw, fb, tr
+
+
+def _read_grads(tr, P, M):
+    ptr, n = tr.grad_buffer()
+    tr.synchronize()
+    planes = 12 + 3 * M
+    Pa = n // planes
+    buf = np.empty(n, np.float32)
+    capi.check(capi.lib().gs_memcpy_d2h(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n * 4))
+    pl = buf.reshape(planes, Pa)[:, :P]
+    return dict(loc=np.ascontiguousarray(pl[0:3].T).reshape(-1), sh=np.ascontiguousarray(pl[3:3 + 3 * M].T).reshape(-1),
+                scale=np.ascontiguousarray(pl[3 + 3 * M:6 + 3 * M].T).reshape(-1), opac=pl[6 + 3 * M].copy(),
+                rot=np.ascontiguousarray(pl[7 + 3 * M:11 + 3 * M].T).reshape(-1), var=pl[11 + 3 * M].copy())
+
+
+def _download(tr):
+    h = gs.ModelSplatsHost.fromDevice(tr.model)
+    n, M = h.count, h.shCoeffs
+    return dict(loc=h.locations[:3 * n].copy(), sh=h.shs[:3 * M * n].copy(), scale=h.scales[:3 * n].copy(),
+                opac=h.opacities[:n].copy(), rot=h.rotations[:4 * n].copy(), count=n)
+
+
+@pytest.mark.parametrize("P,M,n_cams,W,H", [(1000, 4, 1, 256, 256),   # BASELINE cfg1 (+ its black-background twin)
+                                              (1500, 1, 3, 128, 96),
+                                              (700, 16, 2, 112, 112)])
+def test_step_sgd_matches_oracle(orc, P, M, n_cams, W, H):
+    s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 0x5EED0001)
+    proj = gs.Project()
+    st = tr.train(proj, densify=False, stats=True)
+    assert proj.iterations == 1 and st.views == 2 * n_cams and st.count_after == P
+    views = gs.camera.train_views(cams, W, H)
+    truths = np.concatenate(fw + fb)
+    o = orc.train_views(P, s["D"], M, W, H, s["loc"], s["sh"], s["scale"], s["opac"], s["rot"], views, truths, 2.0 * n_cams)
+    assert st.num_rendered == int(o["num_rendered"].sum())
+    g = _read_grads(tr, P, M)
+    for k in ["loc", "sh", "scale", "opac", "rot", "var"]:
+        assert_close_rel("avg_" + k, g[k], o[k], rtol=1e-4, max_bad_frac=0.002)
+    # the update itself is bit-exact: applyGradients on the GPU's own averaged gradients
+    want = {k: s[k].copy() for k in ["loc", "sh", "scale", "opac", "rot"]}
+    orc.apply_sgd(want["loc"], want["sh"], want["scale"], want["opac"], want["rot"], g,
+                  (proj.lrLocation, proj.lrSh, proj.lrScale, proj.lrOpacity, proj.lrRotation), proj.paramScaleMax, M)
+    got = _download(tr)
+    for k in want:
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+    tr.close()
+
+
+def test_step_adam_matches_oracle(orc):
+    P, M, n_cams, W, H = 800, 4, 2, 96, 96
+    s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 77)
+    proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=1e-3, lrSh=2e-3, lrScale=5e-4, lrOpacity=1e-3, lrRotation=1e-3)
+    want = {k: s[k].copy() for k in ["loc", "sh", "scale", "opac", "rot"]}
+    m = np.zeros((11 + 3 * M) * P, np.float32)
+    v = np.zeros_like(m)
+    for t in range(1, 4):
+        tr.train(proj, stats=True)
+        g = _read_grads(tr, P, M)
+        orc.apply_adam(want["loc"], want["sh"], want["scale"], want["opac"], want["rot"], g, m, v, t,
+                       (proj.lrLocation, proj.lrSh, proj.lrScale, proj.lrOpacity, proj.lrRotation), proj.paramScaleMax,
+                       proj.adamBeta1, proj.adamBeta2, proj.adamEps, M)
+        got = _download(tr)
+        for k in want:
+            assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (t, k)
+    tr.close()
+
+
+def test_training_reduces_loss(orc):
+    P, M, n_cams, W, H = 2000, 4, 2, 128, 128
+    s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 5)
+    proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=2e-3, lrSh=5e-3, lrScale=5e-4, lrOpacity=5e-3, lrRotation=1e-3)
+    losses = [tr.train(proj, stats=True).loss for _ in range(25)]
+    assert losses[-1] < 0.9 * losses[0], losses
+    tr.close()
+
+
+def test_densify_matches_oracle(orc):
+    P, M, n_cams, W, H = 1200, 4, 2, 96, 96
+    s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 123)
+    # thresholds chosen so that all three actions fire on the synthetic scene
+    proj = gs.Project(paramDensifyVariance=0.05, paramCullOpacity=0.15, paramSplitSize=0.06)
+    h = proj.hyper()
+    L = capi.lib()
+    tr._upload_views()
+    capi.check(L.gs_trainer_accumulate(tr.handle, None))
+    g = _read_grads(tr, P, M)
+    st = capi.gs_step_stats()
+    capi.check(L.gs_trainer_apply(tr.handle, C.byref(h), 1, C.byref(st)))
+    got = _download(tr)
+    cap = 1000000
+    want = {k: np.zeros(cap * n, np.float32) for k, n in [("loc", 3), ("sh", 3 * M), ("scale", 3), ("opac", 1), ("rot", 4)]}
+    pre = {k: s[k].copy() for k in ["loc", "sh", "scale", "opac", "rot"]}
+    orc.apply_sgd(pre["loc"], pre["sh"], pre["scale"], pre["opac"], pre["rot"], g,
+                  (proj.lrLocation, proj.lrSh, proj.lrScale, proj.lrOpacity, proj.lrRotation), proj.paramScaleMax, M)
+    for k in want:
+        want[k][:pre[k].size] = pre[k]
+    hp = dict(cull_opacity=proj.paramCullOpacity, cull_size=proj.paramCullSize, densify_variance=proj.paramDensifyVariance,
+              split_size=proj.paramSplitSize, split_distance=proj.paramSplitDistance, split_scale=proj.paramSplitScale,
+              clone_distance=proj.paramCloneDistance)
+    n2 = orc.densify(want["loc"], want["sh"], want["scale"], want["opac"], want["rot"], P, cap, M, g["var"], g["loc"], hp, 1)
+    assert st.count_before == P and st.count_after == n2 == got["count"]
+    assert n2 != P
+    for k, n in [("loc", 3), ("sh", 3 * M), ("scale", 3), ("opac", 1), ("rot", 4)]:
+        assert np.array_equal(got[k].view(np.uint32), want[k][:n * n2].view(np.uint32)), k
+    # the trainer keeps stepping on the re-indexed model
+    tr.train(proj, stats=True)
+    tr.close()
+
+
+def test_preview_render_matches_oracle(orc):
+    P, M, W, H = 1500, 4, 200, 120
+    s = gs.synth.random_splats(P, M, 9)
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    tr = gs.Trainer(64, 64)
+    tr.model = gs.ModelSplatsDevice(host)
+    camera = gs.camera.get_cameras(3)[2]
+    fb = tr.render(W, H, 1.3, camera)
+    import math
+    blk = gs.camera.view_block(camera, W, H, white=False)
+    blk[35] = np.float32(math.tan(math.radians(W * camera.fovDegY / H) * 0.5))
+    vp = view_parts(blk)
+    r = orc.Rasterizer(np.float32)
+    out, _ = r.forward(1, M, vp["bg"], W, H, s["loc"], s["sh"], s["opac"], s["scale"], 1.3, s["rot"], vp["view"], vp["proj"],
+                       vp["campos"], vp["tanx"], vp["tany"])
+    want = orc.image_float_to_int(out, W, H).reshape(H, W)
+    diff = np.abs(((fb >> np.arange(0, 32, 8)[:, None, None]) & 0xFF).astype(int) - ((want >> np.arange(0, 32, 8)[:, None, None]) & 0xFF).astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3  # quantisation of values 1e-7 apart
+    tr.close()
+
+
+def test_model_round_trip_and_clone():
+    P, M = 777, 9
+    s = gs.synth.random_splats(P, M, 42)
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    assert (host.capacity, host.shCoeffs, host.shDegree, host.count) == (1000000, 9, 2, P)
+    dev = gs.ModelSplatsDevice(host)
+    assert (dev.capacity, dev.shDegree, dev.shCoeffs, dev.count) == (1000000, 2, 9, P)
+    clone = gs.ModelSplatsDevice(dev)
+    back = gs.ModelSplatsHost.fromDevice(clone)
+    assert back.count == P
+    for a, b, n in [(back.locations, s["loc"], 3 * P), (back.shs, s["sh"], 3 * M * P), (back.scales, s["scale"], 3 * P),
+                    (back.opacities, s["opac"], P), (back.rotations, s["rot"], 4 * P)]:
+        assert np.array_equal(a[:n], b)
+
+
+def test_reference_error_behaviour():
+    tr = gs.Trainer(32, 32)
+    with pytest.raises(RuntimeError, match="no truth data"):
+        tr.train(gs.Project())
+    L = capi.lib()
+    h = capi.hyper_defaults()
+    assert L.gs_trainer_step(tr.handle, C.byref(h), 0, None) == -3  # GS_ERR_NO_TRUTH
+    assert b"no truth data" in L.gs_last_error()
+    assert tr.model.count == 0  # placeholder model, src/Trainer.cu:112
+    tr.close()
