@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — train steps/s of the Gaussian-splat training step on MI355X (BASELINE.json metric).
+
+One "step" = Trainer::train (src/Trainer.cu:252-543): every pass of the iteration (forward raster,
+loss, backward, gradient averaging), the gradient all-reduce when views are sharded, and the Adam
+update.  Inputs are synthetic (PCG32 random-init splats, Fibonacci-sphere cameras,
+truth = quantised render of a second splat set) and resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, parameters replicated, the 16 passes sharded round-robin over the
+ranks (strong scaling), one RCCL sum all-reduce of the averaged-gradient buffer per step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
+
+WORKLOAD_TEXT = {
+    1: "cfg1: 1k random-init splats, 1 camera x (white,black) @256x256, SH degree 1 (M=4)",
+    2: "cfg2: 10k random-init splats, 8 views (4 cameras x white/black) @512x512, SH degree 0 (M=1)",
+    3: "cfg3: 100k random-init splats, 16 views (8 cameras x white/black) @1024x1024, SH degree 3 (M=16)",
+    4: "cfg4: 100k random-init splats, 32 views (16 cameras x white/black) @1024x1024, SH degree 3 (M=16)",
+    5: "cfg5: 1M random-init splats, 64 views (32 cameras x white/black) @2048x2048, SH degree 3 (M=16)",
+}
+
+
+def stage_bytes(stage, P, M, N, R, V):
+    """ALGORITHMIC bytes of one launch of `stage` over V views (SURVEY.md §8d per-unit figures; R = mean
+    num_rendered per view, N = pixels per view).  See DESIGN.md §Roofline for the derivation."""
+    per_view = {
+        "preprocess": (44 + 12 * M) * P + 75 * P,       # fwd param read + geometry-state write
+        "scan": 8 * P,
+        "scatter": 20 * P + 12 * R,                      # duplicate-stage read + key/value write
+        "tile_sort": 24 * R + 8 * R,                     # one read+write of the 12-byte pair + range detection
+        "render_forward": 40 * R + 20 * N,               # list read + (rgb, final_T, n_contrib) write
+        "render_backward": 40 * R + 24 * N + 44 * P,     # list read + truth/colour/T/n_contrib read + intermediates
+        "splat_backward": ((44 + 12 * M) + 44 + 31) * P,  # per-splat bwd reads
+    }
+    if stage in per_view:
+        b = per_view[stage] * V
+        if stage == "splat_backward":
+            b += 2 * (48 + 12 * M) * P * V               # avg-grad + var accumulation (SURVEY counts an RMW per view)
+        return b
+    if stage == "update":
+        return 7 * (44 + 12 * M) * P                     # Adam
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (default 3 = the metric's config)")
+    ap.add_argument("--update", choices=["adam", "sgd"], default="adam")
+    ap.add_argument("--collective", choices=["torch", "rccl"], default="torch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=2, help="views of the workload the CPU baseline leg times")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+
+    torch = dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank))
+
+    import gsplat_amd as gs
+    from gsplat_amd import capi
+    L = capi.lib()
+    if L.gs_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libgsplat_mi355 has no CPU fallback")
+    P, M, V_total, W, H = gs.synth.CONFIGS[args.config]
+    D = gs.synth.sh_degree_for(M)
+    n_cams = max(V_total // 2, 1)
+    V_total = 2 * n_cams
+    seed = gs.synth.seed_for(args.config)
+    s = gs.synth.random_splats(P, M, seed)
+    cams = gs.camera.get_cameras(n_cams)
+
+    # ---- truth images: the product's own preview render of a second splat set, quantised RGBA8 ----
+    t0 = time.time()
+    tsp = gs.synth.random_splats(max(P // 2, 1), M, seed + 1000)
+    thost = gs.ModelSplatsHost.fromVectors(tsp["loc"], tsp["sh"], tsp["scale"], tsp["opac"], tsp["rot"])
+    thost.shDegree = D
+    tr = gs.Trainer(W, H)
+    tr.model = gs.ModelSplatsDevice(thost)
+    mine = gs.dist.shard_views(V_total, rank, world)
+    framesW, framesB = [None] * n_cams, [None] * n_cams
+    for v in mine:
+        cam = cams[v % n_cams]
+        white = v < n_cams
+        fb = tr.render(W, H, 1.0, cam, background=(1.0, 1.0, 1.0) if white else (0.0, 0.0, 0.0)).reshape(-1)
+        (framesW if white else framesB)[v % n_cams] = fb
+    blank = np.zeros(W * H, np.uint32)
+    framesW = [f if f is not None else blank for f in framesW]   # passes owned by other ranks are never read here
+    framesB = [f if f is not None else blank for f in framesB]
+
+    # ---- the model under training ----
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = D
+    tr.model = gs.ModelSplatsDevice(host)
+    tr.captureTruths(cams, framesW, framesB)
+    tr.shard(rank, world)
+    proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM if args.update == "adam" else capi.GS_UPDATE_SGD_CLAMP)
+    hook = None
+    if world > 1:
+        from gsplat_amd import dist as gsdist
+        hook = gsdist.TorchAllReduce(tr) if args.collective == "torch" else gsdist.NativeRcclComm(tr, rank, world)
+    setup_s = time.time() - t0
+
+    def sync_all():
+        tr.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up (untimed), then EXACTLY K timed steps ----
+    st = None
+    for _ in range(args.warmup):
+        st = tr.train(proj, densify=False, stats=True)
+    capi.check(L.gs_trainer_set_profiling(tr.handle, 1))
+    sync_all()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train(proj, densify=False)
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    ms = (C.c_double * capi.GS_STAGE_COUNT)()
+    launches = (C.c_longlong * capi.GS_STAGE_COUNT)()
+    capi.check(L.gs_trainer_stage_times(tr.handle, ms, launches))
+    capi.check(L.gs_trainer_set_profiling(tr.handle, 0))
+    st = tr.train(proj, densify=False, stats=True) if st is None else st
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+
+    if rank == 0:
+        V_local = len(mine)
+        R_mean = st.num_rendered / max(st.views, 1)
+        N = W * H
+        stages = {}
+        for i in range(capi.GS_STAGE_COUNT):
+            name = L.gs_stage_name(i).decode()
+            if launches[i]:
+                stages[name] = {"ms_per_launch": ms[i] / launches[i], "launches": int(launches[i])}
+        # dominant kernel = the stage with the largest device time
+        kern = {k: v for k, v in stages.items() if k not in ("collective",)}
+        dom = max(kern, key=lambda k: kern[k]["ms_per_launch"] * kern[k]["launches"])
+        dom_ms = kern[dom]["ms_per_launch"]
+        dom_bytes = stage_bytes(dom, P, M, N, R_mean, V_local)
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        step_bytes = sum(stage_bytes(k, P, M, N, R_mean, V_local) for k in kern) + (48 + 12 * M) * P
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "train steps/sec (fwd+bwd+Adam), 100k splats x 16 views @1024^2, 1->8 GPU" if args.config == 3 else
+                      f"train steps/sec (fwd+bwd+update), BASELINE config {args.config}",
+            "value": args.steps / elapsed,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": WORKLOAD_TEXT[args.config], "splats": P, "sh_coeffs": M, "views_per_step": V_total,
+                       "views_per_gpu": V_local, "width": W, "height": H, "update": args.update,
+                       "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                       "collective": (args.collective + " all-reduce of %d fp32" % ((12 + 3 * M) * P)) if world > 1 else "none",
+                       "mean_num_rendered_per_view": R_mean, "max_tile_list": st.max_tile_list},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
+                         "step_algorithmic_GB": step_bytes / 1e9,
+                         "step_achieved_GBs": step_bytes / (ms_per_step * 1e-3) / 1e9,
+                         "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
+            "setup_seconds": round(setup_s, 2),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(gs, s, cams, framesW, framesB, P, M, D, W, H, n_cams, args.cpu_views)
+        print(json.dumps(out), flush=True)
+    tr.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(gs, s, cams, framesW, framesB, P, M, D, W, H, n_cams, n_views):
+    """The oracle (CPU restatement of the reference step; the reference has no CPU path of its own, SURVEY
+    D2) timed on this box's host cores on a bounded sample: `n_views` of the workload's passes, scaled
+    to the full pass count, plus the update timed in full."""
+    from oracle import pyoracle as orc
+    views = gs.camera.train_views(cams, W, H)
+    V_total = 2 * n_cams
+    pick = [0, n_cams][:n_views] if n_views <= 2 else list(range(min(n_views, V_total)))
+    truths = np.concatenate([(framesW[v] if v < n_cams else framesB[v - n_cams]) for v in pick])
+    t0 = time.perf_counter()
+    o = orc.train_views(P, D, M, W, H, s["loc"], s["sh"], s["scale"], s["opac"], s["rot"], views[pick], truths, float(V_total))
+    t_views = time.perf_counter() - t0
+    p = {k: s[k].copy() for k in ("loc", "sh", "scale", "opac", "rot")}
+    m = np.zeros((11 + 3 * M) * P, np.float32)
+    v = np.zeros_like(m)
+    t0 = time.perf_counter()
+    orc.apply_adam(p["loc"], p["sh"], p["scale"], p["opac"], p["rot"], o, m, v, 1, (5e-5, 1e-4, 2e-5, 1e-4, 2.5e-5), 0.3, 0.9, 0.999, 1e-15, M)
+    t_upd = time.perf_counter() - t0
+    step_s = t_views / len(pick) * V_total + t_upd
+    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{len(pick)} of {V_total} passes of the same workload timed ({t_views:.2f} s) and scaled x{V_total / len(pick):g}, "
+                      f"Adam update timed in full ({t_upd:.3f} s); CPU restatement of the reference semantics (oracle/), OpenMP"}
+
+
+if __name__ == "__main__":
+    main()

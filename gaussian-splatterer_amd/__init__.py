@@ -6,6 +6,6 @@ csrc/); this package is the Python host-side mirror of the reference interface p
 and camera helpers.  There is no CPU fallback: any device entry point raises when the HIP library
 is missing or no GPU is visible.
 """
-from . import camera, capi, synth  # noqa: F401
+from . import camera, capi, dist, synth  # noqa: F401
 from .model import ModelSplatsDevice, ModelSplatsHost  # noqa: F401
 from .trainer import Project, Trainer  # noqa: F401

@@ -11,6 +11,7 @@ GS_OK = 0
 GS_UPDATE_SGD_CLAMP, GS_UPDATE_ADAM = 0, 1
 GS_QUAT_WXYZ, GS_QUAT_XYZW = 0, 1
 GS_COMM_ID_BYTES = 128
+GS_STAGE_COUNT = 9
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
@@ -49,12 +50,13 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void
 
 # every symbol include/gsplat.h declares (tests/test_capi_symbols.py checks the library exports them all)
 SYMBOLS = [
-    "gs_last_error", "gs_status_string", "gs_version", "gs_device_count", "gs_device_malloc", "gs_device_free",
+    "gs_last_error", "gs_status_string", "gs_version", "gs_device_count", "gs_set_option", "gs_device_malloc", "gs_device_free",
     "gs_memcpy_h2d", "gs_memcpy_d2h", "gs_memset_d", "gs_device_synchronize", "gs_model_create", "gs_model_clone",
     "gs_model_download", "gs_model_info", "gs_model_destroy", "gs_hyper_defaults", "gs_trainer_create",
     "gs_trainer_destroy", "gs_trainer_set_model", "gs_trainer_get_model", "gs_trainer_set_views", "gs_trainer_step",
     "gs_trainer_accumulate", "gs_trainer_grad_buffer", "gs_trainer_apply", "gs_trainer_set_allreduce",
     "gs_trainer_get_stream", "gs_trainer_synchronize", "gs_trainer_render", "gs_trainer_read_image",
+    "gs_trainer_set_profiling", "gs_trainer_stage_times", "gs_stage_name",
     "gs_comm_unique_id", "gs_comm_create", "gs_comm_destroy", "gs_trainer_attach_comm", "gs_rasterize_forward",
     "gs_rasterize_backward", "gs_raster_chunk_field", "gs_image_float_to_int", "gs_image_int_to_loss",
 ]
@@ -75,6 +77,7 @@ def lib():
     L.gs_status_string.restype = C.c_char_p
     L.gs_status_string.argtypes = [C.c_int]
     vp, i, f = C.c_void_p, C.c_int, C.c_float
+    L.gs_set_option.argtypes = [C.c_char_p, i]
     L.gs_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.gs_device_free.argtypes = [vp]
     L.gs_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
@@ -101,6 +104,10 @@ def lib():
     L.gs_trainer_synchronize.argtypes = [vp]
     L.gs_trainer_render.argtypes = [vp, vp, i, i, i, f, C.POINTER(gs_view)]
     L.gs_trainer_read_image.argtypes = [vp, i, vp]
+    L.gs_trainer_set_profiling.argtypes = [vp, i]
+    L.gs_trainer_stage_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    L.gs_stage_name.argtypes = [i]
+    L.gs_stage_name.restype = C.c_char_p
     L.gs_comm_unique_id.argtypes = [vp]
     L.gs_comm_create.argtypes = [vp, i, i, C.POINTER(vp)]
     L.gs_comm_destroy.argtypes = [vp]

@@ -21,6 +21,9 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static int g_opt_cull = 1;
+int option_cull() { return g_opt_cull; }
+
 // grow-only device buffer
 struct DevBuf {
     void* p = nullptr;
@@ -52,7 +55,7 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
     Dims d;
     d.P = P; d.Pa = Pa; d.D = D; d.M = M; d.W = W; d.H = H; d.N = W * H;
     d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
-    d.V = V; d.Rcap = Rcap; d.mod = mod;
+    d.V = V; d.Rcap = Rcap; d.mod = mod; d.cull = g_opt_cull;
     return d;
 }
 
@@ -185,6 +188,13 @@ extern "C" int gs_memcpy_d2h(void* h, const void* d, size_t n) { if (n) GS_HIP(h
 extern "C" int gs_memset_d(void* d, int v, size_t n) { if (n) GS_HIP(hipMemset(d, v, n)); return GS_OK; }
 extern "C" int gs_device_synchronize(void) { GS_HIP(hipDeviceSynchronize()); return GS_OK; }
 
+extern "C" int gs_set_option(const char* name, int value) {
+    if (!name) return GS_ERR_INVALID_ARGUMENT;
+    if (strcmp(name, "cull") == 0) { g_opt_cull = value != 0; return GS_OK; }
+    set_error("gs_set_option: unknown option '%s'", name);
+    return GS_ERR_INVALID_ARGUMENT;
+}
+
 extern "C" int gs_hyper_defaults(gs_hyper* h) {
     if (!h) return GS_ERR_INVALID_ARGUMENT;
     h->lr_location = 0.00005f; h->lr_sh = 0.0001f; h->lr_scale = 0.00002f; h->lr_opacity = 0.0001f; h->lr_rotation = 0.000025f;
@@ -313,7 +323,46 @@ struct gs_trainer {
     void* allreduce_user = nullptr;
     gs_step_stats last{};
     bool accumulated = false;
+    // optional per-stage HIP-event timing (bench / roofline evidence)
+    bool profiling = false;
+    struct Pending { int stage; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    double stage_ms[GS_STAGE_COUNT] = { 0 };
+    long long stage_launches[GS_STAGE_COUNT] = { 0 };
 };
+
+namespace {
+const char* const kStageNames[GS_STAGE_COUNT] = { "preprocess", "scan", "scatter", "tile_sort", "render_forward",
+                                                  "render_backward", "splat_backward", "update", "collective" };
+hipEvent_t prof_event(gs_trainer* t) {
+    hipEvent_t e = nullptr;
+    if (!t->event_pool.empty()) { e = t->event_pool.back(); t->event_pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+    return e;
+}
+struct StageTimer {  // records an event pair around one stage on the trainer's stream when profiling is on
+    gs_trainer* t; int stage; hipEvent_t a = nullptr;
+    StageTimer(gs_trainer* t_, int stage_) : t(t_), stage(stage_) {
+        if (t->profiling && (a = prof_event(t))) (void)hipEventRecord(a, t->stream);
+    }
+    ~StageTimer() {
+        if (!a) return;
+        hipEvent_t b = prof_event(t);
+        if (!b) { t->event_pool.push_back(a); return; }
+        (void)hipEventRecord(b, t->stream);
+        t->pending.push_back({ stage, a, b });
+    }
+};
+void prof_resolve(gs_trainer* t) {  // caller has synchronised the stream
+    for (auto& p : t->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { t->stage_ms[p.stage] += ms; t->stage_launches[p.stage]++; }
+        t->event_pool.push_back(p.a); t->event_pool.push_back(p.b);
+    }
+    t->pending.clear();
+}
+}  // namespace
 
 extern "C" int gs_trainer_create(int width, int height, gs_trainer** out) {
     if (!out || width <= 0 || height <= 0 || width > 65535 * TILE || height > 65535 * TILE) {
@@ -340,6 +389,8 @@ extern "C" int gs_trainer_destroy(gs_trainer* t) {
     t->truth.release(); t->grad.release(); t->adam_m.release(); t->adam_v.release();
     t->train.release(); t->preview.release();
     if (t->h_flags) (void)hipHostFree(t->h_flags);
+    prof_resolve(t);
+    for (hipEvent_t e : t->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(t->stream);
     delete t;
     return GS_OK;
@@ -414,15 +465,22 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
         GS_HIP(hipMemcpyAsync((void*)s.views, t->h_views.data(), (size_t)V * sizeof(gs_view), hipMemcpyHostToDevice, t->stream));
         GS_HIP(hipMemsetAsync(t->train.zero_block.p, 0, t->train.zero_bytes, t->stream));
         if (P > 0) {
-            GS_TRY(stage_project(d, m->planes, s, t->train.scan_tmp.as<uint32_t>(), t->stream));
-            GS_TRY(stage_bin_render(d, s, t->stream));
-            GS_TRY(launch_render_backward(d, s, t->stream));
-            GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), t->stream));
+            uint32_t* tmp = t->train.scan_tmp.as<uint32_t>();
+            { StageTimer tm(t, 0); GS_TRY(launch_preprocess(d, m->planes, s, t->stream)); }
+            { StageTimer tm(t, 1);
+              GS_TRY(launch_scan_u32(s.tiles_touched, s.point_offsets, d.P, d.Pa, d.V, tmp, t->stream));
+              GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.V, tmp + scan_partials_count(d.Pa, d.V), t->stream)); }
+            { StageTimer tm(t, 2); GS_TRY(launch_scatter(d, s, t->stream)); }
+            { StageTimer tm(t, 3); GS_TRY(launch_tile_sort(d, s, t->stream)); }
+            { StageTimer tm(t, 4); GS_TRY(launch_render_forward(d, s, t->stream)); }
+            { StageTimer tm(t, 5); GS_TRY(launch_render_backward(d, s, t->stream)); }
+            { StageTimer tm(t, 6); GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), t->stream)); }
         } else {
             GS_TRY(launch_render_forward(d, s, t->stream));
         }
         GS_HIP(hipMemcpyAsync(t->h_flags, s.flags, (size_t)V * 20, hipMemcpyDeviceToHost, t->stream));
         GS_HIP(hipStreamSynchronize(t->stream));
+        prof_resolve(t);
         bool overflow = false;
         uint32_t need = 0;
         st.num_rendered = 0; st.max_tile_list = 0;
@@ -502,8 +560,9 @@ extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, g
         set_error("unknown update rule %d", h->update_rule);
         return GS_ERR_INVALID_ARGUMENT;
     }
-    GS_TRY(launch_update(pl, m->count, m->Pa, m->planes, t->grad.as<float>(), t->adam_m.as<float>(), t->adam_v.as<float>(),
-                         t->adam_t, *h, t->stream));
+    { StageTimer tm(t, 7);
+      GS_TRY(launch_update(pl, m->count, m->Pa, m->planes, t->grad.as<float>(), t->adam_m.as<float>(), t->adam_v.as<float>(),
+                           t->adam_t, *h, t->stream)); }
     t->accumulated = false;
     if (densify) GS_TRY(trainer_densify(t, h, &st));
     if (stats) { GS_HIP(hipStreamSynchronize(t->stream)); *stats = st; }
@@ -517,7 +576,8 @@ extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs
     if (t->allreduce) {
         float* buf = nullptr; size_t n = 0;
         GS_TRY(gs_trainer_grad_buffer(t, &buf, &n));
-        const int rc = t->allreduce(buf, n, (void*)t->stream, t->allreduce_user);
+        int rc;
+        { StageTimer tm(t, 8); rc = t->allreduce(buf, n, (void*)t->stream, t->allreduce_user); }
         if (rc != 0) { set_error("all-reduce hook failed with %d", rc); return GS_ERR_INTERNAL; }
     }
     return gs_trainer_apply(t, h, densify, stats);
@@ -538,6 +598,23 @@ extern "C" int gs_trainer_synchronize(gs_trainer* t) {
     GS_HIP(hipStreamSynchronize(t->stream));
     return GS_OK;
 }
+
+extern "C" int gs_trainer_set_profiling(gs_trainer* t, int enable) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    GS_HIP(hipStreamSynchronize(t->stream));
+    prof_resolve(t);
+    t->profiling = enable != 0;
+    for (int i = 0; i < GS_STAGE_COUNT; i++) { t->stage_ms[i] = 0; t->stage_launches[i] = 0; }
+    return GS_OK;
+}
+extern "C" int gs_trainer_stage_times(gs_trainer* t, double* ms_sum, long long* launches) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    GS_HIP(hipStreamSynchronize(t->stream));
+    prof_resolve(t);
+    for (int i = 0; i < GS_STAGE_COUNT; i++) { if (ms_sum) ms_sum[i] = t->stage_ms[i]; if (launches) launches[i] = t->stage_launches[i]; }
+    return GS_OK;
+}
+extern "C" const char* gs_stage_name(int i) { return (i >= 0 && i < GS_STAGE_COUNT) ? kStageNames[i] : ""; }
 
 extern "C" int gs_trainer_read_image(gs_trainer* t, int view, float* host_chw) {
     if (!t || !host_chw || view < 0 || view >= t->V || !t->train.s.out_color) return GS_ERR_INVALID_ARGUMENT;

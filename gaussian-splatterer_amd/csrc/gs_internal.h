@@ -13,6 +13,7 @@ namespace gs {
 // error plumbing
 // ---------------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
+int option_cull();
 #define GS_HIP(expr)                                                                           \
     do {                                                                                       \
         hipError_t e__ = (expr);                                                               \
@@ -72,6 +73,7 @@ struct Dims {
     int V;        // views in this launch
     uint32_t Rcap;  // entries per view the binning arena holds
     float mod;    // scale modifier
+    int cull;     // 1: sub-tile alpha>=1/255 box culling on (default); 0: evaluate every staged pair
 };
 
 // Device pointers of the per-view scratch; every array is [V][...] with the strides in Dims.

@@ -150,7 +150,9 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
     // conics disable culling.
     const float opacity = params[pl.opac() * st + i];
     float hx, hy;
-    if (!(opacity >= 0.0039f)) {  // 1/255 = 0.003921...: alpha <= opacity can never reach it
+    if (!d.cull) {
+        hx = 3.0e38f; hy = 3.0e38f;
+    } else if (!(opacity >= 0.0039f)) {  // 1/255 = 0.003921...: alpha <= opacity can never reach it
         hx = -1.0f; hy = -1.0f;
     } else {
         const float tau = fmaxf(0.0f, __logf(255.0f * opacity)) * 1.01f + 0.01f;

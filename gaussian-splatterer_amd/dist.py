@@ -1,0 +1,90 @@
+"""Data-parallel plumbing over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo"
+on CPU for tests).  One process per GPU; splat parameters are replicated, the passes of an
+iteration are sharded round-robin (pass v -> rank v % world), and ONE sum all-reduce of the
+averaged-gradient buffer [(12+3M) planes x plane stride fp32] runs between accumulate and apply
+(SURVEY §8e).  S (the divisor of accumulateGradients, src/Trainer.cu:419) stays the GLOBAL pass
+count, so local sums are already correctly scaled and the reduction is a plain sum.
+
+The reference has no multi-GPU path; this module is the build-side addition north_star asks for.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_views(total_views, rank, world):
+    """Passes owned by `rank`: v % world == rank (white/black twins of a camera may land on different ranks)."""
+    return [v for v in range(total_views) if v % world == rank]
+
+
+def allreduce_sum_numpy(arr):
+    """In-place sum all-reduce of a numpy array through the default process group (gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(arr)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return arr
+
+
+class _DevPtr:
+    """Minimal __cuda_array_interface__ carrier so torch can alias a raw device pointer (no copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class TorchAllReduce:
+    """gs_allreduce_fn implemented with torch.distributed.all_reduce on a tensor that aliases the
+    trainer's gradient buffer, enqueued behind the trainer's HIP stream."""
+
+    def __init__(self, trainer):
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        self.torch, self.dist = torch, dist
+        st = C.c_void_p()
+        capi.check(capi.lib().gs_trainer_get_stream(trainer.handle, C.byref(st)))
+        self.stream = torch.cuda.ExternalStream(st.value)
+        self._alias = {}
+
+        def hook(buf, n, hip_stream, user):
+            try:
+                key = (buf, n)
+                t = self._alias.get(key)
+                if t is None:
+                    t = torch.as_tensor(_DevPtr(buf, n), device=torch.device("cuda", torch.cuda.current_device()))
+                    self._alias = {key: t}
+                with torch.cuda.stream(self.stream):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("all-reduce hook failed:", repr(e), flush=True)
+                return 1
+
+        self._cb = capi.ALLREDUCE_FN(hook)
+        capi.check(capi.lib().gs_trainer_set_allreduce(trainer.handle, C.cast(self._cb, C.c_void_p), None))
+
+
+class NativeRcclComm:
+    """The library's own RCCL communicator (gs_comm_*): the 128-byte unique id is created on rank 0
+    and broadcast through torch.distributed's store; the collective itself never touches Python."""
+
+    def __init__(self, trainer, rank, world):
+        import torch.distributed as dist
+        from . import capi
+        L = capi.lib()
+        ident = (C.c_char * capi.GS_COMM_ID_BYTES)()
+        if rank == 0:
+            capi.check(L.gs_comm_unique_id(ident))
+        if world > 1:
+            box = [bytes(ident.raw) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            C.memmove(ident, box[0], capi.GS_COMM_ID_BYTES)
+        self.handle = C.c_void_p()
+        capi.check(L.gs_comm_create(ident, rank, world, C.byref(self.handle)))
+        capi.check(L.gs_trainer_attach_comm(trainer.handle, self.handle))

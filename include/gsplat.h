@@ -56,6 +56,10 @@ const char* gs_status_string(int status);
 int gs_version(int* major, int* minor, int* patch);
 /* Number of visible HIP devices (0 when none); never fails. */
 int gs_device_count(void);
+/* Process-wide diagnostic switches.  "cull" (default 1): the render kernels skip (splat, 8x8 pixel
+ * block) pairs whose alpha >= 1/255 box misses the block; 0 evaluates every staged pair.  Results
+ * are bit-identical either way (tests/test_gpu_raster.py checks exactly that). */
+int gs_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
  * Raw device-memory helpers (current HIP device).  They exist so that C / ctypes callers and the
@@ -185,6 +189,14 @@ int gs_trainer_synchronize(gs_trainer* trainer);
  * tan(radians(sizeX*fovY/sizeY)/2) (:196).  Synchronous like the reference (:215). */
 int gs_trainer_render(gs_trainer* trainer, uint32_t* framebuffer, int fb_on_device, int size_x, int size_y,
                       float splat_scale, const gs_view* view);
+/* Per-stage device timing with HIP events recorded on the trainer's stream (evidence for the
+ * roofline report; off by default).  Stage i is named gs_stage_name(i): preprocess, scan, scatter,
+ * tile_sort, render_forward, render_backward, splat_backward, update, collective.
+ * gs_trainer_stage_times returns the sums (ms) and launch counts since profiling was switched on. */
+#define GS_STAGE_COUNT 9
+int gs_trainer_set_profiling(gs_trainer* trainer, int enable);
+int gs_trainer_stage_times(gs_trainer* trainer, double ms_sum[GS_STAGE_COUNT], long long launches[GS_STAGE_COUNT]);
+const char* gs_stage_name(int stage);
 /* Diagnostics for tests: copy pass `view_index`'s last rendered float image [3][H][W] to host. */
 int gs_trainer_read_image(gs_trainer* trainer, int view_index, float* host_chw);
 

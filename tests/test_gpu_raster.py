@@ -173,7 +173,11 @@ def test_long_tile_lists_take_the_spill_path(orc):
 
 
 def test_elongated_splats_cull_box_is_conservative(orc):
-    """Needle-shaped and huge splats stress the alpha>=1/255 cull box: results must not change."""
+    """Needle-shaped, huge and nearly transparent splats stress the alpha >= 1/255 cull box.
+    (1) culling on vs off must be BIT-identical (a skipped pair is one the blend skips anyway);
+    (2) these covariances are ill-conditioned, so the comparison with the fp32 oracle is made against
+        the fp64 oracle: the GPU may be at most 10x further from fp64 than the fp32 restatement is."""
+    from gsplat_amd import capi
     P, M, D, W, H = 400, 4, 1, 160, 96
     s, cams, views = make_scene(P, M, 31, W, H)
     rng = np.random.default_rng(4)
@@ -182,11 +186,31 @@ def test_elongated_splats_cull_box_is_conservative(orc):
     sc[:, 2] *= rng.choice([1.0, 0.02], P).astype(np.float32)
     s["opac"] = rng.choice([0.002, 0.004, 0.01, 0.5, 1.0], P).astype(np.float32)
     vp = view_parts(views[0])
-    sr, r, out, oout = _check_forward(orc, s, D, M, vp, W, H)
     dpix = rng.uniform(-1, 1, (3, H, W)).astype(np.float32)
-    g, og = sr.backward(dpix), r.backward(dpix)
+    sr, r, out, oout = _check_forward(orc, s, D, M, vp, W, H, min_solid=0.95)
+    g = sr.backward(dpix)
+    try:
+        capi.check(capi.lib().gs_set_option(b"cull", 0))
+        sr2 = SeamRaster()
+        out2, R2 = sr2.forward(s, D, M, vp, W, H)
+        g2 = sr2.backward(dpix)
+    finally:
+        capi.check(capi.lib().gs_set_option(b"cull", 1))
+    assert np.array_equal(out.view(np.uint32), out2.view(np.uint32))
+    assert np.array_equal(sr.field("image", "n_contrib", np.uint32), sr2.field("image", "n_contrib", np.uint32))
+    for k in g:
+        assert np.array_equal(g[k].view(np.uint32), g2[k].view(np.uint32)), k
+    og = r.backward(dpix)
+    r64 = orc.Rasterizer(np.float64)
+    r64.forward(D, M, vp["bg"], W, H, s["loc"], s["sh"], s["opac"], s["scale"], 1.0, s["rot"], vp["view"], vp["proj"], vp["campos"],
+                vp["tanx"], vp["tany"])
+    g64 = r64.backward(dpix)
     for name in ["dL_dmean3D", "dL_dscale", "dL_drot", "dL_dopacity", "dL_dsh"]:
-        assert_close_rel(name, g[name], og[name], rtol=1e-4, max_bad_frac=0.01)
+        e_gpu = np.abs(g[name].astype(np.float64) - g64[name])
+        e_f32 = np.abs(og[name].astype(np.float64) - g64[name])
+        scale = np.abs(g64[name]).max()
+        bad = e_gpu > 10.0 * e_f32 + 1e-4 * np.maximum(np.abs(g64[name]), 1e-3 * scale)
+        assert bad.mean() <= 0.01, (name, int(bad.sum()), bad.size)
 
 
 def test_scale_modifier_and_image_kernels(orc):
