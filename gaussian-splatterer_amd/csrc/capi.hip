@@ -533,8 +533,10 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
     const int n2 = densify_host(loc.data(), sh.data(), scale.data(), opac.data(), rot.data(), count, cap, M, var.data(), gl.data(), *h);
     gs_model* fresh = nullptr;
     GS_TRY(gs_model_create(cap, m->sh_degree, M, n2, loc.data(), sh.data(), scale.data(), opac.data(), rot.data(), &fresh));
-    gs_model_destroy(t->model);
-    t->model = fresh;
+    // keep the gs_model object's identity (callers hold the pointer): swap the new planes in
+    std::swap(m->planes, fresh->planes);
+    m->Pa = fresh->Pa; m->count = fresh->count;
+    gs_model_destroy(fresh);
     t->adam_valid = false; t->adam_t = 0;  // optimizer state does not survive re-indexing
     st->count_after = n2;
     return GS_OK;

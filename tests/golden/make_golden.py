@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/cfg1.npz from the CPU oracle (oracle/gs_oracle.cpp) at BASELINE cfg1 scale:
+1k random-init splats (seed 0x5EED0001), one camera, white + black pass, 256x256, truth = quantised
+oracle render of the second splat set (seed + 1000, P/2 splats).
+
+The reference itself holds no fixtures and cannot be run here, so these vectors pin the
+ORACLE's behaviour over time (tests/test_golden.py, CPU) and give the GPU path a committed target
+(tests/test_gpu_golden.py); they are not reference outputs.  Run from the repo root:
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import gsplat_amd as gs  # noqa: E402
+from oracle import pyoracle as orc  # noqa: E402
+
+
+def build():
+    P, M, V, W, H = gs.synth.CONFIGS[1]
+    seed = gs.synth.seed_for(1)
+    s = gs.synth.random_splats(P, M, seed)
+    t = gs.synth.random_splats(P // 2, M, seed + 1000)
+    cams = gs.camera.get_cameras(1)
+    views = gs.camera.train_views(cams, W, H)
+    out = dict(P=P, M=M, W=W, H=H, seed=seed, views=views)
+    truths = []
+    for v in range(2):
+        b = views[v]
+        r = orc.Rasterizer(np.float32)
+        img, _ = r.forward(1, M, b[37:40], W, H, t["loc"], t["sh"], t["opac"], t["scale"], 1.0, t["rot"], b[0:16], b[16:32], b[32:35],
+                           float(b[35]), float(b[36]))
+        truths.append(orc.image_float_to_int(img, W, H))
+    out["truth_sha256"] = np.array([hashlib.sha256(x.tobytes()).hexdigest() for x in truths])
+    for v in range(2):
+        b = views[v]
+        r = orc.Rasterizer(np.float32)
+        img, R = r.forward(1, M, b[37:40], W, H, s["loc"], s["sh"], s["opac"], s["scale"], 1.0, s["rot"], b[0:16], b[16:32], b[32:35],
+                           float(b[35]), float(b[36]))
+        out[f"v{v}_num_rendered"] = R
+        out[f"v{v}_point_list_sha256"] = hashlib.sha256(r.get("point_list").tobytes()).hexdigest()
+        out[f"v{v}_ranges_sha256"] = hashlib.sha256(r.get("ranges").tobytes()).hexdigest()
+        out[f"v{v}_radii_sha256"] = hashlib.sha256(r.get("radii").tobytes()).hexdigest()
+        out[f"v{v}_point_list_head"] = r.get("point_list")[:256]
+        out[f"v{v}_image_crop"] = img[:, 96:160, 96:160].copy()
+        out[f"v{v}_image_mean"] = img.reshape(3, -1).mean(1)
+        out[f"v{v}_final_T_crop"] = r.get("final_T").reshape(H, W)[96:160, 96:160].copy()
+        out[f"v{v}_n_contrib_sum"] = int(r.get("n_contrib").astype(np.int64).sum())
+        out[f"v{v}_margin_crop"] = r.get("margin").reshape(H, W)[96:160, 96:160].copy()
+    o = orc.train_views(P, 1, M, W, H, s["loc"], s["sh"], s["scale"], s["opac"], s["rot"], views, np.concatenate(truths), 2.0)
+    for k in ("var", "loc", "sh", "scale", "opac", "rot"):
+        out["avg_" + k] = o[k]
+    return out, truths
+
+
+if __name__ == "__main__":
+    out, _ = build()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfg1.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")

@@ -1,0 +1,49 @@
+"""GPU vs the committed golden vectors (tests/golden/cfg1.npz, BASELINE cfg1): tile / sort indices
+bit-exact via SHA-256 of the arrays, pixels and averaged gradients <= 1e-4 relative."""
+import hashlib
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import gsplat_amd as gs
+from util import SeamRaster, assert_close_rel, view_parts
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_cfg1_matches_golden(orc):
+    gold = np.load(os.path.join(HERE, "golden", "cfg1.npz"))
+    P, M, W, H = int(gold["P"]), int(gold["M"]), int(gold["W"]), int(gold["H"])
+    s = gs.synth.random_splats(P, M, int(gold["seed"]))
+    views = gold["views"]
+    for v in range(2):
+        sr = SeamRaster()
+        img, R = sr.forward(s, 1, M, view_parts(views[v]), W, H)
+        assert R == int(gold[f"v{v}_num_rendered"])
+        assert hashlib.sha256(sr.field("binning", "point_list", np.uint32).tobytes()).hexdigest() == str(gold[f"v{v}_point_list_sha256"])
+        assert hashlib.sha256(sr.field("image", "ranges", np.uint32).tobytes()).hexdigest() == str(gold[f"v{v}_ranges_sha256"])
+        solid = gold[f"v{v}_margin_crop"] > 1e-3
+        for c in range(3):
+            assert_close_rel(f"image[{c}]", img[c, 96:160, 96:160][solid], gold[f"v{v}_image_crop"][c][solid], rtol=1e-4, floor=1e-3)
+        fT = sr.field("image", "final_T", np.float32).reshape(H, W)[96:160, 96:160]
+        assert_close_rel("final_T", fT[solid], gold[f"v{v}_final_T_crop"][solid], rtol=1e-4, floor=1e-4)
+        assert abs(int(sr.field("image", "n_contrib", np.uint32).astype(np.int64).sum()) - int(gold[f"v{v}_n_contrib_sum"])) <= 8
+    # full step: averaged gradients against the golden ones
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    _, truths = mk.build()
+    assert [hashlib.sha256(t.tobytes()).hexdigest() for t in truths] == [str(x) for x in gold["truth_sha256"]]
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    tr = gs.Trainer(W, H)
+    tr.model = gs.ModelSplatsDevice(host)
+    tr.captureTruths(gs.camera.get_cameras(1), truths[:1], truths[1:])
+    tr.train(gs.Project(), stats=True)
+    from test_gpu_trainer import _read_grads
+    g = _read_grads(tr, P, M)
+    for k in ("var", "loc", "sh", "scale", "opac", "rot"):
+        assert_close_rel("avg_" + k, g[k], gold["avg_" + k], rtol=1e-4, max_bad_frac=0.002)
+    tr.close()
