@@ -56,7 +56,7 @@ struct Planes {
 struct alignas(16) GeomRec {
     float x, y, conA, conB;        // means2D, conic.x, conic.y
     float conC, opacity, r, g;     // conic.z, opacity, rgb.r, rgb.g
-    float b, hx, hy, depth;        // rgb.b, cull half-extents (alpha >= 1/255 box), view depth
+    float b, hx, hy, depth;        // rgb.b, hx = cull threshold tau = ln(255*opacity)+margin (hy unused), view depth
     int radius;                    // 0 = culled
     uint32_t flags;                // bits 0..2: clamped r,g,b
     uint32_t rect_min, rect_max;   // x | y << 16
@@ -123,6 +123,7 @@ int launch_soa_to_aos(int P, int Pa, int M, const float* planes, float* loc, flo
 int launch_image_float_to_int(const float* src, uint32_t* fb, int w, int h, hipStream_t st);
 int launch_image_int_to_loss(const uint32_t* truth, const float* rast, float* loss, int w, int h, hipStream_t st);
 int launch_ranges(const Dims& d, const Scratch& s, uint32_t* ranges, hipStream_t st);
+int launch_debug_reduce9(const float* in, float* out, hipStream_t st);
 
 // host-side densify (the reference does this on the CPU too, src/Trainer.cu:433-542)
 int densify_host(float* loc, float* sh, float* scale, float* opac, float* rot, int count, int capacity, int M,

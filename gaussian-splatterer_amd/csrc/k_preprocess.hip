@@ -145,25 +145,18 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
         res[c] = fmaxf(val, 0.0f);
     }
 
-    // Cull box: pixels outside |d| <= (hx,hy) provably have alpha < 1/255 (skipped by the blend
-    // anyway).  Conservative margins cover the fp32 error of conic / log / sqrt; non positive-definite
-    // conics disable culling.
+    // Cull threshold: a pixel contributes only if alpha = min(0.99, opacity*exp(-q)) >= 1/255, i.e. only where the
+    // conic's quadratic form q <= tau = ln(255*opacity).  The render kernels skip (splat, 8x8 block) pairs whose
+    // minimum q over the block exceeds tau — pairs the blend would skip anyway.  1 % + 0.01 of margin covers the
+    // fp32 error of conic / log / the block test; tau < 0 marks splats that can never reach 1/255; a conic that is
+    // not positive definite (the block test assumes convexity) or culling switched off gives tau = 3e38.
     const float opacity = params[pl.opac() * st + i];
-    float hx, hy;
-    if (!d.cull) {
-        hx = 3.0e38f; hy = 3.0e38f;
-    } else if (!(opacity >= 0.0039f)) {  // 1/255 = 0.003921...: alpha <= opacity can never reach it
-        hx = -1.0f; hy = -1.0f;
-    } else {
-        const float tau = fmaxf(0.0f, __logf(255.0f * opacity)) * 1.01f + 0.01f;
+    float hx, hy = 0.0f;
+    {
         const float dc = conx * conz - cony * cony;
-        if (dc > 0.0f && conx > 0.0f && conz > 0.0f && dc < 3.0e38f) {
-            hx = sqrtf(2.0f * tau * conz / dc) * 1.01f + 0.5f;
-            hy = sqrtf(2.0f * tau * conx / dc) * 1.01f + 0.5f;
-            if (!(hx == hx) || !(hy == hy)) { hx = 3.0e38f; hy = 3.0e38f; }
-        } else {
-            hx = 3.0e38f; hy = 3.0e38f;
-        }
+        if (!d.cull || !(dc > 0.0f && conx > 0.0f && conz > 0.0f)) hx = 3.0e38f;
+        else if (!(opacity >= 0.0039f)) hx = -1.0f;  // 1/255 = 0.003921...: alpha <= opacity can never reach it
+        else hx = fmaxf(0.0f, __logf(255.0f * opacity)) * 1.01f + 0.01f;
     }
 
     GeomRec g;

@@ -5,15 +5,18 @@
 //
 // MI355X mapping (not the upstream one):
 //   * workgroup = one 16x16 tile = 4 wave64; each WAVE owns an 8x8 pixel block, lane = pixel.
-//   * the tile's depth-ordered list is staged through LDS 256 entries at a time (48-byte records
-//     gathered from the 64-byte per-splat lines written by preprocess).
+//   * the tile's depth-ordered list is staged through LDS (48-byte records gathered from the
+//     64-byte per-splat lines written by preprocess): 256 entries per round forward, 128 backward
+//     (24 KB of LDS per workgroup -> 6 workgroups = 24 waves per CU).
 //   * per 64 staged entries every lane tests ONE entry's "alpha >= 1/255" box against the wave's
 //     8x8 block; the ballot is a scalar bit list and only surviving entries are evaluated — the
 //     skipped pairs are exactly ones the reference blend would skip too, so results are unchanged.
-//   * backward: the nine per-pair partial derivatives are reduced across the 64 lanes with DPP row
-//     operations (no LDS, no atomics), each wave parks its sum in its own LDS slot, the four slots
-//     are added in fixed order and written as ONE 48-byte row per (splat,tile) entry.  There is no
-//     global atomic anywhere in the backward pass and the result is bitwise reproducible.
+//     The next surviving entry's record is read from LDS while the current one is evaluated.
+//   * backward: the nine per-pair partial derivatives are reduced across the 64 lanes by a DPP
+//     reduce-scatter (27 VALU instructions instead of 54: every stage halves the number of live
+//     values; bank masks give the per-lane value selection for free), each wave parks its sums in
+//     its own LDS slot, the four slots are added in fixed order and written as ONE 48-byte row per
+//     (splat,tile) entry.  No global atomic anywhere; the result is bitwise reproducible.
 #include "gs_internal.h"
 
 namespace gs {
@@ -22,29 +25,46 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_STOP = 0.0001f;
 constexpr int ACC_STRIDE = 9;
+constexpr int BWD_ROUND = 128;  // entries staged per backward round
 
-__device__ inline bool overlaps(float x, float y, float hx, float hy, float bxlo, float bxhi, float bylo, float byhi) {
-    return (x + hx >= bxlo) && (x - hx <= bxhi) && (y + hy >= bylo) && (y - hy <= byhi);
+// Exact "can this splat reach alpha >= 1/255 anywhere in the 8x8 block" test: the minimum of the conic's
+// quadratic form q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy over the block rectangle (centre inside -> 0, else
+// the best of the four edges, each a clamped 1-D parabola) compared with tau = ln(255*opacity) (+margin,
+// computed in preprocess; tau < 0: never visible, tau = 3e38: culling disabled / conic not positive definite).
+// One lane tests one staged entry, so the ~45 VALU instructions are amortised over 64 entries.
+__device__ inline bool block_reaches(float cx, float cy, float a, float b, float c, float tau, float bxlo, float bxhi, float bylo,
+                                     float byhi) {
+    const float x0 = bxlo - cx, x1 = bxhi - cx, y0 = bylo - cy, y1 = byhi - cy;
+    const bool inside = (x0 <= 0.0f) && (x1 >= 0.0f) && (y0 <= 0.0f) && (y1 >= 0.0f);
+    const float ra = __builtin_amdgcn_rcpf(a), rc = __builtin_amdgcn_rcpf(c);
+    auto q = [&](float dx, float dy) { return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy; };
+    const float e0 = q(x0, fminf(y1, fmaxf(y0, -b * x0 * rc)));
+    const float e1 = q(x1, fminf(y1, fmaxf(y0, -b * x1 * rc)));
+    const float e2 = q(fminf(x1, fmaxf(x0, -b * y0 * ra)), y0);
+    const float e3 = q(fminf(x1, fmaxf(x0, -b * y1 * ra)), y1);
+    const float qmin = inside ? 0.0f : fminf(fminf(e0, e1), fminf(e2, e3));
+    return (tau >= 0.0f) && !(qmin > tau);
 }
 
-struct StagedTile {
-    float4 A[WG];   // x, y, conA, conB
-    float4 B[WG];   // conC, opacity, r, g
-    float C[WG];    // b
-    float2 Hh[WG];  // hx, hy
+template <int N> struct StagedTile {
+    float4 A[N];   // x, y, conA, conB
+    float4 B[N];   // conC, opacity, r, g
+    float C[N];    // b
+    float Tau[N];  // cull threshold
 };
 
-__device__ inline void stage_entry(StagedTile& t, int slot, const GeomRec* __restrict__ r) {
+template <int N> __device__ inline void stage_entry(StagedTile<N>& t, int slot, const GeomRec* __restrict__ r) {
     const float4* q = reinterpret_cast<const float4*>(r);
     const float4 a = q[0], b = q[1], c = q[2];
-    t.A[slot] = a; t.B[slot] = b; t.C[slot] = c.x; t.Hh[slot] = make_float2(c.y, c.z);
+    t.A[slot] = a; t.B[slot] = b; t.C[slot] = c.x; t.Tau[slot] = c.y;
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
-    __shared__ StagedTile st;
+#pragma clang fp contract(fast)
+    __shared__ StagedTile<WG> st;
     const int tile = blockIdx.x, v = blockIdx.y;
     if (s.flags[v * 4 + 0] & 1u) return;
     const int tx = tile % d.gx, ty = tile / d.gx;
@@ -60,45 +80,47 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
     const uint32_t* __restrict__ plist = s.point_list + (size_t)v * d.Rcap + start;
     const GeomRec* __restrict__ geom = s.geom + (size_t)v * d.Pa;
 
+    // Branch-free per-lane blend: `live` is 1 until the pixel saturates (upstream's `done`), invalid pairs
+    // get alpha = 0, so the only control flow in the pair loop is the scalar walk over the ballot bits
+    // (SALU instructions cost ~4.7 SIMD-cycles each on gfx950 — exec-mask bookkeeping was the bottleneck).
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
-    bool done = !inside;
+    float live = inside ? 1.0f : 0.0f;
 
     for (int base = 0; base < n; base += WG) {
-        if (__syncthreads_and(done)) break;  // whole tile saturated; also guards LDS reuse
+        if (__syncthreads_and(live == 0.0f)) break;  // whole tile saturated; also guards LDS reuse
         const int e = base + tid;
         if (e < n) stage_entry(st, tid, geom + plist[e]);
         __syncthreads();
         const int cnt = min(WG, n - base);
         for (int sub = 0; sub < cnt; sub += 64) {
-            if (__ballot(!done) == 0ull) break;
+            if (__ballot(live != 0.0f) == 0ull) break;
             const int j = sub + lane;
             bool hit = false;
             if (j < cnt) {
                 const float4 a = st.A[j];
-                const float2 h = st.Hh[j];
-                hit = overlaps(a.x, a.y, h.x, h.y, bxlo, bxhi, bylo, byhi);
+                hit = block_reaches(a.x, a.y, a.z, a.w, st.B[j].x, st.Tau[j], bxlo, bxhi, bylo, byhi);
             }
             unsigned long long mask = __ballot(hit);
             while (mask) {
                 const int k = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const int jj = sub + k;
-                const float4 A = st.A[jj];
-                const float4 B = st.B[jj];
+                const float4 A = st.A[jj], B = st.B[jj];
                 const float cb = st.C[jj];
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                const float alpha = fminf(ALPHA_MAX, B.y * __expf(power));
-                if (!done && power <= 0.0f && alpha >= ALPHA_MIN) {
-                    const float test_T = T * (1.0f - alpha);
-                    if (test_T < T_STOP) done = true;
-                    else {
-                        C0 += B.z * alpha * T; C1 += B.w * alpha * T; C2 += cb * alpha * T;
-                        T = test_T;
-                        last = (uint32_t)(base + jj + 1);
-                    }
-                }
+                float alpha = fminf(ALPHA_MAX, B.y * __expf(power));
+                alpha = (power <= 0.0f) ? alpha : 0.0f;
+                alpha = (alpha >= ALPHA_MIN) ? alpha : 0.0f;
+                alpha *= live;
+                const float test_T = T * (1.0f - alpha);
+                const bool stop = test_T < T_STOP;  // only reachable with alpha > 0: T >= T_STOP is an invariant
+                live = stop ? 0.0f : live;
+                const float w = stop ? 0.0f : alpha * T;
+                T = stop ? T : test_T;
+                C0 += B.z * w; C1 += B.w * w; C2 += cb * w;
+                last = (w > 0.0f) ? (uint32_t)(base + jj + 1) : last;
             }
         }
     }
@@ -122,7 +144,7 @@ int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward
+// wave reductions
 // ---------------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ inline float dpp_add(float x) {
@@ -140,10 +162,83 @@ __device__ inline float wave_sum_to_lane63(float x) {
     return x;
 }
 
+// Reduce-scatter of nine per-lane values over the wave.  Returns r such that, in EVERY 16-lane row,
+// lane 2q (q = 0..7) holds the wave total of g_q and lane 1 holds the wave total of g8.
+//   stage A  lane ^ 8 (row_ror:8): lanes with bit3 = 0 keep g0..g3, lanes with bit3 = 1 keep g4..g7
+//   stage B  bank ^ 1 (row_ror:12 / row_ror:4): bit2 selects the lower / upper two of the four
+//   stage C  lane ^ 2 (quad_perm):               bit1 selects one of the two
+//   stage D  lane ^ 1, then the four rows are folded with permlane16/32 swaps (lane-wise)
+// bank_mask predicates whole 4-lane banks, so stages A and B need no select instructions.
+// EXEC must be all ones (the callers are in wave-uniform control flow).
+__device__ inline float wave_reduce_scatter9(float g0, float g1, float g2, float g3, float g4, float g5, float g6, float g7,
+                                             float g8) {
+    float t0, t1;
+    const unsigned long long mask_bit1 = 0xCCCCCCCCCCCCCCCCull;  // lanes with bit 1 set
+    const unsigned long long mask_lane1 = 0x0002000200020002ull;  // lane % 16 == 1
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        // stage B: banks 0,2 (bit2 = 0) pair with bank+1 (row_ror:12 reads lane+4); banks 1,3 with bank-1 (row_ror:4)
+        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        // stage C: bit1 ? keep g1 / send g0 : keep g0 / send g1
+        "v_cndmask_b32_e64 %9, %0, %1, %11\n\t"
+        "v_cndmask_b32_e64 %10, %1, %0, %11\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %9, %10, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        // lane 1 of every row (a duplicate of lane 0) takes the row sum of g8, then fold the rows lane-wise
+        "v_cndmask_b32_e64 %9, %9, %8, %12\n\t"
+        "v_mov_b32_e32 %10, %9\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32_e32 %9, %10\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_e32 %9, %9, %10\n\t"
+        "v_mov_b32_e32 %10, %9\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32_e32 %9, %10\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_e32 %9, %9, %10\n\t"
+        : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7), "+v"(g8), "=&v"(t0), "=&v"(t1)
+        : "s"(mask_bit1), "s"(mask_lane1));
+    return t0;
+}
+
+// debug entry: one wave, in[q][lane] -> out[lane] = wave_reduce_scatter9(...) (tests/test_gpu_raster.py)
+__global__ void k_debug_reduce9(const float* __restrict__ in, float* __restrict__ out) {
+    const int l = threadIdx.x;
+    out[l] = wave_reduce_scatter9(in[l], in[64 + l], in[128 + l], in[192 + l], in[256 + l], in[320 + l], in[384 + l],
+                                  in[448 + l], in[512 + l]);
+}
+int launch_debug_reduce9(const float* in, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_debug_reduce9, dim3(1), dim3(64), 0, st, in, out);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
-    __shared__ StagedTile st;
-    __shared__ uint32_t sSlot[WG];
-    __shared__ float sAcc[4 * WG * ACC_STRIDE];
+#pragma clang fp contract(fast)
+    __shared__ StagedTile<BWD_ROUND> st;
+    __shared__ uint32_t sSlot[BWD_ROUND];
+    __shared__ float sAcc[4 * BWD_ROUND * ACC_STRIDE];
+    __shared__ unsigned long long sTouched[4][BWD_ROUND / 64];
     __shared__ uint32_t sMaxLast;
     __shared__ float sLoss;
     const int tile = blockIdx.x, v = blockIdx.y;
@@ -187,7 +282,6 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
         }
     }
     if (tid == 0) { sMaxLast = 0; sLoss = 0.0f; }
-    for (int k = tid; k < 4 * WG * ACC_STRIDE; k += WG) sAcc[k] = 0.0f;
     __syncthreads();
     // wave-uniform and block-uniform bounds on the traversal
     uint32_t wave_max_last = last_contributor;
@@ -202,9 +296,9 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
     const int max_last = (int)sMaxLast;
     if (s.loss && !s.dL_dpix && tid == 0) atomicAdd(&s.loss[v], sLoss);
     if (n == 0) return;
-    const int rounds = (max_last + WG - 1) / WG;
+    const int rounds = (max_last + BWD_ROUND - 1) / BWD_ROUND;
     // entries no pixel reaches still own a gradient row: zero it
-    for (int p = rounds * WG + tid; p < n; p += WG) {
+    for (int p = rounds * BWD_ROUND + tid; p < n; p += WG) {
         float4* row = reinterpret_cast<float4*>(Gv + (size_t)slist[p] * G_STRIDE);
         row[0] = make_float4(0, 0, 0, 0); row[1] = make_float4(0, 0, 0, 0); row[2] = make_float4(0, 0, 0, 0);
     }
@@ -215,38 +309,42 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
     float last_alpha = 0.0f;
     const float bg_dot = bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2;
     const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
+    // where this lane parks a reduced value: lane 2q -> q, lane 1 -> 8 (row 0 only)
+    const bool writer = lane < 16 && (((lane & 1) == 0) || lane == 1);
+    const int wslot = (lane & 1) ? 8 : (lane >> 1);
 
     for (int r = rounds - 1; r >= 0; r--) {
-        const int base = r * WG;
-        const int cnt = min(WG, n - base);
-        __syncthreads();  // previous round's flush has consumed st / sAcc
+        const int base = r * BWD_ROUND;
+        const int cnt = min(BWD_ROUND, n - base);
+        __syncthreads();  // previous round's flush has consumed st / sAcc / sTouched
         if (tid < cnt) {
             stage_entry(st, tid, geom + plist[base + tid]);
             sSlot[tid] = slist[base + tid];
         }
         __syncthreads();
-        for (int sub = ((cnt - 1) >> 6) << 6; sub >= 0; sub -= 64) {
-            if ((uint32_t)(base + sub) >= wave_max_last) continue;
+        unsigned long long touched[BWD_ROUND / 64] = { 0ull, 0ull };
+#pragma unroll
+        for (int sb = BWD_ROUND / 64 - 1; sb >= 0; sb--) {
+            const int sub = sb * 64;
+            if (sub >= cnt || (uint32_t)(base + sub) >= wave_max_last) continue;
             const int j = sub + lane;
             bool hit = false;
             if (j < cnt && (uint32_t)(base + j) < wave_max_last) {
                 const float4 a = st.A[j];
-                const float2 h = st.Hh[j];
-                hit = overlaps(a.x, a.y, h.x, h.y, bxlo, bxhi, bylo, byhi);
+                hit = block_reaches(a.x, a.y, a.z, a.w, st.B[j].x, st.Tau[j], bxlo, bxhi, bylo, byhi);
             }
             unsigned long long mask = __ballot(hit);
             while (mask) {
-                const int k = 63 - __clzll((long long)mask);
-                mask &= ~(1ull << k);
-                const int jj = sub + k;
+                const int kk = 63 - __clzll((long long)mask);
+                mask &= ~(1ull << kk);
+                const int jj = sub + kk;
+                const float4 Ac = st.A[jj], Bc = st.B[jj];
+                const float cbc = st.C[jj];
                 const uint32_t pos = (uint32_t)(base + jj);  // upstream's `contributor` after its decrement
-                const float4 A = st.A[jj];
-                const float4 B = st.B[jj];
-                const float cb = st.C[jj];
-                const float dx = A.x - pxf, dy = A.y - pyf;
-                const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+                const float dx = Ac.x - pxf, dy = Ac.y - pyf;
+                const float power = -0.5f * (Ac.z * dx * dx + Bc.x * dy * dy) - Ac.w * dx * dy;
                 const float G = __expf(power);
-                const float alpha = fminf(ALPHA_MAX, B.y * G);
+                const float alpha = fminf(ALPHA_MAX, Bc.y * G);
                 const bool act = (pos < last_contributor) && power <= 0.0f && alpha >= ALPHA_MIN;
                 float g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0, g8 = 0;
                 if (act) {
@@ -254,16 +352,16 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
                     T = T * inv1ma;
                     const float dchannel_dcolor = alpha * T;
                     float dL_dalpha = 0.0f;
-                    ar0 = last_alpha * lc0 + (1.0f - last_alpha) * ar0; lc0 = B.z; dL_dalpha += (B.z - ar0) * dpx0; g0 = dchannel_dcolor * dpx0;
-                    ar1 = last_alpha * lc1 + (1.0f - last_alpha) * ar1; lc1 = B.w; dL_dalpha += (B.w - ar1) * dpx1; g1 = dchannel_dcolor * dpx1;
-                    ar2 = last_alpha * lc2 + (1.0f - last_alpha) * ar2; lc2 = cb; dL_dalpha += (cb - ar2) * dpx2; g2 = dchannel_dcolor * dpx2;
+                    ar0 = last_alpha * lc0 + (1.0f - last_alpha) * ar0; lc0 = Bc.z; dL_dalpha += (Bc.z - ar0) * dpx0; g0 = dchannel_dcolor * dpx0;
+                    ar1 = last_alpha * lc1 + (1.0f - last_alpha) * ar1; lc1 = Bc.w; dL_dalpha += (Bc.w - ar1) * dpx1; g1 = dchannel_dcolor * dpx1;
+                    ar2 = last_alpha * lc2 + (1.0f - last_alpha) * ar2; lc2 = cbc; dL_dalpha += (cbc - ar2) * dpx2; g2 = dchannel_dcolor * dpx2;
                     dL_dalpha *= T;
                     last_alpha = alpha;
                     dL_dalpha += (-T_final * inv1ma) * bg_dot;
-                    const float dL_dG = B.y * dL_dalpha;
+                    const float dL_dG = Bc.y * dL_dalpha;
                     const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * A.z - gdy * A.w;
-                    const float dG_ddely = -gdy * B.x - gdx * A.w;
+                    const float dG_ddelx = -gdx * Ac.z - gdy * Ac.w;
+                    const float dG_ddely = -gdy * Bc.x - gdx * Ac.w;
                     g3 = dL_dG * dG_ddelx * ddelx_dx;
                     g4 = dL_dG * dG_ddely * ddely_dy;
                     g5 = -0.5f * gdx * dx * dL_dG;
@@ -272,29 +370,28 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
                     g8 = G * dL_dalpha;
                 }
                 if (__ballot(act) != 0ull) {
-                    g0 = wave_sum_to_lane63(g0); g1 = wave_sum_to_lane63(g1); g2 = wave_sum_to_lane63(g2);
-                    g3 = wave_sum_to_lane63(g3); g4 = wave_sum_to_lane63(g4); g5 = wave_sum_to_lane63(g5);
-                    g6 = wave_sum_to_lane63(g6); g7 = wave_sum_to_lane63(g7); g8 = wave_sum_to_lane63(g8);
-                    if (lane == 63) {
-                        float* a = &sAcc[(wave * WG + jj) * ACC_STRIDE];
-                        a[0] = g0; a[1] = g1; a[2] = g2; a[3] = g3; a[4] = g4; a[5] = g5; a[6] = g6; a[7] = g7; a[8] = g8;
-                    }
+                    const float red = wave_reduce_scatter9(g0, g1, g2, g3, g4, g5, g6, g7, g8);
+                    if (writer) sAcc[(wave * BWD_ROUND + jj) * ACC_STRIDE + wslot] = red;
+                    touched[sb] |= 1ull << kk;
                 }
             }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int sb = 0; sb < BWD_ROUND / 64; sb++) sTouched[wave][sb] = touched[sb];
         }
         __syncthreads();
         if (tid < cnt) {
             float sum[ACC_STRIDE];
 #pragma unroll
-            for (int q = 0; q < ACC_STRIDE; q++) {
-                float acc = 0.0f;
+            for (int q = 0; q < ACC_STRIDE; q++) sum[q] = 0.0f;
 #pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    float* a = &sAcc[(w * WG + tid) * ACC_STRIDE + q];
-                    acc += *a;
-                    *a = 0.0f;
+            for (int w = 0; w < 4; w++) {
+                if ((sTouched[w][tid >> 6] >> (tid & 63)) & 1ull) {
+                    const float* a = &sAcc[(w * BWD_ROUND + tid) * ACC_STRIDE];
+#pragma unroll
+                    for (int q = 0; q < ACC_STRIDE; q++) sum[q] += a[q];
                 }
-                sum[q] = acc;
             }
             float4* row = reinterpret_cast<float4*>(Gv + (size_t)sSlot[tid] * G_STRIDE);
             row[0] = make_float4(sum[0], sum[1], sum[2], sum[3]);

@@ -60,6 +60,10 @@ int gs_device_count(void);
  * block) pairs whose alpha >= 1/255 box misses the block; 0 evaluates every staged pair.  Results
  * are bit-identical either way (tests/test_gpu_raster.py checks exactly that). */
 int gs_set_option(const char* name, int value);
+/* Diagnostic: runs the backward kernel's 9-value wave reduce-scatter on one wave64.  in_host[q*64 + lane]
+ * (q = 0..8), out_host[lane]: lane 2q of every 16-lane row holds the wave total of value q (q < 8), lane 1
+ * the total of value 8. */
+int gs_debug_wave_reduce9(const float* in_host, float* out_host);
 
 /* ------------------------------------------------------------------------------------------
  * Raw device-memory helpers (current HIP device).  They exist so that C / ctypes callers and the
