@@ -63,13 +63,13 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
 // grow-only, sized for V views at once: with 288 GB of HBM every view of a step keeps its own
 // state and each stage is ONE launch over all views.
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, zero_block, tile_end, bins, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp;
+    DevBuf views, geom, tiles, offsets, zero_block, tile_end, bins, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads;
     int V = 0, Pa = 0, T = 0, N = 0;
     uint32_t Rcap = 0;
     Scratch s{};
     size_t zero_bytes = 0;
 
-    int ensure(int P, int V_, int W, int H, uint32_t Rcap_) {
+    int ensure(int P, int V_, int W, int H, uint32_t Rcap_, bool want_splat_grads = false) {
         Pa = std::max(64, round_up(P, 64));
         V = V_; N = W * H;
         T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
@@ -92,6 +92,8 @@ struct ScratchSet {
         GS_TRY(finalT.ensure(v * N * 4));
         GS_TRY(ncontrib.ensure(v * N * 4));
         GS_TRY(scan_tmp.ensure((scan_partials_count(Pa, (int)v) + scan_partials_count(T, (int)v) + 64) * 4));
+        if (want_splat_grads) GS_TRY(sgrads.ensure(v * Pa * 64));
+        s.splat_grads = sgrads.as<float>();
         s.views = views.as<gs_view>();
         s.geom = geom.as<GeomRec>();
         s.tiles_touched = tiles.as<uint32_t>();
@@ -115,7 +117,7 @@ struct ScratchSet {
     }
     void release() {
         for (DevBuf* b : { &views, &geom, &tiles, &offsets, &zero_block, &tile_end, &bins, &ids, &plist, &slist, &G, &color,
-                           &finalT, &ncontrib, &scan_tmp })
+                           &finalT, &ncontrib, &scan_tmp, &sgrads })
             b->release();
     }
 };
@@ -473,7 +475,7 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
     for (;;) {
         Dims d;
         GS_TRY(trainer_dims(t, &d));
-        GS_TRY(t->train.ensure(P, V, t->W, t->H, t->Rcap));
+        GS_TRY(t->train.ensure(P, V, t->W, t->H, t->Rcap, true));
         d.Rcap = t->train.Rcap;
         Scratch s = t->train.s;
         s.truth = t->truth.as<uint32_t>();

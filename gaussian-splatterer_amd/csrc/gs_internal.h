@@ -90,6 +90,7 @@ struct Scratch {
     uint32_t* point_list;      // [V][Rcap]  sorted splat ids
     uint32_t* slot_list;       // [V][Rcap]  sorted slots
     float* G;                  // [V][Rcap][G_STRIDE]
+    float* splat_grads;        // [V][Pa][16]  per-(view,splat) backward records (trainer only)
     float* out_color;          // [V][3][N]
     float* final_T;            // [V][N]
     uint32_t* n_contrib;       // [V][N]

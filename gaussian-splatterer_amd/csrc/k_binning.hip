@@ -139,8 +139,9 @@ int launch_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-tile bitonic sort on the 64-bit key; LDS for n <= SORT_LDS_CAP, global scratch (the not yet
-// used gradient-slot buffer G) for longer lists — the "tile-list spill path".
+// per-tile sort on the unique 64-bit key: counting-rank sort in LDS for n <= 512, bitonic sort in LDS for
+// n <= SORT_LDS_CAP, bitonic in global scratch (the not yet used gradient-slot buffer G) for longer lists —
+// the "tile-list spill path".
 // ---------------------------------------------------------------------------------------------
 __device__ inline void bitonic_sort(uint64_t* a, uint32_t n2) {
     for (uint32_t k = 2; k <= n2; k <<= 1)
@@ -169,6 +170,29 @@ __global__ __launch_bounds__(WG) void k_tile_sort(Dims d, Scratch s) {
     uint32_t* pl = s.point_list + (size_t)v * d.Rcap + start;
     uint32_t* sl = s.slot_list + (size_t)v * d.Rcap + start;
     if (threadIdx.x == 0) atomicMax(&s.flags[v * 4 + 1], n);
+    constexpr uint32_t RANK_MAX = 512;
+    if (n <= RANK_MAX) {
+        // Short lists (the common case: a few hundred entries): counting-rank sort.  Keys are unique, so
+        // rank = #keys smaller is the final position; every thread ranks its key against the whole list with
+        // broadcast 16-byte LDS reads.  Two barriers in total instead of one per bitonic step.
+        const uint32_t ne = (n + 1) & ~1u;
+        for (uint32_t t = threadIdx.x; t < ne; t += WG) sk[t] = t < n ? bins[t] : ~0ull;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < n; t += WG) {
+            const uint64_t mine = sk[t];
+            uint32_t rank = 0;
+            const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(sk);
+            for (uint32_t j = 0; j < ne / 2; j++) {
+                const ulonglong2 kk = pairs[j];
+                rank += (kk.x < mine) ? 1u : 0u;
+                rank += (kk.y < mine) ? 1u : 0u;
+            }
+            const uint32_t slot = (uint32_t)mine;
+            sl[rank] = slot;
+            pl[rank] = ids[slot];
+        }
+        return;
+    }
     uint32_t n2 = 2;
     while (n2 < n) n2 <<= 1;
     uint64_t* a;
@@ -176,7 +200,7 @@ __global__ __launch_bounds__(WG) void k_tile_sort(Dims d, Scratch s) {
     else a = reinterpret_cast<uint64_t*>(s.G + (size_t)v * d.Rcap * G_STRIDE) + 2 * (size_t)start;  // n2 < 2n entries
     for (uint32_t t = threadIdx.x; t < n2; t += WG) a[t] = t < n ? bins[t] : ~0ull;
     __syncthreads();
-    if (n > 1) bitonic_sort(a, n2);
+    bitonic_sort(a, n2);
     for (uint32_t t = threadIdx.x; t < n; t += WG) {
         const uint32_t slot = (uint32_t)a[t];
         sl[t] = slot;

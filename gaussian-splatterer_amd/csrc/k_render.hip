@@ -46,17 +46,15 @@ __device__ inline bool block_reaches(float cx, float cy, float a, float b, float
     return (tau >= 0.0f) && !(qmin > tau);
 }
 
-template <int N> struct StagedTile {
-    float4 A[N];   // x, y, conA, conB
-    float4 B[N];   // conC, opacity, r, g
-    float C[N];    // b
-    float Tau[N];  // cull threshold
+template <int N> struct StagedTile {  // three 16-byte-strided arrays: one scalar address serves all reads of an entry
+    float4 A[N];  // x, y, conA, conB
+    float4 B[N];  // conC, opacity, r, g
+    float4 C[N];  // b, tau (cull threshold), -, depth
 };
 
 template <int N> __device__ inline void stage_entry(StagedTile<N>& t, int slot, const GeomRec* __restrict__ r) {
     const float4* q = reinterpret_cast<const float4*>(r);
-    const float4 a = q[0], b = q[1], c = q[2];
-    t.A[slot] = a; t.B[slot] = b; t.C[slot] = c.x; t.Tau[slot] = c.y;
+    t.A[slot] = q[0]; t.B[slot] = q[1]; t.C[slot] = q[2];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -99,7 +97,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
             bool hit = false;
             if (j < cnt) {
                 const float4 a = st.A[j];
-                hit = block_reaches(a.x, a.y, a.z, a.w, st.B[j].x, st.Tau[j], bxlo, bxhi, bylo, byhi);
+                hit = block_reaches(a.x, a.y, a.z, a.w, st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
             }
             unsigned long long mask = __ballot(hit);
             while (mask) {
@@ -107,7 +105,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
                 mask &= mask - 1;
                 const int jj = sub + k;
                 const float4 A = st.A[jj], B = st.B[jj];
-                const float cb = st.C[jj];
+                const float cb = st.C[jj].x;
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
                 float alpha = fminf(ALPHA_MAX, B.y * __expf(power));
@@ -331,7 +329,7 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
             bool hit = false;
             if (j < cnt && (uint32_t)(base + j) < wave_max_last) {
                 const float4 a = st.A[j];
-                hit = block_reaches(a.x, a.y, a.z, a.w, st.B[j].x, st.Tau[j], bxlo, bxhi, bylo, byhi);
+                hit = block_reaches(a.x, a.y, a.z, a.w, st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
             }
             unsigned long long mask = __ballot(hit);
             while (mask) {
@@ -339,7 +337,7 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
                 mask &= ~(1ull << kk);
                 const int jj = sub + kk;
                 const float4 Ac = st.A[jj], Bc = st.B[jj];
-                const float cbc = st.C[jj];
+                const float cbc = st.C[jj].x;
                 const uint32_t pos = (uint32_t)(base + jj);  // upstream's `contributor` after its decrement
                 const float dx = Ac.x - pxf, dy = Ac.y - pyf;
                 const float power = -0.5f * (Ac.z * dx * dx + Bc.x * dy * dy) - Ac.w * dx * dy;

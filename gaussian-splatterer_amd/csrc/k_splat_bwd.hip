@@ -28,11 +28,11 @@ template <int D> struct SplatOut {
 
 // in: mean, s = mod*scale, quaternion (r,x,y,z), sh[NC][3], view, clamp flags, the pixel-stage sums
 // (colour 3, mean2D 2, conic x/y/w 3).  Mirrors oracle/gs_oracle.cpp::preprocess_backward.
-template <int D>
+template <int D, bool WANT_SH, class ShAt>
 __device__ inline void splat_backward_core(const gs_view& vp, int W, int H, const float mean[3], const float s[3],
-                                           const float q[4], const float (*sh)[3], uint32_t clamp_flags,
+                                           const float q[4], ShAt sh, uint32_t clamp_flags,
                                            const float dcolor[3], float g2x, float g2y, float gcx, float gcy, float gcz,
-                                           SplatOut<D>& o) {
+                                           SplatOut<D>& o, float dRGB_out[3]) {
     const float* view = vp.view;
     const float* proj = vp.projview;
     const float focal_x = (float)W / (2.0f * vp.tan_fovx);
@@ -138,36 +138,41 @@ __device__ inline void splat_backward_core(const gs_view& vp, int W, int H, cons
         for (int ch = 0; ch < 3; ch++) {
             const float dl = dcolor[ch] * (((clamp_flags >> ch) & 1u) ? 0.0f : 1.0f);
             float dx_ = 0, dy_ = 0, dz_ = 0;
-            o.sh[0][ch] = C0 * dl;
+            dRGB_out[ch] = dl;
+            if constexpr (WANT_SH) o.sh[0][ch] = C0 * dl;
             if constexpr (D > 0) {
-                o.sh[1][ch] = (-C1 * Y) * dl; o.sh[2][ch] = (C1 * Z) * dl; o.sh[3][ch] = (-C1 * X) * dl;
-                dx_ = -C1 * sh[3][ch]; dy_ = -C1 * sh[1][ch]; dz_ = C1 * sh[2][ch];
+                if constexpr (WANT_SH) { o.sh[1][ch] = (-C1 * Y) * dl; o.sh[2][ch] = (C1 * Z) * dl; o.sh[3][ch] = (-C1 * X) * dl; }
+                dx_ = -C1 * sh(3, ch); dy_ = -C1 * sh(1, ch); dz_ = C1 * sh(2, ch);
             }
             if constexpr (D > 1) {
                 const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
-                o.sh[4][ch] = (C2_0 * xy) * dl; o.sh[5][ch] = (C2_1 * yz) * dl;
-                o.sh[6][ch] = (C2_2 * (2.0f * zz - xx - yy)) * dl; o.sh[7][ch] = (C2_3 * xz) * dl;
-                o.sh[8][ch] = (C2_4 * (xx - yy)) * dl;
-                dx_ += C2_0 * Y * sh[4][ch] + C2_2 * 2.0f * -X * sh[6][ch] + C2_3 * Z * sh[7][ch] + C2_4 * 2.0f * X * sh[8][ch];
-                dy_ += C2_0 * X * sh[4][ch] + C2_1 * Z * sh[5][ch] + C2_2 * 2.0f * -Y * sh[6][ch] + C2_4 * 2.0f * -Y * sh[8][ch];
-                dz_ += C2_1 * Y * sh[5][ch] + C2_2 * 2.0f * 2.0f * Z * sh[6][ch] + C2_3 * X * sh[7][ch];
+                if constexpr (WANT_SH) {
+                    o.sh[4][ch] = (C2_0 * xy) * dl; o.sh[5][ch] = (C2_1 * yz) * dl;
+                    o.sh[6][ch] = (C2_2 * (2.0f * zz - xx - yy)) * dl; o.sh[7][ch] = (C2_3 * xz) * dl;
+                    o.sh[8][ch] = (C2_4 * (xx - yy)) * dl;
+                }
+                dx_ += C2_0 * Y * sh(4, ch) + C2_2 * 2.0f * -X * sh(6, ch) + C2_3 * Z * sh(7, ch) + C2_4 * 2.0f * X * sh(8, ch);
+                dy_ += C2_0 * X * sh(4, ch) + C2_1 * Z * sh(5, ch) + C2_2 * 2.0f * -Y * sh(6, ch) + C2_4 * 2.0f * -Y * sh(8, ch);
+                dz_ += C2_1 * Y * sh(5, ch) + C2_2 * 2.0f * 2.0f * Z * sh(6, ch) + C2_3 * X * sh(7, ch);
                 if constexpr (D > 2) {
-                    o.sh[9][ch] = (C3_0 * Y * (3.0f * xx - yy)) * dl;
-                    o.sh[10][ch] = (C3_1 * xy * Z) * dl;
-                    o.sh[11][ch] = (C3_2 * Y * (4.0f * zz - xx - yy)) * dl;
-                    o.sh[12][ch] = (C3_3 * Z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * dl;
-                    o.sh[13][ch] = (C3_4 * X * (4.0f * zz - xx - yy)) * dl;
-                    o.sh[14][ch] = (C3_5 * Z * (xx - yy)) * dl;
-                    o.sh[15][ch] = (C3_6 * X * (xx - 3.0f * yy)) * dl;
-                    dx_ += C3_0 * sh[9][ch] * 3.0f * 2.0f * xy + C3_1 * sh[10][ch] * yz + C3_2 * sh[11][ch] * -2.0f * xy +
-                           C3_3 * sh[12][ch] * -3.0f * 2.0f * xz + C3_4 * sh[13][ch] * (-3.0f * xx + 4.0f * zz - yy) +
-                           C3_5 * sh[14][ch] * 2.0f * xz + C3_6 * sh[15][ch] * 3.0f * (xx - yy);
-                    dy_ += C3_0 * sh[9][ch] * 3.0f * (xx - yy) + C3_1 * sh[10][ch] * xz +
-                           C3_2 * sh[11][ch] * (-3.0f * yy + 4.0f * zz - xx) + C3_3 * sh[12][ch] * -3.0f * 2.0f * yz +
-                           C3_4 * sh[13][ch] * -2.0f * xy + C3_5 * sh[14][ch] * -2.0f * yz + C3_6 * sh[15][ch] * -3.0f * 2.0f * xy;
-                    dz_ += C3_1 * sh[10][ch] * xy + C3_2 * sh[11][ch] * 4.0f * 2.0f * yz +
-                           C3_3 * sh[12][ch] * 3.0f * (2.0f * zz - xx - yy) + C3_4 * sh[13][ch] * 4.0f * 2.0f * xz +
-                           C3_5 * sh[14][ch] * (xx - yy);
+                    if constexpr (WANT_SH) {
+                        o.sh[9][ch] = (C3_0 * Y * (3.0f * xx - yy)) * dl;
+                        o.sh[10][ch] = (C3_1 * xy * Z) * dl;
+                        o.sh[11][ch] = (C3_2 * Y * (4.0f * zz - xx - yy)) * dl;
+                        o.sh[12][ch] = (C3_3 * Z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * dl;
+                        o.sh[13][ch] = (C3_4 * X * (4.0f * zz - xx - yy)) * dl;
+                        o.sh[14][ch] = (C3_5 * Z * (xx - yy)) * dl;
+                        o.sh[15][ch] = (C3_6 * X * (xx - 3.0f * yy)) * dl;
+                    }
+                    dx_ += C3_0 * sh(9, ch) * 3.0f * 2.0f * xy + C3_1 * sh(10, ch) * yz + C3_2 * sh(11, ch) * -2.0f * xy +
+                           C3_3 * sh(12, ch) * -3.0f * 2.0f * xz + C3_4 * sh(13, ch) * (-3.0f * xx + 4.0f * zz - yy) +
+                           C3_5 * sh(14, ch) * 2.0f * xz + C3_6 * sh(15, ch) * 3.0f * (xx - yy);
+                    dy_ += C3_0 * sh(9, ch) * 3.0f * (xx - yy) + C3_1 * sh(10, ch) * xz +
+                           C3_2 * sh(11, ch) * (-3.0f * yy + 4.0f * zz - xx) + C3_3 * sh(12, ch) * -3.0f * 2.0f * yz +
+                           C3_4 * sh(13, ch) * -2.0f * xy + C3_5 * sh(14, ch) * -2.0f * yz + C3_6 * sh(15, ch) * -3.0f * 2.0f * xy;
+                    dz_ += C3_1 * sh(10, ch) * xy + C3_2 * sh(11, ch) * 4.0f * 2.0f * yz +
+                           C3_3 * sh(12, ch) * 3.0f * (2.0f * zz - xx - yy) + C3_4 * sh(13, ch) * 4.0f * 2.0f * xz +
+                           C3_5 * sh(14, ch) * (xx - yy);
                 }
             }
             ddx += dx_ * dl; ddy += dy_ * dl; ddz += dz_ * dl;
@@ -216,49 +221,92 @@ __device__ inline void gather_rows(const float* __restrict__ Gv, uint32_t first,
     }
 }
 
+// SH basis exactly as the backward writes it: dL_dsh[k][c] = basis[k] * dL_dRGB[c].
+template <int D> __device__ inline void sh_basis(float X, float Y, float Z, float* b) {
+    b[0] = C0;
+    if constexpr (D > 0) { b[1] = -C1 * Y; b[2] = C1 * Z; b[3] = -C1 * X; }
+    if constexpr (D > 1) {
+        const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+        b[4] = C2_0 * xy; b[5] = C2_1 * yz; b[6] = C2_2 * (2.0f * zz - xx - yy); b[7] = C2_3 * xz; b[8] = C2_4 * (xx - yy);
+        if constexpr (D > 2) {
+            b[9] = C3_0 * Y * (3.0f * xx - yy); b[10] = C3_1 * xy * Z; b[11] = C3_2 * Y * (4.0f * zz - xx - yy);
+            b[12] = C3_3 * Z * (2.0f * zz - 3.0f * xx - 3.0f * yy); b[13] = C3_4 * X * (4.0f * zz - xx - yy);
+            b[14] = C3_5 * Z * (xx - yy); b[15] = C3_6 * X * (xx - 3.0f * yy);
+        }
+    }
+}
+
+// Trainer stage 1: one thread per (view, splat) — fully parallel (V*P threads).  Sums the splat's gradient rows
+// and runs the per-splat chain; the result is ONE 64-byte record per (view, splat):
+//   mean(3) scale(3) rot(4) opacity(1) dL_dRGB(3, clamp-masked) pad(2).   Culled splats write zeros.
 template <int D>
-__global__ __launch_bounds__(WG) void k_splat_bwd_avg(Dims d, const float* __restrict__ params, Scratch s, float samples,
-                                                      float* __restrict__ grad) {
+__global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __restrict__ params, Scratch s, float4* __restrict__ rec_out) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    const int v = blockIdx.y;
+    if (i >= d.P) return;
+    const Planes pl{ d.M };
+    const size_t st = (size_t)d.Pa;
+    float4* out = rec_out + ((size_t)v * st + i) * 4;
+    const GeomRec* rec = s.geom + (size_t)v * st + i;
+    if ((s.flags[v * 4 + 0] & 1u) || !(rec->radius > 0)) {  // culled: the reference's nine buffers stay zero
+        const float4 z = make_float4(0, 0, 0, 0);
+        out[0] = z; out[1] = z; out[2] = z; out[3] = z;
+        return;
+    }
+    float mean[3], sc[3], q[4];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { mean[c] = params[pl.loc(c) * st + i]; sc[c] = d.mod * params[pl.scale(c) * st + i]; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = params[pl.rot(c) * st + i];
+    const uint32_t tiles = s.tiles_touched[(size_t)v * st + i];
+    const uint32_t first = s.point_offsets[(size_t)v * st + i] - tiles;
+    float sum[9];
+    gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, first, tiles, sum);
+    SplatOut<D> o;
+    float dRGB[3];
+    auto sh_at = [&](int k, int c) { return params[pl.sh(k, c) * st + i]; };  // streamed: no 48-register SH array
+    splat_backward_core<D, false>(s.views[v], d.W, d.H, mean, sc, q, sh_at, rec->flags, sum, sum[3], sum[4], sum[5], sum[6], sum[7], o, dRGB);
+    out[0] = make_float4(o.mean[0], o.mean[1], o.mean[2], o.scale[0]);
+    out[1] = make_float4(o.scale[1], o.scale[2], o.rot[0], o.rot[1]);
+    out[2] = make_float4(o.rot[2], o.rot[3], sum[8], dRGB[0]);
+    out[3] = make_float4(dRGB[1], dRGB[2], 0.0f, 0.0f);
+}
+
+// Trainer stage 2: one thread per splat walks the views in the reference's order and applies
+// accumulateGradients (src/Trainer.cu:51-76: var += |g_loc| / S, avg += g / S); the SH gradient is rebuilt as
+// basis(view direction) x dL_dRGB.  Every gradient plane is written exactly once per step.
+template <int D>
+__global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __restrict__ params, Scratch s, float samples,
+                                                         const float4* __restrict__ rec_in, float* __restrict__ grad) {
     constexpr int NC = (D + 1) * (D + 1);
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
-    float mean[3], sc[3], q[4], sh[NC][3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { mean[c] = params[pl.loc(c) * st + i]; sc[c] = d.mod * params[pl.scale(c) * st + i]; }
-#pragma unroll
-    for (int c = 0; c < 4; c++) q[c] = params[pl.rot(c) * st + i];
-#pragma unroll
-    for (int k = 0; k < NC; k++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) sh[k][c] = params[pl.sh(k, c) * st + i];
-
+    const float mx = params[pl.loc(0) * st + i], my = params[pl.loc(1) * st + i], mz = params[pl.loc(2) * st + i];
     float var = 0.0f, aLoc[3] = { 0, 0, 0 }, aScale[3] = { 0, 0, 0 }, aRot[4] = { 0, 0, 0, 0 }, aOpac = 0.0f, aSh[NC][3];
 #pragma unroll
     for (int k = 0; k < NC; k++) aSh[k][0] = aSh[k][1] = aSh[k][2] = 0.0f;
-
     for (int v = 0; v < d.V; v++) {
-        if (s.flags[v * 4 + 0] & 1u) continue;
-        const GeomRec* rec = s.geom + (size_t)v * st + i;
-        if (!(rec->radius > 0)) continue;  // culled in this view: all nine reference buffers stay zero
-        const uint32_t tiles = s.tiles_touched[(size_t)v * st + i];
-        const uint32_t first = s.point_offsets[(size_t)v * st + i] - tiles;
-        float sum[9];
-        gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, first, tiles, sum);
-        SplatOut<D> o;
-        splat_backward_core<D>(s.views[v], d.W, d.H, mean, sc, q, sh, rec->flags, sum, sum[3], sum[4], sum[5], sum[6], sum[7], o);
-        // accumulateGradients, src/Trainer.cu:51-76 (division by `samples`, view order)
-        var += sqrtf((o.mean[0] * o.mean[0]) + (o.mean[1] * o.mean[1]) + (o.mean[2] * o.mean[2])) / samples;
+        const float4* r = rec_in + ((size_t)v * st + i) * 4;
+        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        const float gm[3] = { r0.x, r0.y, r0.z }, gs3[3] = { r0.w, r1.x, r1.y }, gr[4] = { r1.z, r1.w, r2.x, r2.y };
+        const float dRGB[3] = { r2.w, r3.x, r3.y };
+        var += sqrtf((gm[0] * gm[0]) + (gm[1] * gm[1]) + (gm[2] * gm[2])) / samples;
 #pragma unroll
-        for (int c = 0; c < 3; c++) { aLoc[c] += o.mean[c] / samples; aScale[c] += o.scale[c] / samples; }
+        for (int c = 0; c < 3; c++) { aLoc[c] += gm[c] / samples; aScale[c] += gs3[c] / samples; }
+        aOpac += r2.z / samples;
+#pragma unroll
+        for (int c = 0; c < 4; c++) aRot[c] += gr[c] / samples;
+        const float* cp = s.views[v].campos;
+        const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
+        const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+        float basis[NC];
+        sh_basis<D>(ox / len, oy / len, oz / len, basis);
 #pragma unroll
         for (int k = 0; k < NC; k++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) aSh[k][c] += o.sh[k][c] / samples;
-        aOpac += sum[8] / samples;
-#pragma unroll
-        for (int c = 0; c < 4; c++) aRot[c] += o.rot[c] / samples;
+            for (int c = 0; c < 3; c++) aSh[k][c] += (basis[k] * dRGB[c]) / samples;
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) { grad[pl.loc(c) * st + i] = aLoc[c]; grad[pl.scale(c) * st + i] = aScale[c]; }
@@ -276,12 +324,17 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_avg(Dims d, const float* __res
 
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, hipStream_t stream) {
     if (d.P == 0) return GS_OK;
-    dim3 grid((d.P + WG - 1) / WG);
+    dim3 g1((d.P + WG - 1) / WG, d.V), g2((d.P + WG - 1) / WG);
+    float4* rec = reinterpret_cast<float4*>(s.splat_grads);
     switch (d.D) {
-        case 0: hipLaunchKernelGGL(k_splat_bwd_avg<0>, grid, dim3(WG), 0, stream, d, params, s, samples, grad); break;
-        case 1: hipLaunchKernelGGL(k_splat_bwd_avg<1>, grid, dim3(WG), 0, stream, d, params, s, samples, grad); break;
-        case 2: hipLaunchKernelGGL(k_splat_bwd_avg<2>, grid, dim3(WG), 0, stream, d, params, s, samples, grad); break;
-        default: hipLaunchKernelGGL(k_splat_bwd_avg<3>, grid, dim3(WG), 0, stream, d, params, s, samples, grad); break;
+        case 0: hipLaunchKernelGGL(k_splat_bwd_view<0>, g1, dim3(WG), 0, stream, d, params, s, rec);
+                hipLaunchKernelGGL(k_splat_bwd_reduce<0>, g2, dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad); break;
+        case 1: hipLaunchKernelGGL(k_splat_bwd_view<1>, g1, dim3(WG), 0, stream, d, params, s, rec);
+                hipLaunchKernelGGL(k_splat_bwd_reduce<1>, g2, dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad); break;
+        case 2: hipLaunchKernelGGL(k_splat_bwd_view<2>, g1, dim3(WG), 0, stream, d, params, s, rec);
+                hipLaunchKernelGGL(k_splat_bwd_reduce<2>, g2, dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad); break;
+        default: hipLaunchKernelGGL(k_splat_bwd_view<3>, g1, dim3(WG), 0, stream, d, params, s, rec);
+                 hipLaunchKernelGGL(k_splat_bwd_reduce<3>, g2, dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad); break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;
@@ -320,7 +373,9 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_seam(Dims d, const float* __re
     g.dL_dconic[4 * (size_t)i] = gcx; g.dL_dconic[4 * (size_t)i + 1] = gcy; g.dL_dconic[4 * (size_t)i + 3] = gcz;
     g.dL_dopacity[i] += sum[8];
     SplatOut<D> o;
-    splat_backward_core<D>(s.views[0], d.W, d.H, mean, sc, q, sh, rec->flags, dcolor, g2x, g2y, gcx, gcy, gcz, o);
+    float dRGB[3];
+    auto sh_at = [&](int k, int c) { return sh[k][c]; };
+    splat_backward_core<D, true>(s.views[0], d.W, d.H, mean, sc, q, sh_at, rec->flags, dcolor, g2x, g2y, gcx, gcy, gcz, o, dRGB);
     for (int c = 0; c < 3; c++) { g.dL_dmean3D[3 * (size_t)i + c] = o.mean[c]; g.dL_dscale[3 * (size_t)i + c] = o.scale[c]; }
     for (int c = 0; c < 6; c++) g.dL_dcov3D[6 * (size_t)i + c] = o.cov3D[c];
     for (int c = 0; c < 4; c++) g.dL_drot[4 * (size_t)i + c] = o.rot[c];
