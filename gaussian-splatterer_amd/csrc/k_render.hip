@@ -305,7 +305,7 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
     float ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f;  // accum_rec
     float lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;  // last_color
     float last_alpha = 0.0f;
-    const float bg_dot = bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2;
+    const float tfbg = -T_final * (bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2);
     const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
     // where this lane parks a reduced value: lane 2q -> q, lane 1 -> 8 (row 0 only)
     const bool writer = lane < 16 && (((lane & 1) == 0) || lane == 1);
@@ -344,31 +344,27 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
                 const float G = __expf(power);
                 const float alpha = fminf(ALPHA_MAX, Bc.y * G);
                 const bool act = (pos < last_contributor) && power <= 0.0f && alpha >= ALPHA_MIN;
-                float g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0, g8 = 0;
+                // Per lane only the colour terms and six moments of u = G * dL_dalpha are formed; the factors
+                // that are constant per splat (opacity, conic, 0.5*W, -0.5) are applied once per entry in the flush.
+                float dchannel_dcolor = 0.0f, u = 0.0f;
                 if (act) {
                     const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
                     T = T * inv1ma;
-                    const float dchannel_dcolor = alpha * T;
-                    float dL_dalpha = 0.0f;
-                    ar0 = last_alpha * lc0 + (1.0f - last_alpha) * ar0; lc0 = Bc.z; dL_dalpha += (Bc.z - ar0) * dpx0; g0 = dchannel_dcolor * dpx0;
-                    ar1 = last_alpha * lc1 + (1.0f - last_alpha) * ar1; lc1 = Bc.w; dL_dalpha += (Bc.w - ar1) * dpx1; g1 = dchannel_dcolor * dpx1;
-                    ar2 = last_alpha * lc2 + (1.0f - last_alpha) * ar2; lc2 = cbc; dL_dalpha += (cbc - ar2) * dpx2; g2 = dchannel_dcolor * dpx2;
-                    dL_dalpha *= T;
+                    dchannel_dcolor = alpha * T;
+                    const float keep = 1.0f - last_alpha;
+                    float dL_dalpha;
+                    ar0 = last_alpha * lc0 + keep * ar0; lc0 = Bc.z; dL_dalpha = (Bc.z - ar0) * dpx0;
+                    ar1 = last_alpha * lc1 + keep * ar1; lc1 = Bc.w; dL_dalpha += (Bc.w - ar1) * dpx1;
+                    ar2 = last_alpha * lc2 + keep * ar2; lc2 = cbc; dL_dalpha += (cbc - ar2) * dpx2;
+                    dL_dalpha = dL_dalpha * T + tfbg * inv1ma;   // tfbg = -T_final * (bg . dL_dpix)
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final * inv1ma) * bg_dot;
-                    const float dL_dG = Bc.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * Ac.z - gdy * Ac.w;
-                    const float dG_ddely = -gdy * Bc.x - gdx * Ac.w;
-                    g3 = dL_dG * dG_ddelx * ddelx_dx;
-                    g4 = dL_dG * dG_ddely * ddely_dy;
-                    g5 = -0.5f * gdx * dx * dL_dG;
-                    g6 = -0.5f * gdx * dy * dL_dG;
-                    g7 = -0.5f * gdy * dy * dL_dG;
-                    g8 = G * dL_dalpha;
+                    u = G * dL_dalpha;
                 }
                 if (__ballot(act) != 0ull) {
-                    const float red = wave_reduce_scatter9(g0, g1, g2, g3, g4, g5, g6, g7, g8);
+                    // inactive lanes contribute exact zeros: dchannel_dcolor = u = 0 there
+                    const float ux = u * dx, uy = u * dy;
+                    const float red = wave_reduce_scatter9(dchannel_dcolor * dpx0, dchannel_dcolor * dpx1, dchannel_dcolor * dpx2, ux, uy,
+                                                           ux * dx, ux * dy, uy * dy, u);
                     if (writer) sAcc[(wave * BWD_ROUND + jj) * ACC_STRIDE + wslot] = red;
                     touched[sb] |= 1ull << kk;
                 }
@@ -391,9 +387,17 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
                     for (int q = 0; q < ACC_STRIDE; q++) sum[q] += a[q];
                 }
             }
+            // moments -> the reference's nine sums (dx = mean2D.x - pixel.x as upstream):
+            //   dL_dmean2D.x = -0.5 W op (conA * S[u dx] + conB * S[u dy]),  .y = -0.5 H op (conC * S[u dy] + conB * S[u dx])
+            //   dL_dconic    = -0.5 op (S[u dx dx], S[u dx dy], S[u dy dy]),  dL_dopacity = S[u]
+            const float4 Af = st.A[tid], Bf = st.B[tid];
+            const float op = Bf.y;
+            const float gmx = -ddelx_dx * op * (Af.z * sum[3] + Af.w * sum[4]);
+            const float gmy = -ddely_dy * op * (Bf.x * sum[4] + Af.w * sum[3]);
+            const float hop = -0.5f * op;
             float4* row = reinterpret_cast<float4*>(Gv + (size_t)sSlot[tid] * G_STRIDE);
-            row[0] = make_float4(sum[0], sum[1], sum[2], sum[3]);
-            row[1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
+            row[0] = make_float4(sum[0], sum[1], sum[2], gmx);
+            row[1] = make_float4(gmy, hop * sum[5], hop * sum[6], hop * sum[7]);
             row[2] = make_float4(sum[8], 0.0f, 0.0f, 0.0f);
         }
     }
