@@ -55,6 +55,7 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
     Dims d;
     d.P = P; d.Pa = Pa; d.D = D; d.M = M; d.W = W; d.H = H; d.N = W * H;
     d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
+    d.sgx = (d.gx + STILE - 1) / STILE; d.sgy = (d.gy + STILE - 1) / STILE; d.NST = d.sgx * d.sgy;
     d.V = V; d.Rcap = Rcap; d.mod = mod; d.cull = g_opt_cull;
     return d;
 }
@@ -63,8 +64,8 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
 // grow-only, sized for V views at once: with 288 GB of HBM every view of a step keeps its own
 // state and each stage is ONE launch over all views.
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, zero_block, tile_end, bins, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads;
-    int V = 0, Pa = 0, T = 0, N = 0;
+    DevBuf views, geom, tiles, offsets, zero_block, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads;
+    int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
     Scratch s{};
     size_t zero_bytes = 0;
@@ -79,11 +80,18 @@ struct ScratchSet {
         GS_TRY(geom.ensure(v * Pa * sizeof(GeomRec)));
         GS_TRY(tiles.ensure(v * Pa * 4));
         GS_TRY(offsets.ensure(v * Pa * 4));
-        // zero block: tile_count | tile_cursor | flags | loss   (cleared by one memset per step)
-        zero_bytes = v * T * 4 * 2 + v * 16 + v * 4;
+        {
+            const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+            NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE) * CGROUPS;  // counters, not super-tiles
+        }
+        // zero block: coarse_count | coarse_cursor | flags | loss   (cleared by one memset per step)
+        zero_bytes = v * NST * 4 * 2 + v * 16 + v * 4;
         GS_TRY(zero_block.ensure(zero_bytes));
+        GS_TRY(coarse_end.ensure(v * NST * 4));
+        GS_TRY(tile_count.ensure(v * T * 4));
         GS_TRY(tile_end.ensure(v * T * 4));
-        GS_TRY(bins.ensure(v * Rcap * 8));
+        GS_TRY(clist.ensure(v * Rcap * 16));
+        GS_TRY(cdepth.ensure(v * Rcap * 4));
         GS_TRY(ids.ensure(v * Rcap * 4));
         GS_TRY(plist.ensure(v * Rcap * 4));
         GS_TRY(slist.ensure(v * Rcap * 4));
@@ -91,19 +99,22 @@ struct ScratchSet {
         GS_TRY(color.ensure(v * 3 * N * 4));
         GS_TRY(finalT.ensure(v * N * 4));
         GS_TRY(ncontrib.ensure(v * N * 4));
-        GS_TRY(scan_tmp.ensure((scan_partials_count(Pa, (int)v) + scan_partials_count(T, (int)v) + 64) * 4));
+        GS_TRY(scan_tmp.ensure((scan_partials_count(Pa, (int)v) + scan_partials_count(T, (int)v) + scan_partials_count(NST, (int)v) + 64) * 4));
         if (want_splat_grads) GS_TRY(sgrads.ensure(v * Pa * 64));
         s.splat_grads = sgrads.as<float>();
         s.views = views.as<gs_view>();
         s.geom = geom.as<GeomRec>();
         s.tiles_touched = tiles.as<uint32_t>();
         s.point_offsets = offsets.as<uint32_t>();
-        s.tile_count = zero_block.as<uint32_t>();
-        s.tile_cursor = s.tile_count + v * T;
-        s.flags = s.tile_cursor + v * T;
+        s.coarse_count = zero_block.as<uint32_t>();
+        s.coarse_cursor = s.coarse_count + v * NST;
+        s.flags = s.coarse_cursor + v * NST;
         s.loss = reinterpret_cast<float*>(s.flags + v * 4);
+        s.coarse_end = coarse_end.as<uint32_t>();
+        s.tile_count = tile_count.as<uint32_t>();
         s.tile_end = tile_end.as<uint32_t>();
-        s.bins = bins.as<uint64_t>();
+        s.coarse_list = clist.as<uint4>();
+        s.coarse_depth = cdepth.as<uint32_t>();
         s.id_of_slot = ids.as<uint32_t>();
         s.point_list = plist.as<uint32_t>();
         s.slot_list = slist.as<uint32_t>();
@@ -116,22 +127,29 @@ struct ScratchSet {
         return GS_OK;
     }
     void release() {
-        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &zero_block, &tile_end, &bins, &ids, &plist, &slist, &G, &color,
+        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &zero_block, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &color,
                            &finalT, &ncontrib, &scan_tmp, &sgrads })
             b->release();
     }
 };
 
-// projection + the two scans (everything that does not need the binning arena)
+// projection + the per-splat and per-super-tile scans (everything that does not need the binning arena)
 static int stage_project(const Dims& d, const float* params, const Scratch& s, uint32_t* scan_tmp, hipStream_t st) {
     GS_TRY(launch_preprocess(d, params, s, st));
     GS_TRY(launch_scan_u32(s.tiles_touched, s.point_offsets, d.P, d.Pa, d.V, scan_tmp, st));
-    GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.V, scan_tmp + scan_partials_count(d.Pa, d.V), st));
     return GS_OK;
 }
-static int stage_bin_render(const Dims& d, const Scratch& s, hipStream_t st) {
-    GS_TRY(launch_scatter(d, s, st));
-    GS_TRY(launch_tile_sort(d, s, st));
+// coarse scan + scatter, per-tile counts + scan.  Runs for P == 0 too (the scans then define empty lists).
+static int stage_bin(const Dims& d, const Scratch& s, uint32_t* scan_tmp, hipStream_t st) {
+    GS_TRY(launch_scan_u32(s.coarse_count, s.coarse_end, d.NST * CGROUPS, d.NST * CGROUPS, d.V, scan_tmp + scan_partials_count(d.Pa, d.V), st));
+    GS_TRY(launch_coarse_scatter(d, s, st));
+    GS_TRY(launch_tile_count(d, s, st));
+    GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.V, scan_tmp + scan_partials_count(d.Pa, d.V) + scan_partials_count(d.NST * CGROUPS, d.V), st));
+    return GS_OK;
+}
+static int stage_bin_render(const Dims& d, const Scratch& s, uint32_t* scan_tmp, hipStream_t st) {
+    GS_TRY(stage_bin(d, s, scan_tmp, st));
+    GS_TRY(launch_tile_build_sort(d, s, st));
     GS_TRY(launch_render_forward(d, s, st));
     return GS_OK;
 }
@@ -484,15 +502,14 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
         if (P > 0) {
             uint32_t* tmp = t->train.scan_tmp.as<uint32_t>();
             { StageTimer tm(t, 0); GS_TRY(launch_preprocess(d, m->planes, s, t->stream)); }
-            { StageTimer tm(t, 1);
-              GS_TRY(launch_scan_u32(s.tiles_touched, s.point_offsets, d.P, d.Pa, d.V, tmp, t->stream));
-              GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.V, tmp + scan_partials_count(d.Pa, d.V), t->stream)); }
-            { StageTimer tm(t, 2); GS_TRY(launch_scatter(d, s, t->stream)); }
-            { StageTimer tm(t, 3); GS_TRY(launch_tile_sort(d, s, t->stream)); }
+            { StageTimer tm(t, 1); GS_TRY(launch_scan_u32(s.tiles_touched, s.point_offsets, d.P, d.Pa, d.V, tmp, t->stream)); }
+            { StageTimer tm(t, 2); GS_TRY(stage_bin(d, s, tmp, t->stream)); }
+            { StageTimer tm(t, 3); GS_TRY(launch_tile_build_sort(d, s, t->stream)); }
             { StageTimer tm(t, 4); GS_TRY(launch_render_forward(d, s, t->stream)); }
             { StageTimer tm(t, 5); GS_TRY(launch_render_backward(d, s, t->stream)); }
             { StageTimer tm(t, 6); GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), t->stream)); }
-        } else {
+        } else {  // empty model: tile lists are empty, the image is the background
+            GS_TRY(stage_bin(d, s, t->train.scan_tmp.as<uint32_t>(), t->stream));
             GS_TRY(launch_render_forward(d, s, t->stream));
         }
         GS_HIP(hipMemcpyAsync(t->h_flags, s.flags, (size_t)V * 20, hipMemcpyDeviceToHost, t->stream));
@@ -660,8 +677,9 @@ extern "C" int gs_trainer_render(gs_trainer* t, uint32_t* fb, int fb_on_device, 
         GS_HIP(hipMemsetAsync(t->preview.zero_block.p, 0, t->preview.zero_bytes, t->stream));
         if (m->count > 0) {
             GS_TRY(stage_project(d, m->planes, s, t->preview.scan_tmp.as<uint32_t>(), t->stream));
-            GS_TRY(stage_bin_render(d, s, t->stream));
+            GS_TRY(stage_bin_render(d, s, t->preview.scan_tmp.as<uint32_t>(), t->stream));
         } else {
+            GS_TRY(stage_bin(d, s, t->preview.scan_tmp.as<uint32_t>(), t->stream));
             GS_TRY(launch_render_forward(d, s, t->stream));
         }
         uint32_t flags[4];
@@ -704,38 +722,47 @@ struct Field { const char* name; size_t off, bytes; };
 inline size_t al(size_t x) { return round_up_sz(x, 256); }
 
 struct GeomLayout { size_t record, tiles, offsets, scan_tmp, view, flags, planes, total; int Pa; };
-GeomLayout geom_layout(int P, int M) {
+GeomLayout geom_layout(int P, int M, int W = 16, int H = 16) {
     GeomLayout L; L.Pa = std::max(64, round_up(P, 64));
     size_t o = 0;
     L.record = o; o = al(o + (size_t)L.Pa * sizeof(GeomRec));
     L.tiles = o; o = al(o + (size_t)L.Pa * 4);
     L.offsets = o; o = al(o + (size_t)L.Pa * 4);
-    L.scan_tmp = o; o = al(o + (scan_partials_count(L.Pa, 1) + 64) * 4);
+    {
+        const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+        const int T = gx * gy, NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE) * CGROUPS;
+        L.scan_tmp = o; o = al(o + (scan_partials_count(L.Pa, 1) + scan_partials_count(T, 1) + scan_partials_count(NST, 1) + 64) * 4);
+    }
     L.view = o; o = al(o + sizeof(gs_view));
     L.flags = o; o = al(o + 32);
     L.planes = o; o = al(o + (size_t)(11 + 3 * M) * L.Pa * 4);
     L.total = o;
     return L;
 }
-struct ImageLayout { size_t zero, tile_count, tile_cursor, tile_end, ranges, final_T, n_contrib, scan_tmp, total; int T; size_t zero_bytes; };
+struct ImageLayout { size_t zero, coarse_count, coarse_cursor, coarse_end, tile_count, tile_end, ranges, final_T, n_contrib, scan_tmp, total; int T, NST; size_t zero_bytes; };
 ImageLayout image_layout(int W, int H) {
     ImageLayout L; const size_t N = (size_t)W * H;
-    L.T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    L.T = gx * gy;
+    L.NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE) * CGROUPS;  // counters
     size_t o = 0;
-    L.zero = o; L.tile_count = o; o += (size_t)L.T * 4; L.tile_cursor = o; o += (size_t)L.T * 4; L.zero_bytes = o; o = al(o);
+    L.zero = o; L.coarse_count = o; o += (size_t)L.NST * 4; L.coarse_cursor = o; o += (size_t)L.NST * 4; L.zero_bytes = o; o = al(o);
+    L.coarse_end = o; o = al(o + (size_t)L.NST * 4);
+    L.tile_count = o; o = al(o + (size_t)L.T * 4);
     L.tile_end = o; o = al(o + (size_t)L.T * 4);
     L.ranges = o; o = al(o + (size_t)L.T * 8);
     L.final_T = o; o = al(o + N * 4);
     L.n_contrib = o; o = al(o + N * 4);
-    L.scan_tmp = o; o = al(o + (scan_partials_count(L.T, 1) + 64) * 4);
+    L.scan_tmp = o; o = al(o + (scan_partials_count(L.T, 1) + scan_partials_count(L.NST, 1) + 64) * 4);
     L.total = o;
     return L;
 }
-struct BinLayout { size_t bins, ids, plist, slist, G, total; uint32_t Rcap; };
+struct BinLayout { size_t clist, cdepth, ids, plist, slist, G, total; uint32_t Rcap; };
 BinLayout bin_layout(int R) {
     BinLayout L; L.Rcap = (uint32_t)std::max(R, 1);
     size_t o = 0;
-    L.bins = o; o = al(o + (size_t)L.Rcap * 8);
+    L.clist = o; o = al(o + (size_t)L.Rcap * 16);
+    L.cdepth = o; o = al(o + (size_t)L.Rcap * 4);
     L.ids = o; o = al(o + (size_t)L.Rcap * 4);
     L.plist = o; o = al(o + (size_t)L.Rcap * 4);
     L.slist = o; o = al(o + (size_t)L.Rcap * 4);
@@ -750,13 +777,16 @@ Scratch seam_scratch(char* geom, const GeomLayout& g, char* img, const ImageLayo
     s.tiles_touched = reinterpret_cast<uint32_t*>(geom + g.tiles);
     s.point_offsets = reinterpret_cast<uint32_t*>(geom + g.offsets);
     s.flags = reinterpret_cast<uint32_t*>(geom + g.flags);
+    s.coarse_count = reinterpret_cast<uint32_t*>(img + im.coarse_count);
+    s.coarse_cursor = reinterpret_cast<uint32_t*>(img + im.coarse_cursor);
+    s.coarse_end = reinterpret_cast<uint32_t*>(img + im.coarse_end);
     s.tile_count = reinterpret_cast<uint32_t*>(img + im.tile_count);
-    s.tile_cursor = reinterpret_cast<uint32_t*>(img + im.tile_cursor);
     s.tile_end = reinterpret_cast<uint32_t*>(img + im.tile_end);
     s.final_T = reinterpret_cast<float*>(img + im.final_T);
     s.n_contrib = reinterpret_cast<uint32_t*>(img + im.n_contrib);
     if (bin && b) {
-        s.bins = reinterpret_cast<uint64_t*>(bin + b->bins);
+        s.coarse_list = reinterpret_cast<uint4*>(bin + b->clist);
+        s.coarse_depth = reinterpret_cast<uint32_t*>(bin + b->cdepth);
         s.id_of_slot = reinterpret_cast<uint32_t*>(bin + b->ids);
         s.point_list = reinterpret_cast<uint32_t*>(bin + b->plist);
         s.slot_list = reinterpret_cast<uint32_t*>(bin + b->slist);
@@ -771,7 +801,7 @@ extern "C" int gs_raster_chunk_field(const char* chunk, const char* field, int P
     if (!chunk || !field || !offset || !bytes) return GS_ERR_INVALID_ARGUMENT;
     const std::string c(chunk), f(field);
     if (c == "geometry") {
-        const GeomLayout L = geom_layout(P, 1);
+        const GeomLayout L = geom_layout(P, 1, width, height);
         if (f == "record") { *offset = L.record; *bytes = (size_t)P * sizeof(GeomRec); return GS_OK; }
         if (f == "tiles_touched") { *offset = L.tiles; *bytes = (size_t)P * 4; return GS_OK; }
         if (f == "point_offsets") { *offset = L.offsets; *bytes = (size_t)P * 4; return GS_OK; }
@@ -811,7 +841,7 @@ extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_u
     GS_TRY(require_device());
     int D = 0;
     GS_TRY(effective_degree(D_in, M, &D));
-    const GeomLayout gl = geom_layout(P, M);
+    const GeomLayout gl = geom_layout(P, M, width, height);
     const ImageLayout il = image_layout(width, height);
     char* geom = geometry_alloc(gl.total, geometry_user);
     char* img = image_alloc(il.total, image_user);
@@ -847,8 +877,7 @@ extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_u
     s = seam_scratch(geom, gl, img, il, bin, &bl);
     s.out_color = out_color;
     d.Rcap = bl.Rcap;
-    if (P > 0) GS_TRY(stage_bin_render(d, s, st));
-    else GS_TRY(launch_render_forward(d, s, st));
+    GS_TRY(stage_bin_render(d, s, reinterpret_cast<uint32_t*>(geom + gl.scan_tmp), st));  // P == 0: empty lists, background image
     GS_TRY(launch_ranges(d, s, reinterpret_cast<uint32_t*>(img + il.ranges), st));
     GS_HIP(hipStreamSynchronize(st));
     if (num_rendered) *num_rendered = R;
@@ -878,7 +907,7 @@ extern "C" int gs_rasterize_backward(int P, int D_in, int M, int R, const float*
     int D = 0;
     GS_TRY(effective_degree(D_in, M, &D));
     if (P == 0) return GS_OK;
-    const GeomLayout gl = geom_layout(P, M);
+    const GeomLayout gl = geom_layout(P, M, width, height);
     const ImageLayout il = image_layout(width, height);
     const BinLayout bl = bin_layout(R);
     Scratch s = seam_scratch(geom_buffer, gl, image_buffer, il, binning_buffer, &bl);

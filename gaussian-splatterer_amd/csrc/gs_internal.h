@@ -34,7 +34,9 @@ int option_cull();
 constexpr int TILE = 16;           // 16x16-pixel tiles (upstream BLOCK_X/BLOCK_Y)
 constexpr int WG = 256;            // workgroup = 4 wave64
 constexpr int G_STRIDE = 12;       // floats per (splat,tile) gradient slot (9 used, 48-byte rows)
-constexpr int SORT_LDS_CAP = 4096; // entries a tile sorts in LDS; longer lists take the global path
+constexpr int SORT_LDS_CAP = 2048; // entries a tile sorts in LDS; longer lists take the global path
+constexpr int STILE = 4;           // a super-tile is STILE x STILE tiles (64x64 px): the coarse binning unit
+constexpr int CGROUPS = 16;        // each super-tile has CGROUPS counters (by splat workgroup) to spread same-address atomics
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
@@ -70,6 +72,7 @@ struct Dims {
     int M;        // SH coefficients per channel (plane count)
     int W, H, N;  // image
     int gx, gy, T;
+    int sgx, sgy, NST;  // super-tile grid
     int V;        // views in this launch
     uint32_t Rcap;  // entries per view the binning arena holds
     float mod;    // scale modifier
@@ -82,11 +85,14 @@ struct Scratch {
     GeomRec* geom;             // [V][Pa]
     uint32_t* tiles_touched;   // [V][Pa]
     uint32_t* point_offsets;   // [V][Pa]  inclusive scan of tiles_touched
+    uint32_t* coarse_count;    // [V][NST*CGROUPS] splats per (super-tile, splat group) (zeroed each step)
+    uint32_t* coarse_cursor;   // [V][NST*CGROUPS] (zeroed each step)
+    uint32_t* coarse_end;      // [V][NST*CGROUPS] inclusive scan of coarse_count (super-tile major: a super-tile's list is contiguous)
+    uint4* coarse_list;        // [V][Rcap] {splat id, rect_min, rect_max, first slot} per (splat, super-tile)
+    uint32_t* coarse_depth;    // [V][Rcap] depth bits of the same entries
     uint32_t* tile_count;      // [V][T]
     uint32_t* tile_end;        // [V][T]   inclusive scan of tile_count
-    uint32_t* tile_cursor;     // [V][T]
-    uint64_t* bins;            // [V][Rcap]  depth_bits << 32 | slot
-    uint32_t* id_of_slot;      // [V][Rcap]
+    uint32_t* id_of_slot;      // [V][Rcap] (only tiles longer than the rank-sort limit use it)
     uint32_t* point_list;      // [V][Rcap]  sorted splat ids
     uint32_t* slot_list;       // [V][Rcap]  sorted slots
     float* G;                  // [V][Rcap][G_STRIDE]
@@ -106,8 +112,9 @@ struct Scratch {
 int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st);
 int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int batch, uint32_t* partials, hipStream_t st);
 size_t scan_partials_count(int n, int batch);
-int launch_scatter(const Dims& d, const Scratch& s, hipStream_t st);
-int launch_tile_sort(const Dims& d, const Scratch& s, hipStream_t st);
+int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st);
+int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st);
+int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_backward(const Dims& d, const Scratch& s, hipStream_t st);
 // Trainer form: loops the views, writes the averaged-gradient planes (incl. var) once.

@@ -1,14 +1,16 @@
-// k_binning.hip — scan, per-tile scatter and per-tile depth sort.  Together they replace the
-// InclusiveSum -> duplicateWithKeys -> global 64-bit radix sort -> identifyTileRanges chain of
+// k_binning.hip — scans, coarse (super-tile) scatter, per-tile gather + depth sort.  Together they replace
+// the InclusiveSum -> duplicateWithKeys -> global 64-bit radix sort -> identifyTileRanges chain of
 // CudaRasterizer::Rasterizer::forward (reference call site src/Trainer.cu:334-360; SURVEY.md
 // Appendix A.2-A.5) and produce the identical per-tile ordered lists:
 //   upstream sorts (tile << 32 | depth_bits) stably, ties keep emission order = ascending splat id;
-//   here every entry gets the slot its upstream emission position would have had
-//   (slot = point_offsets[i-1] + k, k-th tile of splat i in y-outer/x-inner order), entries are
-//   scattered into their tile's segment in arbitrary (atomic) order, and each tile is sorted on
-//   the unique 64-bit key (depth_bits << 32 | slot).  slot is monotone in splat id, so the result
-//   equals the stable global sort, deterministically, without any global multi-pass sort.
-// MI355X: a tile's list lives in LDS (160 KB/CU) for the whole sort; integer arithmetic only.
+//   here every (splat, tile) entry is identified by the slot its upstream emission position would have had
+//   (slot = point_offsets[i-1] + k, k-th tile of splat i in y-outer/x-inner order) and each tile is sorted
+//   on the unique 64-bit key (depth_bits << 32 | slot).  slot is monotone in splat id, so the result equals
+//   the stable global sort, deterministically, without any global multi-pass sort.
+// MI355X: scattered device-scope atomics are the scarce resource (~20 G/s, they execute at the memory
+// side), so splats are binned with atomics only at 64x64-px super-tile granularity (~1.5 per splat);
+// every 16x16 tile then GATHERS its entries from its super-tile's candidate list, compacts them into LDS
+// and sorts them there (160 KB LDS/CU).  No per-tile global atomics, no unsorted key array in HBM.
 #include "gs_internal.h"
 
 namespace gs {
@@ -95,9 +97,9 @@ int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int ba
 }
 
 // ---------------------------------------------------------------------------------------------
-// scatter: one thread per (view, splat); entry k of splat i -> slot, tile segment position by atomic
+// coarse scatter: one thread per (view, splat); one candidate record per super-tile the splat touches
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_scatter(Dims d, Scratch s) {
+__global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
     const int i = blockIdx.x * WG + threadIdx.x;
     const int v = blockIdx.y;
     if (i >= d.P) return;
@@ -108,40 +110,78 @@ __global__ __launch_bounds__(WG) void k_scatter(Dims d, Scratch s) {
     const GeomRec* rec = s.geom + pv + i;
     const uint32_t rmin = rec->rect_min, rmax = rec->rect_max;
     const uint32_t depth = __float_as_uint(rec->depth);
-    uint32_t slot = s.point_offsets[pv + i] - tiles;
+    const uint32_t slot_base = s.point_offsets[pv + i] - tiles;
     const uint32_t total = s.point_offsets[pv + d.P - 1];
     if (total > d.Rcap) {  // arena too small for this view: flag it, the host grows and replays
-        if ((threadIdx.x & 63) == 0 || slot == 0) atomicOr(&s.flags[v * 4 + 0], 1u);
+        if ((threadIdx.x & 63) == 0 || slot_base == 0) atomicOr(&s.flags[v * 4 + 0], 1u);
         return;
     }
-    const uint32_t* tend = s.tile_end + (size_t)v * d.T;
-    const uint32_t* tcnt = s.tile_count + (size_t)v * d.T;
-    uint32_t* cur = s.tile_cursor + (size_t)v * d.T;
-    uint64_t* bins = s.bins + (size_t)v * d.Rcap;
-    uint32_t* ids = s.id_of_slot + (size_t)v * d.Rcap;
+    const size_t cg = (size_t)v * d.NST * CGROUPS + (blockIdx.x % CGROUPS);  // same group as in preprocess
+    const uint32_t* cend = s.coarse_end + cg;
+    const uint32_t* ccnt = s.coarse_count + cg;
+    uint32_t* cur = s.coarse_cursor + cg;
+    uint4* list = s.coarse_list + (size_t)v * d.Rcap;
+    uint32_t* dl = s.coarse_depth + (size_t)v * d.Rcap;
     const int x0 = rmin & 0xffff, y0 = rmin >> 16, x1 = rmax & 0xffff, y1 = rmax >> 16;
-    for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) {
-            const int tile = ty * d.gx + tx;
-            const uint32_t pos = atomicAdd(&cur[tile], 1u);
-            const uint32_t start = tend[tile] - tcnt[tile];
-            bins[start + pos] = ((uint64_t)depth << 32) | slot;
-            ids[slot] = (uint32_t)i;
-            slot++;
+    const int sx0 = x0 / STILE, sx1 = (x1 - 1) / STILE + 1, sy0 = y0 / STILE, sy1 = (y1 - 1) / STILE + 1;
+    for (int sy = sy0; sy < sy1; sy++)
+        for (int sx = sx0; sx < sx1; sx++) {
+            const int st = (sy * d.sgx + sx) * CGROUPS;
+            const uint32_t pos = cend[st] - ccnt[st] + atomicAdd(&cur[st], 1u);
+            list[pos] = make_uint4((uint32_t)i, rmin, rmax, slot_base);
+            dl[pos] = depth;
         }
 }
 
-int launch_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
+int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.P == 0 || d.V == 0) return GS_OK;
-    hipLaunchKernelGGL(k_scatter, dim3((d.P + WG - 1) / WG, d.V), dim3(WG), 0, st, d, s);
+    hipLaunchKernelGGL(k_coarse_scatter, dim3((d.P + WG - 1) / WG, d.V), dim3(WG), 0, st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-tile sort on the unique 64-bit key: counting-rank sort in LDS for n <= 512, bitonic sort in LDS for
-// n <= SORT_LDS_CAP, bitonic in global scratch (the not yet used gradient-slot buffer G) for longer lists —
-// the "tile-list spill path".
+// per-tile entry counts: one workgroup per super-tile walks its candidates once, LDS atomics only
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_tile_count(Dims d, Scratch s) {
+    __shared__ uint32_t cnt[STILE * STILE];
+    const int st = blockIdx.x, v = blockIdx.y;
+    const int stx = st % d.sgx, sty = st / d.sgx;
+    if (threadIdx.x < STILE * STILE) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (!(s.flags[v * 4 + 0] & 1u)) {
+        const size_t c0 = ((size_t)v * d.NST + st) * CGROUPS;  // the super-tile's CGROUPS sub-lists are contiguous
+        const uint32_t cstart = s.coarse_end[c0] - s.coarse_count[c0];
+        const uint32_t nc = s.coarse_end[c0 + CGROUPS - 1] - cstart;
+        const uint4* list = s.coarse_list + (size_t)v * d.Rcap + cstart;
+        const int tx0 = stx * STILE, ty0 = sty * STILE;
+        for (uint32_t c = threadIdx.x; c < nc; c += WG) {
+            const uint4 e = list[c];
+            const int x0 = max((int)(e.y & 0xffff), tx0), x1 = min((int)(e.z & 0xffff), tx0 + STILE);
+            const int y0 = max((int)(e.y >> 16), ty0), y1 = min((int)(e.z >> 16), ty0 + STILE);
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) atomicAdd(&cnt[(y - ty0) * STILE + (x - tx0)], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < STILE * STILE) {
+        const int tx = stx * STILE + (threadIdx.x % STILE), ty = sty * STILE + (threadIdx.x / STILE);
+        if (tx < d.gx && ty < d.gy) s.tile_count[(size_t)v * d.T + ty * d.gx + tx] = cnt[threadIdx.x];
+    }
+}
+
+int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st) {
+    if (d.NST == 0 || d.V == 0) return GS_OK;
+    hipLaunchKernelGGL(k_tile_count, dim3(d.NST, d.V), dim3(WG), 0, st, d, s);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-tile gather + sort on the unique 64-bit key: the tile's workgroup scans its super-tile's candidates,
+// compacts the overlapping ones into LDS, and sorts: counting-rank sort for n <= 512, bitonic in LDS for
+// n <= SORT_LDS_CAP, bitonic in global scratch (the not yet used gradient-row buffer G) beyond — the
+// "tile-list spill path".
 // ---------------------------------------------------------------------------------------------
 __device__ inline void bitonic_sort(uint64_t* a, uint32_t n2) {
     for (uint32_t k = 2; k <= n2; k <<= 1)
@@ -157,26 +197,51 @@ __device__ inline void bitonic_sort(uint64_t* a, uint32_t n2) {
         }
 }
 
-__global__ __launch_bounds__(WG) void k_tile_sort(Dims d, Scratch s) {
+constexpr uint32_t RANK_MAX = 512;
+
+__global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint64_t* sk = reinterpret_cast<uint64_t*>(smem_raw);
+    __shared__ uint32_t sid[RANK_MAX];
+    __shared__ uint32_t fill;
     const int tile = blockIdx.x, v = blockIdx.y;
     if (s.flags[v * 4 + 0] & 1u) return;  // overflowed view: nothing was scattered
     const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
     if (n == 0) return;
     const uint32_t start = s.tile_end[(size_t)v * d.T + tile] - n;
-    uint64_t* bins = s.bins + (size_t)v * d.Rcap + start;
-    const uint32_t* ids = s.id_of_slot + (size_t)v * d.Rcap;
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const int st = (ty / STILE) * d.sgx + (tx / STILE);
+    const size_t c0 = ((size_t)v * d.NST + st) * CGROUPS;
+    const uint32_t cstart = s.coarse_end[c0] - s.coarse_count[c0];
+    const uint32_t nc = s.coarse_end[c0 + CGROUPS - 1] - cstart;
+    const uint4* __restrict__ list = s.coarse_list + (size_t)v * d.Rcap + cstart;
+    const uint32_t* __restrict__ dlist = s.coarse_depth + (size_t)v * d.Rcap + cstart;
+    uint32_t* ids = s.id_of_slot + (size_t)v * d.Rcap;
     uint32_t* pl = s.point_list + (size_t)v * d.Rcap + start;
     uint32_t* sl = s.slot_list + (size_t)v * d.Rcap + start;
-    if (threadIdx.x == 0) atomicMax(&s.flags[v * 4 + 1], n);
-    constexpr uint32_t RANK_MAX = 512;
-    if (n <= RANK_MAX) {
-        // Short lists (the common case: a few hundred entries): counting-rank sort.  Keys are unique, so
-        // rank = #keys smaller is the final position; every thread ranks its key against the whole list with
-        // broadcast 16-byte LDS reads.  Two barriers in total instead of one per bitonic step.
+    if (threadIdx.x == 0) { atomicMax(&s.flags[v * 4 + 1], n); fill = 0; }
+    const bool by_rank = n <= RANK_MAX;
+    uint32_t n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    uint64_t* a = sk;
+    if (n > (uint32_t)SORT_LDS_CAP) a = reinterpret_cast<uint64_t*>(s.G + (size_t)v * d.Rcap * G_STRIDE) + 2 * (size_t)start;  // n2 < 2n
+    __syncthreads();
+    // gather: every candidate of the super-tile whose tile rectangle contains (tx, ty)
+    for (uint32_t c = threadIdx.x; c < nc; c += WG) {
+        const uint4 e = list[c];
+        const int x0 = e.y & 0xffff, y0 = e.y >> 16, x1 = e.z & 0xffff, y1 = e.z >> 16;
+        if (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) {
+            const uint32_t slot = e.w + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            const uint32_t pos = atomicAdd(&fill, 1u);  // order is irrelevant: the key is unique
+            a[pos] = ((uint64_t)dlist[c] << 32) | slot;
+            if (by_rank) sid[pos] = e.x; else ids[slot] = e.x;
+        }
+    }
+    if (by_rank) {
+        // counting-rank sort: rank = #keys smaller is the final position (keys are unique); every thread ranks its
+        // key against the whole list with broadcast 16-byte LDS reads — two barriers instead of one per bitonic step
         const uint32_t ne = (n + 1) & ~1u;
-        for (uint32_t t = threadIdx.x; t < ne; t += WG) sk[t] = t < n ? bins[t] : ~0ull;
+        if (threadIdx.x == 0 && ne != n) sk[n] = ~0ull;
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < n; t += WG) {
             const uint64_t mine = sk[t];
@@ -187,18 +252,12 @@ __global__ __launch_bounds__(WG) void k_tile_sort(Dims d, Scratch s) {
                 rank += (kk.x < mine) ? 1u : 0u;
                 rank += (kk.y < mine) ? 1u : 0u;
             }
-            const uint32_t slot = (uint32_t)mine;
-            sl[rank] = slot;
-            pl[rank] = ids[slot];
+            sl[rank] = (uint32_t)mine;
+            pl[rank] = sid[t];
         }
         return;
     }
-    uint32_t n2 = 2;
-    while (n2 < n) n2 <<= 1;
-    uint64_t* a;
-    if (n <= (uint32_t)SORT_LDS_CAP) a = sk;
-    else a = reinterpret_cast<uint64_t*>(s.G + (size_t)v * d.Rcap * G_STRIDE) + 2 * (size_t)start;  // n2 < 2n entries
-    for (uint32_t t = threadIdx.x; t < n2; t += WG) a[t] = t < n ? bins[t] : ~0ull;
+    for (uint32_t t = n + threadIdx.x; t < n2; t += WG) a[t] = ~0ull;
     __syncthreads();
     bitonic_sort(a, n2);
     for (uint32_t t = threadIdx.x; t < n; t += WG) {
@@ -208,9 +267,9 @@ __global__ __launch_bounds__(WG) void k_tile_sort(Dims d, Scratch s) {
     }
 }
 
-int launch_tile_sort(const Dims& d, const Scratch& s, hipStream_t st) {
+int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.T == 0 || d.V == 0) return GS_OK;
-    hipLaunchKernelGGL(k_tile_sort, dim3(d.T, d.V), dim3(WG), SORT_LDS_CAP * sizeof(uint64_t), st, d, s);
+    hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T, d.V), dim3(WG), SORT_LDS_CAP * sizeof(uint64_t), st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
