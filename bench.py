@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--collective", choices=["torch", "rccl"], default="torch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=2, help="views of the workload the CPU baseline leg times")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and the collective hook even with one rank (plumbing test)")
+    ap.add_argument("--views", type=int, default=0, help="diagnostic only: override the number of views per step (not the metric's config)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,12 +83,17 @@ def main():
         sys.exit(2)
 
     torch = dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     import gsplat_amd as gs
     from gsplat_amd import capi
@@ -94,6 +101,8 @@ def main():
     if L.gs_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libgsplat_mi355 has no CPU fallback")
     P, M, V_total, W, H = gs.synth.CONFIGS[args.config]
+    if args.views:
+        V_total = args.views
     D = gs.synth.sh_degree_for(M)
     n_cams = max(V_total // 2, 1)
     V_total = 2 * n_cams
@@ -127,14 +136,14 @@ def main():
     tr.shard(rank, world)
     proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM if args.update == "adam" else capi.GS_UPDATE_SGD_CLAMP)
     hook = None
-    if world > 1:
+    if use_dist:
         from gsplat_amd import dist as gsdist
         hook = gsdist.TorchAllReduce(tr) if args.collective == "torch" else gsdist.NativeRcclComm(tr, rank, world)
     setup_s = time.time() - t0
 
     def sync_all():
         tr.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -155,7 +164,7 @@ def main():
     capi.check(L.gs_trainer_stage_times(tr.handle, ms, launches))
     capi.check(L.gs_trainer_set_profiling(tr.handle, 0))
     st = tr.train(proj, densify=False, stats=True) if st is None else st
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
@@ -191,10 +200,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": WORKLOAD_TEXT[args.config], "splats": P, "sh_coeffs": M, "views_per_step": V_total,
+            "config": {"workload": WORKLOAD_TEXT[args.config] + (f" [DIAGNOSTIC: views overridden to {V_total}]" if args.views else ""), "splats": P, "sh_coeffs": M, "views_per_step": V_total,
                        "views_per_gpu": V_local, "width": W, "height": H, "update": args.update,
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
-                       "collective": (args.collective + " all-reduce of %d fp32" % ((12 + 3 * M) * P)) if world > 1 else "none",
+                       "collective": (args.collective + " all-reduce of %d fp32" % ((12 + 3 * M) * P)) if use_dist else "none",
                        "mean_num_rendered_per_view": R_mean, "max_tile_list": st.max_tile_list},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -209,7 +218,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(gs, s, cams, framesW, framesB, P, M, D, W, H, n_cams, args.cpu_views)
         print(json.dumps(out), flush=True)
     tr.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
