@@ -8,4 +8,5 @@ is missing or no GPU is visible.
 """
 from . import camera, capi, dist, synth  # noqa: F401
 from .model import ModelSplatsDevice, ModelSplatsHost  # noqa: F401
-from .trainer import Project, Trainer  # noqa: F401
+from .trainer import CameraSphere, Project, Trainer  # noqa: F401
+from . import driver, fields, io  # noqa: F401,E402

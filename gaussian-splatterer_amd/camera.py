@@ -88,6 +88,33 @@ def get_cameras(count, distance=10.0, fov_deg=60.0):
     return [Camera(p, (0, 0, 0), fov_deg) for p in fibonacci_sphere(count, distance)]
 
 
+def _angle_axis_mat3(angle_rad, axis):
+    """(glm::mat4)glm::angleAxis(angle, axis): quaternion (cos a/2, axis sin a/2) -> rotation matrix, row-major 3x3."""
+    a = F(angle_rad)
+    s, c = np.sin(a * F(0.5)), np.cos(a * F(0.5))
+    x, y, z = (F(axis[0]) * s, F(axis[1]) * s, F(axis[2]) * s)
+    w = c
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], F)
+
+
+def get_cameras_project(project):
+    """Camera::getCameras(project), src/Camera.cpp:33-58: two Fibonacci spheres, each rotated by
+    angleAxis(radians(rotX), +Y) * angleAxis(radians(rotY), +X); all cameras look at the origin."""
+    out = []
+    for sp in (project.sphere1, project.sphere2):
+        rot = (_angle_axis_mat3(math.radians(sp.rotX), (0, 1, 0)) @ _angle_axis_mat3(math.radians(sp.rotY), (1, 0, 0))).astype(F)
+        for p in fibonacci_sphere(sp.count, sp.distance):
+            out.append(Camera((rot @ p).astype(F), (0, 0, 0), sp.fovDeg))
+    return out
+
+
+def get_cameras_count(project):
+    """Camera::getCamerasCount, src/Camera.cpp:29-31."""
+    return project.sphere1.count + project.sphere2.count
+
+
 def view_block(cam, width, height, white):
     """The 40-float gs_view the reference computes per pass (src/Trainer.cu:317-326,355-356)."""
     v = np.zeros(VIEW_FLOATS, F)

@@ -1,0 +1,100 @@
+"""On-disk formats either side of the training path:
+  * `.gobj` — the reference's text splat format, UiFrame::saveSplats / loadSplats (src/ui/UiFrame.cpp:333-358,
+    :373-450): five lines per splat `v x y z`, `sh f0 f1 ...`, `s x y z`, `a opacity`, `r q0 q1 q2 q3`, floats at
+    the C++ ostream default (6 significant digits, %g) — lossy, like the reference.
+  * `settings.json` — Project via nlohmann's NLOHMANN_DEFINE_TYPE_INTRUSIVE_WITH_DEFAULT (src/Project.h:64-73):
+    keys are the member names, missing keys keep their defaults."""
+import dataclasses
+import json
+
+import numpy as np
+
+from .model import ModelSplatsHost
+from .trainer import CameraSphere, Project
+
+
+def _g(x):
+    return "%g" % float(np.float32(x))
+
+
+def saveSplats(path, model):
+    """UiFrame::saveSplats, src/ui/UiFrame.cpp:333-358.  `model` is a ModelSplatsHost (or anything with the same fields)."""
+    M = model.shCoeffs
+    with open(path, "w") as f:
+        for i in range(model.count):
+            f.write("v " + " ".join(_g(v) for v in model.locations[3 * i:3 * i + 3]) + "\n")
+            f.write("sh" + "".join(" " + _g(v) for v in model.shs[3 * M * i:3 * M * (i + 1)]) + "\n")
+            f.write("s " + " ".join(_g(v) for v in model.scales[3 * i:3 * i + 3]) + "\n")
+            f.write("a " + _g(model.opacities[i]) + "\n")
+            f.write("r " + " ".join(_g(v) for v in model.rotations[4 * i:4 * i + 4]) + "\n")
+
+
+def loadSplats(path):
+    """UiFrame::loadSplats, src/ui/UiFrame.cpp:373-450 -> ModelSplatsHost (five-vector constructor semantics:
+    capacity 1e6 grown x10, shDegree = (M-1)/3; inconsistent SH counts raise "Inconsistent SH degree!")."""
+    loc, shs, sc, op, rot = [], [], [], [], []
+    sh_coeffs = None
+    with open(path) as f:
+        for line in f:
+            parts = line.split()
+            if not parts:
+                continue
+            p, vals = parts[0], parts[1:]
+            if p == "v":
+                loc += [float(x) for x in vals[:3]]
+            elif p == "sh":
+                got = []
+                for x in vals:           # `while (iss >> x)`: stops at the first token that is not a number
+                    try:
+                        got.append(float(x))
+                    except ValueError:
+                        break
+                shs += got
+                if sh_coeffs is None:
+                    sh_coeffs = len(got)
+                elif sh_coeffs != len(got):
+                    raise RuntimeError("Inconsistent SH degree!")
+            elif p == "s":
+                sc += [float(x) for x in vals[:3]]
+            elif p == "a":
+                op.append(float(vals[0]))
+            elif p == "r":
+                rot += [float(x) for x in vals[:4]]
+    return ModelSplatsHost.fromVectors(loc, shs, sc, op, rot)
+
+
+_SERIALISED = ["perspective", "pathModel", "pathTextureDiffuse", "sphere1", "sphere2", "rtSamples", "lrLocation", "lrSh", "lrScale",
+               "lrOpacity", "lrRotation", "paramScaleMax", "paramCullOpacity", "paramCullSize", "paramDensifyVariance",
+               "paramSplitSize", "paramSplitDistance", "paramSplitScale", "paramCloneDistance", "iterations", "intervalCapture",
+               "intervalDensify", "previewTimer", "previewRtSamples", "previewSplatScale", "previewTruth", "previewTruthIndex",
+               "previewFreeOrbit", "previewFreeOrbitSpeed", "previewFreeDistance", "previewFreeFovDeg", "previewFreeRotX",
+               "previewFreeRotY", "renderResX", "renderResY"]   # src/Project.h:64-73, in order
+
+
+def saveSettings(path, project):
+    """UiFrame::saveSettings, src/ui/UiFrame.cpp:323-331."""
+    j = {}
+    for k in _SERIALISED:
+        v = getattr(project, k)
+        j[k] = dataclasses.asdict(v) if isinstance(v, CameraSphere) else v
+    with open(path, "w") as f:
+        json.dump(j, f)
+
+
+def loadSettings(path, project=None):
+    """UiFrame::loadSettings, src/ui/UiFrame.cpp:360-371: from_json WITH_DEFAULT — keys absent from the file keep defaults."""
+    project = project or Project()
+    with open(path) as f:
+        j = json.load(f)
+    for k in _SERIALISED:
+        if k not in j:
+            continue
+        if k in ("sphere1", "sphere2"):
+            sp = CameraSphere()
+            for kk, vv in j[k].items():
+                if hasattr(sp, kk):
+                    setattr(sp, kk, vv)
+            setattr(project, k, sp)
+        else:
+            setattr(project, k, j[k])
+    return project

@@ -3,7 +3,7 @@ src/Project.h:24-45 over the C-ABI.  Same public surface: .model, .truthFrameBuf
 .truthCameras, render(), train(project, densify); captureTruths() takes the truth images as input
 because the reference's OptiX renderer is out of scope."""
 import ctypes as C
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import numpy as np
 
@@ -13,8 +13,24 @@ from .model import ModelSplatsDevice, ModelSplatsHost
 
 
 @dataclass
+class CameraSphere:
+    """Project::CameraSphere, src/Project.h:14-22."""
+    count: int = 16
+    distance: float = 10.0
+    fovDeg: float = 60.0
+    rotX: float = 0.0
+    rotY: float = 0.0
+
+
+@dataclass
 class Project:
-    """src/Project.h:24-45 (the fields the training path reads)."""
+    """src/Project.h:6-75: every serialised field, same names and defaults (JSON keys = member names)."""
+    perspective: str = ""
+    pathModel: str = ""
+    pathTextureDiffuse: str = ""
+    sphere1: CameraSphere = field(default_factory=CameraSphere)
+    sphere2: CameraSphere = field(default_factory=CameraSphere)
+    rtSamples: int = 100
     lrLocation: float = 0.00005
     lrSh: float = 0.0001
     lrScale: float = 0.00002
@@ -31,12 +47,33 @@ class Project:
     iterations: int = 0
     intervalCapture: int = 50
     intervalDensify: int = 200
-    # build-side extensions: update rule and Adam constants
+    previewTimer: float = 0.0
+    previewRtSamples: int = 50
+    previewSplatScale: float = 1.0
+    previewTruth: bool = False
+    previewTruthIndex: int = 0
+    previewFreeOrbit: bool = True
+    previewFreeOrbitSpeed: float = 0.5
+    previewFreeDistance: float = 10.0
+    previewFreeFovDeg: float = 60.0
+    previewFreeRotX: float = 25.0
+    previewFreeRotY: float = 0.0
+    renderResX: int = 2048
+    renderResY: int = 2048
+    # build-side extensions, NOT serialised: update rule and Adam constants
     updateRule: int = capi.GS_UPDATE_SGD_CLAMP
     adamBeta1: float = 0.9
     adamBeta2: float = 0.999
     adamEps: float = 1e-15
     quatLayout: int = capi.GS_QUAT_XYZW
+
+    @classmethod
+    def initProject(cls):
+        """UiFrame::initProject, src/ui/UiFrame.cpp:129-134: a fresh project has an empty second sphere."""
+        p = cls()
+        p.sphere2.count = 0
+        p.sphere2.fovDeg = 30.0
+        return p
 
     def hyper(self):
         h = capi.gs_hyper()

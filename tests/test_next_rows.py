@@ -1,0 +1,128 @@
+"""CPU tests of the rows either side of the training path: field initialisers (N3,
+src/ui/UiFrame.cpp:137-264), the .gobj / settings.json formats (N2, :323-450), the two-sphere camera
+rig (src/Camera.cpp:33-58) and the auto-train driver loop (N4, :266-298)."""
+import json
+import math
+
+import numpy as np
+import pytest
+
+import gsplat_amd as gs
+
+
+def test_field_grid_and_mono():
+    h = gs.fields.initFieldGrid()
+    assert (h.count, h.capacity, h.shDegree, h.shCoeffs) == (17 ** 3, 1000000, 1, 4)
+    loc = h.locations[:3 * h.count].reshape(-1, 3)
+    assert loc.min() == -4 and loc.max() == 4 and np.array_equal(loc[1], [-4, -4, -3.5])       # z fastest, step 0.5
+    assert np.all(h.scales[:3 * h.count] == np.float32(0.5) * np.float32(0.1)) and np.all(h.opacities[:h.count] == 1)
+    assert not h.shs[:12 * h.count].any()
+    assert np.array_equal(h.rotations[:4], [0, 0, 0, 1])                                        # glm::quat memory {x,y,z,w}
+    assert np.array_equal(gs.fields.initFieldGrid(quat_xyzw=False).rotations[:4], [1, 0, 0, 0])
+    m = gs.fields.initFieldMono()
+    assert m.count == 1 and np.allclose(m.scales[:3], 0.3) and not m.locations[:3].any()
+
+
+def test_field_from_obj_triangles():
+    obj = "v 0 0 0\nv 2 0 0\nv 2 0 -2\nv 0 0 -2\nvt 0.5 0.5\nf 1/1/1 2/1/1 3/1/1 4/1/1\n# comment\nf 1 2 3\n"
+    verts, tris = gs.fields.parse_obj_triangles(obj)
+    assert tris == [(0, 1, 2), (0, 2, 3), (0, 1, 2)]                       # quad fanned, then the triangle
+    h = gs.fields.initFieldModel(obj)
+    assert h.count == 3
+    assert np.allclose(h.locations[:3], [4 / 3, 0, -2 / 3])
+    assert np.allclose(h.scales[:3], [0.2 * 2.0, 0.2 * math.sqrt(8.0), 0.2 * 0.005])
+    # normal of (v1-v0) x (v2-v0) = (2,0,0) x (2,0,-2) = (0,4,0) -> +Y; rotate +Z onto +Y: axis (-1,0,0)*1, angle 90 deg
+    s = math.sin(math.pi / 4)
+    assert np.allclose(h.rotations[:4], [-s, 0, 0, s], atol=1e-6)
+    with pytest.raises(RuntimeError, match="Unexpected vertex count"):
+        gs.fields.parse_obj_triangles("v 0 0 0\nf 1 1 1 1 1\n")
+
+
+def test_gobj_round_trip(tmp_path):
+    s = gs.synth.random_splats(50, 4, 3)
+    h = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    path = tmp_path / "m.gobj"
+    gs.io.saveSplats(path, h)
+    lines = open(path).read().splitlines()
+    assert len(lines) == 5 * 50 and lines[0].startswith("v ") and lines[1].startswith("sh ") and lines[4].startswith("r ")
+    assert lines[0] == "v " + " ".join("%g" % float(v) for v in s["loc"][:3])   # ostream default: 6 significant digits
+    back = gs.io.loadSplats(path)
+    assert (back.count, back.shCoeffs, back.shDegree, back.capacity) == (50, 4, 1, 1000000)
+    for a, b, n in [(back.locations, s["loc"], 150), (back.shs, s["sh"], 600), (back.scales, s["scale"], 150),
+                    (back.opacities, s["opac"], 50), (back.rotations, s["rot"], 200)]:
+        assert np.allclose(a[:n], b, rtol=1e-5, atol=1e-7)                       # lossy by design
+    bad = tmp_path / "bad.gobj"
+    bad.write_text("v 0 0 0\nsh 1 2 3\ns 1 1 1\na 1\nr 1 0 0 0\nv 0 0 0\nsh 1 2 3 4 5 6\ns 1 1 1\na 1\nr 1 0 0 0\n")
+    with pytest.raises(RuntimeError, match="Inconsistent SH degree"):
+        gs.io.loadSplats(bad)
+
+
+def test_settings_json_round_trip(tmp_path):
+    p = gs.Project.initProject()
+    assert p.sphere2.count == 0 and p.sphere2.fovDeg == 30.0 and p.sphere1.count == 16
+    p.lrSh, p.iterations, p.sphere1.rotX, p.pathModel = 0.1, 3491, 123.0, "C:/models/a.obj"
+    path = tmp_path / "settings.json"
+    gs.io.saveSettings(path, p)
+    j = json.load(open(path))
+    assert j["sphere1"] == {"count": 16, "distance": 10.0, "fovDeg": 60.0, "rotX": 123.0, "rotY": 0.0}
+    assert "updateRule" not in j and j["intervalDensify"] == 200 and len(j) == 35
+    q = gs.io.loadSettings(path)
+    assert q.lrSh == 0.1 and q.iterations == 3491 and q.sphere1.rotX == 123.0 and q.sphere2.count == 0 and q.pathModel == p.pathModel
+    path.write_text('{"lrScale": 0.5, "sphere2": {"count": 3}}')               # WITH_DEFAULT: missing keys keep defaults
+    r = gs.io.loadSettings(path)
+    assert r.lrScale == 0.5 and r.sphere2.count == 3 and r.sphere2.distance == 10.0 and r.lrSh == pytest.approx(0.0001)
+
+
+def test_two_sphere_camera_rig():
+    p = gs.Project.initProject()
+    p.sphere1.count, p.sphere2.count, p.sphere2.distance = 8, 4, 5.0
+    cams = gs.camera.get_cameras_project(p)
+    assert len(cams) == gs.camera.get_cameras_count(p) == 12
+    assert np.allclose([np.linalg.norm(c.location) for c in cams[:8]], 10.0, atol=1e-4)
+    assert np.allclose([np.linalg.norm(c.location) for c in cams[8:]], 5.0, atol=1e-4) and cams[8].fovDegY == 30.0
+    base = np.array([c.location for c in cams[:8]])
+    assert np.allclose(base, gs.camera.fibonacci_sphere(8, 10.0), atol=1e-5)  # rot 0 = identity
+    p.sphere1.rotX = 90.0                                                      # rotX turns about +Y (src/Camera.cpp:40)
+    rot = np.array([c.location for c in gs.camera.get_cameras_project(p)[:8]])
+    assert np.allclose(rot[:, 1], base[:, 1], atol=1e-4)
+    assert np.allclose(rot[:, 0], base[:, 2], atol=1e-4) and np.allclose(rot[:, 2], -base[:, 0], atol=1e-4)
+
+
+class _FakeTrainer:
+    def __init__(self):
+        self.calls = []
+
+    def captureTruths(self, cameras, fw, fb):
+        self.calls.append(("capture", len(cameras)))
+
+    def train(self, project, densify):
+        project.iterations += 1
+        self.calls.append(("train", bool(densify)))
+
+
+def test_auto_train_driver_loop():
+    p = gs.Project.initProject()
+    p.sphere1.count, p.intervalCapture, p.intervalDensify = 3, 4, 6
+    tr = _FakeTrainer()
+    now = [0.0]
+    drv = gs.driver.AutoTrainer(tr, p, capture=lambda cams: ([None] * len(cams), [None] * len(cams)), clock=lambda: now[0])
+    ran = 0
+    for tick in range(400):                      # host idle events 12.5 ms apart: budget 100 steps/s -> one step per tick
+        now[0] += 0.0125
+        ran += drv.update()
+    assert ran == 400 and p.iterations == 400
+    trains = [c for c in tr.calls if c[0] == "train"]
+    assert [i for i, c in enumerate(trains) if c[1]] == list(range(0, 400, 6))           # densify when iterations % 6 == 0 (incl. 0)
+    assert sum(1 for c in tr.calls if c[0] == "capture") == 100 and tr.calls[0] == ("capture", 3)
+    assert 0 <= p.sphere1.rotX < 360 and p.sphere1.rotX != 0.0                           # spheres re-rotated before each capture
+    # throttle: events 1 ms apart only accumulate 0.1 budget each -> one step per 10 events
+    tr2, p2 = _FakeTrainer(), gs.Project.initProject()
+    drv2 = gs.driver.AutoTrainer(tr2, p2, capture=lambda cams: ([None] * len(cams), [None] * len(cams)), clock=lambda: now[0])
+    ran = 0
+    for tick in range(1000):
+        now[0] += 0.001
+        ran += drv2.update()
+    assert 95 <= ran <= 100
+    drv2.autoTraining = False
+    now[0] += 1.0
+    assert drv2.update() is False
