@@ -33,7 +33,7 @@ def test_auto_train_on_grid_field(tmp_path):
     assert [f[1] for f in flags] == [True, False, False, False, True, False]
     assert p.iterations == 6 and len(tr.truthCameras) == 3 and len(tr.truthFrameBuffersW) == 3
     n = tr.model.count
-    assert 0 < n <= 4913
+    assert 0 < n <= 1000000 and n != 4913   # densify at iterations 0 and 4 re-indexed the model (clones, splits, prunes)
     host = gs.ModelSplatsHost.fromDevice(tr.model)
     assert np.isfinite(host.locations[:3 * n]).all() and np.isfinite(host.shs[:12 * n]).all()
     gs.io.saveSplats(tmp_path / "out.gobj", host)
