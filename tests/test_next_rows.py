@@ -126,3 +126,20 @@ def test_auto_train_driver_loop():
     drv2.autoTraining = False
     now[0] += 1.0
     assert drv2.update() is False
+
+
+def test_cpp_extras_header_and_gobj_interop(tmp_path):
+    """include/gsplat_extras.hpp (C++): grid field + .gobj writer/reader; the file it writes is read by the Python mirror."""
+    import os
+    import subprocess
+    from gsplat_amd import capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "extras_cpu"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "extras_cpu.cpp"),
+                           "-o", str(exe), capi.LIB_PATH, "-Wl,-rpath," + os.path.dirname(capi.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    path = tmp_path / "grid.gobj"
+    out = subprocess.run([str(exe), str(path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "extras ok" in out.stdout, (out.returncode, out.stderr)
+    h = gs.io.loadSplats(path)
+    ref = gs.fields.initFieldGrid()
+    assert h.count == 40 and np.allclose(h.locations[:120], ref.locations[:120]) and np.allclose(h.rotations[:160], ref.rotations[:160])
