@@ -216,6 +216,45 @@ __device__ inline float wave_reduce_scatter9(float g0, float g1, float g2, float
     return t0;
 }
 
+// Form used by the backward kernel: stages A-D and the g8 merge only — on return every 16-lane ROW holds its own
+// row totals (lane 2q: value q, lane 1: value 8).  The caller folds the four rows lane-wise with two
+// ds_bpermute_b32 (the LDS crossbar, no VALU issue slot): v_permlane16/32_swap cost 8.2 cycles each on gfx950
+// (tools/valu_rate.hip) and needed a v_mov and wait states apiece.
+__device__ inline float wave_reduce_scatter9_rows(float g0, float g1, float g2, float g3, float g4, float g5, float g6, float g7,
+                                                  float g8) {
+    float t0, t1;
+    const unsigned long long mask_bit1 = 0xCCCCCCCCCCCCCCCCull;  // lanes with bit 1 set
+    const unsigned long long mask_lane1 = 0x0002000200020002ull;  // lane % 16 == 1
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_cndmask_b32_e64 %9, %0, %1, %11\n\t"
+        "v_cndmask_b32_e64 %10, %1, %0, %11\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %9, %10, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %9, %9, %8, %12\n\t"
+        : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7), "+v"(g8), "=&v"(t0), "=&v"(t1)
+        : "s"(mask_bit1), "s"(mask_lane1));
+    return t0;
+}
+
 // debug entry: one wave, in[q][lane] -> out[lane] = wave_reduce_scatter9(...) (tests/test_gpu_raster.py)
 __global__ void k_debug_reduce9(const float* __restrict__ in, float* __restrict__ out) {
     const int l = threadIdx.x;
@@ -302,14 +341,13 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
     }
 
     float T = T_final;
-    float ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f;  // accum_rec
-    float lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;  // last_color
-    float last_alpha = 0.0f;
+    float ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f;  // accum_rec, already blended with the previously visited entry
     const float tfbg = -T_final * (bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2);
     const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
     // where this lane parks a reduced value: lane 2q -> q, lane 1 -> 8 (row 0 only)
     const bool writer = lane < 16 && (((lane & 1) == 0) || lane == 1);
     const int wslot = (lane & 1) ? 8 : (lane >> 1);
+    const int fold16 = (lane ^ 16) << 2, fold32 = (lane ^ 32) << 2;  // ds_bpermute byte addresses of the row partners
 
     for (int r = rounds - 1; r >= 0; r--) {
         const int base = r * BWD_ROUND;
@@ -338,6 +376,7 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
                 const int jj = sub + kk;
                 const float4 Ac = st.A[jj], Bc = st.B[jj];
                 const float cbc = st.C[jj].x;
+                asm volatile("" ::"v"(Bc.z), "v"(Bc.w), "v"(cbc));  // issue all three LDS reads up front, not inside the branch
                 const uint32_t pos = (uint32_t)(base + jj);  // upstream's `contributor` after its decrement
                 const float dx = Ac.x - pxf, dy = Ac.y - pyf;
                 const float power = -0.5f * (Ac.z * dx * dx + Bc.x * dy * dy) - Ac.w * dx * dy;
@@ -348,23 +387,28 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
                 // that are constant per splat (opacity, conic, 0.5*W, -0.5) are applied once per entry in the flush.
                 float dchannel_dcolor = 0.0f, u = 0.0f;
                 if (act) {
-                    const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    const float keep = 1.0f - alpha;
+                    const float inv1ma = __builtin_amdgcn_rcpf(keep);
                     T = T * inv1ma;
                     dchannel_dcolor = alpha * T;
-                    const float keep = 1.0f - last_alpha;
-                    float dL_dalpha;
-                    ar0 = last_alpha * lc0 + keep * ar0; lc0 = Bc.z; dL_dalpha = (Bc.z - ar0) * dpx0;
-                    ar1 = last_alpha * lc1 + keep * ar1; lc1 = Bc.w; dL_dalpha += (Bc.w - ar1) * dpx1;
-                    ar2 = last_alpha * lc2 + keep * ar2; lc2 = cbc; dL_dalpha += (cbc - ar2) * dpx2;
+                    // upstream blends (last_alpha, last_color) into accum_rec BEFORE using it; doing the same blend with
+                    // this entry's (alpha, colour) AFTER use is the identical recurrence one step early
+                    float dL_dalpha = (Bc.z - ar0) * dpx0;
+                    dL_dalpha += (Bc.w - ar1) * dpx1;
+                    dL_dalpha += (cbc - ar2) * dpx2;
+                    ar0 = alpha * Bc.z + keep * ar0;
+                    ar1 = alpha * Bc.w + keep * ar1;
+                    ar2 = alpha * cbc + keep * ar2;
                     dL_dalpha = dL_dalpha * T + tfbg * inv1ma;   // tfbg = -T_final * (bg . dL_dpix)
-                    last_alpha = alpha;
                     u = G * dL_dalpha;
                 }
                 if (__ballot(act) != 0ull) {
                     // inactive lanes contribute exact zeros: dchannel_dcolor = u = 0 there
                     const float ux = u * dx, uy = u * dy;
-                    const float red = wave_reduce_scatter9(dchannel_dcolor * dpx0, dchannel_dcolor * dpx1, dchannel_dcolor * dpx2, ux, uy,
-                                                           ux * dx, ux * dy, uy * dy, u);
+                    float red = wave_reduce_scatter9_rows(dchannel_dcolor * dpx0, dchannel_dcolor * dpx1, dchannel_dcolor * dpx2, ux, uy,
+                                                          ux * dx, ux * dy, uy * dy, u);
+                    red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold16, __builtin_bit_cast(int, red)));
+                    red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold32, __builtin_bit_cast(int, red)));
                     if (writer) sAcc[(wave * BWD_ROUND + jj) * ACC_STRIDE + wslot] = red;
                     touched[sb] |= 1ull << kk;
                 }
@@ -380,7 +424,7 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
 #pragma unroll
             for (int q = 0; q < ACC_STRIDE; q++) sum[q] = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
+            for (int w = 0; w < 4; w++) {  // fixed order over the four waves; only slots written this round are read
                 if ((sTouched[w][tid >> 6] >> (tid & 63)) & 1ull) {
                     const float* a = &sAcc[(w * BWD_ROUND + tid) * ACC_STRIDE];
 #pragma unroll

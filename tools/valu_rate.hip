@@ -52,6 +52,12 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
             a0 += (float)(s0 + s1 + s2);
         } else if (KIND == 9) {  // v_cmp (VOPC -> vcc) + v_cndmask vcc (VOP2)
             REP16(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_lt_f32 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");)
+        } else if (KIND == 11) {  // v_permlane32_swap (both operands read-write)
+            REP16(asm volatile("v_permlane32_swap_b32_e32 %0, %1\n v_permlane32_swap_b32_e32 %2, %3\n v_permlane32_swap_b32_e32 %0, %2\n v_permlane32_swap_b32_e32 %1, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == 12) {  // v_permlane16_swap
+            REP16(asm volatile("v_permlane16_swap_b32_e32 %0, %1\n v_permlane16_swap_b32_e32 %2, %3\n v_permlane16_swap_b32_e32 %0, %2\n v_permlane16_swap_b32_e32 %1, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == 13) {  // swap + dependent add (the reduce-scatter step)
+            REP16(asm volatile("v_permlane32_swap_b32_e32 %0, %1\n v_add_f32 %0, %0, %1\n v_permlane32_swap_b32_e32 %2, %3\n v_add_f32 %2, %2, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
         } else if (KIND == 10) {  // ds_read_b128 broadcast (uniform address)
             __shared__ float4 sm[256];
             if (i == 0) sm[threadIdx.x] = make_float4(a0, a1, a2, a3);
@@ -97,6 +103,9 @@ int main() {
         run<7>("1 VALU : 1 SALU (counts both)", 128, w);
         run<8>("1 VALU : 3 SALU (counts all)", 64, w);
         run<9>("v_cmp+v_cndmask vcc", 64, w);
+        run<11>("v_permlane32_swap", 64, w);
+        run<12>("v_permlane16_swap", 64, w);
+        run<13>("swap32 + dependent add", 64, w);
     }
     return 0;
 }
