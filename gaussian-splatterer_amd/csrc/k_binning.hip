@@ -179,9 +179,8 @@ int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // per-tile gather + sort on the unique 64-bit key: the tile's workgroup scans its super-tile's candidates,
-// compacts the overlapping ones into LDS, and sorts: counting-rank sort for n <= 512, bitonic in LDS for
-// n <= SORT_LDS_CAP, bitonic in global scratch (the not yet used gradient-row buffer G) beyond — the
-// "tile-list spill path".
+// compacts the overlapping ones into LDS, and sorts: counting-rank sort for n <= SORT_LDS_CAP (2048), bitonic in
+// global scratch (the not yet used gradient-row buffer G) beyond — the "tile-list spill path".
 // ---------------------------------------------------------------------------------------------
 __device__ inline void bitonic_sort(uint64_t* a, uint32_t n2) {
     for (uint32_t k = 2; k <= n2; k <<= 1)
@@ -197,7 +196,7 @@ __device__ inline void bitonic_sort(uint64_t* a, uint32_t n2) {
         }
 }
 
-constexpr uint32_t RANK_MAX = 512;
+constexpr uint32_t RANK_MAX = SORT_LDS_CAP;  // every list that fits LDS is rank-sorted (measured faster than LDS bitonic up to 2048)
 
 __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -226,34 +225,105 @@ __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
     uint64_t* a = sk;
     if (n > (uint32_t)SORT_LDS_CAP) a = reinterpret_cast<uint64_t*>(s.G + (size_t)v * d.Rcap * G_STRIDE) + 2 * (size_t)start;  // n2 < 2n
     __syncthreads();
-    // gather: every candidate of the super-tile whose tile rectangle contains (tx, ty)
-    for (uint32_t c = threadIdx.x; c < nc; c += WG) {
-        const uint4 e = list[c];
-        const int x0 = e.y & 0xffff, y0 = e.y >> 16, x1 = e.z & 0xffff, y1 = e.z >> 16;
-        if (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) {
-            const uint32_t slot = e.w + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-            const uint32_t pos = atomicAdd(&fill, 1u);  // order is irrelevant: the key is unique
-            a[pos] = ((uint64_t)dlist[c] << 32) | slot;
-            if (by_rank) sid[pos] = e.x; else ids[slot] = e.x;
+    // gather: every candidate of the super-tile whose tile rectangle contains (tx, ty).  Four independent
+    // candidate loads per thread are in flight at once (the scan is latency-bound: ~600 candidates per tile).
+    for (uint32_t c0 = threadIdx.x; c0 < nc; c0 += 4 * WG) {
+        uint4 e[4];
+        uint32_t dz[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t c = c0 + k * WG;
+            e[k] = c < nc ? list[c] : make_uint4(0, 0, 0, 0);  // empty rectangle: never a hit
+            dz[k] = c < nc ? dlist[c] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x0 = e[k].y & 0xffff, y0 = e[k].y >> 16, x1 = e[k].z & 0xffff, y1 = e[k].z >> 16;
+            if (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) {
+                const uint32_t slot = e[k].w + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+                const uint32_t pos = atomicAdd(&fill, 1u);  // order is irrelevant: the key is unique
+                a[pos] = ((uint64_t)dz[k] << 32) | slot;
+                if (by_rank) sid[pos] = e[k].x; else ids[slot] = e[k].x;
+            }
         }
     }
     if (by_rank) {
-        // counting-rank sort: rank = #keys smaller is the final position (keys are unique); every thread ranks its
-        // key against the whole list with broadcast 16-byte LDS reads — two barriers instead of one per bitonic step
-        const uint32_t ne = (n + 1) & ~1u;
-        if (threadIdx.x == 0 && ne != n) sk[n] = ~0ull;
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < n; t += WG) {
-            const uint64_t mine = sk[t];
-            uint32_t rank = 0;
-            const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(sk);
-            for (uint32_t j = 0; j < ne / 2; j++) {
-                const ulonglong2 kk = pairs[j];
-                rank += (kk.x < mine) ? 1u : 0u;
-                rank += (kk.y < mine) ? 1u : 0u;
+        constexpr uint32_t NB = 64, KPT = SORT_LDS_CAP / WG;  // depth buckets; keys per thread
+        if (n <= 128) {
+            // counting-rank sort: rank = #keys smaller is the final position (keys are unique); every thread ranks its
+            // key against the whole list with broadcast 16-byte LDS reads
+            const uint32_t ne = (n + 1) & ~1u;
+            if (threadIdx.x == 0 && ne != n) sk[n] = ~0ull;
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < n; t += WG) {
+                const uint64_t mine = sk[t];
+                uint32_t rank = 0;
+                const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(sk);
+                for (uint32_t j = 0; j < ne / 2; j++) {
+                    const ulonglong2 kk = pairs[j];
+                    rank += (kk.x < mine) ? 1u : 0u;
+                    rank += (kk.y < mine) ? 1u : 0u;
+                }
+                sl[rank] = (uint32_t)mine;
+                pl[rank] = sid[t];
             }
-            sl[rank] = (uint32_t)mine;
-            pl[rank] = sid[t];
+            return;
+        }
+        // Longer lists: bucket by depth first (a monotone map of the depth bits onto NB buckets), then rank inside the
+        // bucket — n*n/NB comparisons instead of n*n.  Skewed depth distributions only cost speed, never order.
+        __shared__ uint32_t dmin, dmax, bcount[NB], bstart[NB + 1];
+        uint64_t key[KPT];
+        uint32_t id[KPT], bk[KPT], bp[KPT];
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        if (threadIdx.x == 0) { dmin = 0xFFFFFFFFu; dmax = 0u; }
+        if (threadIdx.x < NB) bcount[threadIdx.x] = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < KPT; k++) {
+            const uint32_t t = threadIdx.x + k * WG;
+            key[k] = t < n ? sk[t] : 0ull;
+            id[k] = t < n ? sid[t] : 0u;
+            if (t < n) { const uint32_t dz = (uint32_t)(key[k] >> 32); lo = min(lo, dz); hi = max(hi, dz); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { atomicMin(&dmin, lo); atomicMax(&dmax, hi); }
+        __syncthreads();
+        const uint32_t base = dmin;
+        const float scale = (float)NB / ((float)(dmax - base) + 1.0f);
+#pragma unroll
+        for (uint32_t k = 0; k < KPT; k++) {
+            const uint32_t t = threadIdx.x + k * WG;
+            if (t < n) {
+                bk[k] = min(NB - 1, (uint32_t)((float)((uint32_t)(key[k] >> 32) - base) * scale));
+                bp[k] = atomicAdd(&bcount[bk[k]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // exclusive scan of the NB = 64 bucket counts by one wave
+            const uint32_t c = bcount[threadIdx.x];
+            const uint32_t inc = wave_incl_scan(c);
+            bstart[threadIdx.x] = inc - c;
+            if (threadIdx.x == 63) bstart[NB] = inc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < KPT; k++) {
+            const uint32_t t = threadIdx.x + k * WG;
+            if (t < n) sk[bstart[bk[k]] + bp[k]] = key[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < KPT; k++) {
+            const uint32_t t = threadIdx.x + k * WG;
+            if (t < n) {
+                const uint32_t b0 = bstart[bk[k]], b1 = bstart[bk[k] + 1];
+                uint32_t rank = b0;
+                for (uint32_t j = b0; j < b1; j++) rank += (sk[j] < key[k]) ? 1u : 0u;
+                sl[rank] = (uint32_t)key[k];
+                pl[rank] = id[k];
+            }
         }
         return;
     }

@@ -158,7 +158,7 @@ def test_empty_and_all_culled(orc):
 
 
 def test_long_tile_lists_take_the_spill_path(orc):
-    """> 4096 entries in one tile: the sort leaves LDS for the global scratch path; lists stay bit-exact."""
+    """> 2048 entries in one tile: the sort leaves LDS for the global scratch path; lists stay bit-exact."""
     P, M, D, W, H = 6000, 1, 0, 32, 32
     s = util.gs.synth.random_splats(P, M, 99)
     s["loc"] = (s["loc"] * 0.05).astype(np.float32)  # everything projects into the same few tiles
