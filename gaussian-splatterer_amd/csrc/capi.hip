@@ -23,6 +23,8 @@ void set_error(const char* fmt, ...) {
 
 static int g_opt_cull = 1;
 int option_cull() { return g_opt_cull; }
+static int g_opt_share = 1;
+int option_share_passes() { return g_opt_share; }
 
 // grow-only device buffer
 struct DevBuf {
@@ -51,18 +53,55 @@ static int effective_degree(int sh_degree, int M, int* D_out) {
     return GS_OK;
 }
 
-static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t Rcap, float mod) {
+static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t Rcap, float mod, int VG = -1) {
     Dims d;
     d.P = P; d.Pa = Pa; d.D = D; d.M = M; d.W = W; d.H = H; d.N = W * H;
     d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
     d.sgx = (d.gx + STILE - 1) / STILE; d.sgy = (d.gy + STILE - 1) / STILE; d.NST = d.sgx * d.sgy;
-    d.V = V; d.Rcap = Rcap; d.mod = mod; d.cull = g_opt_cull;
+    d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = g_opt_cull;
     return d;
 }
 
 // Per-view scratch owned by the library (trainer / preview).  One allocation per array family,
 // grow-only, sized for V views at once: with 288 GB of HBM every view of a step keeps its own
 // state and each stage is ONE launch over all views.
+// One device block carries everything that describes the passes of a step: the per-pass view structs, the camera
+// of every geometry group, and the pass <-> group maps.  One host-to-device copy per step.
+static size_t view_block_bytes(int V) { return (size_t)V * 2 * sizeof(gs_view) + ((size_t)3 * V + 1) * sizeof(int); }
+static void set_view_block_pointers(Scratch& s, char* base, int V) {
+    s.views = reinterpret_cast<const gs_view*>(base);
+    s.gviews = s.views + V;
+    const int* m = reinterpret_cast<const int*>(s.gviews + V);
+    s.view_group = m; s.group_first = m + V; s.group_views = m + 2 * V + 1;
+}
+// Groups the passes by bit-identical camera (view, projview, campos, tan_fov*): the reference runs a white- and a
+// black-background pass per camera (src/Trainer.cu:311-318) whose projection, tile lists and blend are identical.
+static int build_view_block(const gs_view* views, int V, bool share, std::vector<char>& out) {
+    out.assign(view_block_bytes(V), 0);
+    gs_view* pv = reinterpret_cast<gs_view*>(out.data());
+    gs_view* gv = pv + V;
+    int* vg = reinterpret_cast<int*>(gv + V);
+    int* gfirst = vg + V;
+    int* glist = gfirst + V + 1;
+    int VG = 0;
+    for (int v = 0; v < V; v++) {
+        pv[v] = views[v];
+        int g = -1;
+        if (share)
+            for (int k = 0; k < VG && g < 0; k++)
+                if (memcmp(&gv[k], &views[v], offsetof(gs_view, bg)) == 0) g = k;
+        if (g < 0) { g = VG++; gv[g] = views[v]; }
+        vg[v] = g;
+    }
+    int pos = 0;
+    for (int g = 0; g < VG; g++) {
+        gfirst[g] = pos;
+        for (int v = 0; v < V; v++) if (vg[v] == g) glist[pos++] = v;
+    }
+    gfirst[VG] = pos;
+    return VG;
+}
+
 struct ScratchSet {
     DevBuf views, geom, tiles, offsets, zero_block, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads;
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
@@ -76,7 +115,7 @@ struct ScratchSet {
         T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
         Rcap = std::max<uint32_t>(Rcap_, 1024);
         const size_t v = (size_t)std::max(V, 1);
-        GS_TRY(views.ensure(v * sizeof(gs_view)));
+        GS_TRY(views.ensure(view_block_bytes((int)v)));
         GS_TRY(geom.ensure(v * Pa * sizeof(GeomRec)));
         GS_TRY(tiles.ensure(v * Pa * 4));
         GS_TRY(offsets.ensure(v * Pa * 4));
@@ -102,7 +141,7 @@ struct ScratchSet {
         GS_TRY(scan_tmp.ensure((scan_partials_count(Pa, (int)v) + scan_partials_count(T, (int)v) + scan_partials_count(NST, (int)v) + 64) * 4));
         if (want_splat_grads) GS_TRY(sgrads.ensure(v * Pa * 64));
         s.splat_grads = sgrads.as<float>();
-        s.views = views.as<gs_view>();
+        set_view_block_pointers(s, views.as<char>(), (int)v);
         s.geom = geom.as<GeomRec>();
         s.tiles_touched = tiles.as<uint32_t>();
         s.point_offsets = offsets.as<uint32_t>();
@@ -211,6 +250,7 @@ extern "C" int gs_device_synchronize(void) { GS_HIP(hipDeviceSynchronize()); ret
 extern "C" int gs_set_option(const char* name, int value) {
     if (!name) return GS_ERR_INVALID_ARGUMENT;
     if (strcmp(name, "cull") == 0) { g_opt_cull = value != 0; return GS_OK; }
+    if (strcmp(name, "share_camera_passes") == 0) { g_opt_share = value != 0; return GS_OK; }
     set_error("gs_set_option: unknown option '%s'", name);
     return GS_ERR_INVALID_ARGUMENT;
 }
@@ -346,6 +386,9 @@ struct gs_trainer {
     gs_model* model = nullptr;
     int V = 0, total_samples = 0;
     std::vector<gs_view> h_views;
+    std::vector<char> h_view_block;  // views | group cameras | maps, uploaded each step
+    std::vector<int> h_view_group;
+    int VG = 0;
     DevBuf truth;                 // [V][N] u32
     DevBuf grad, adam_m, adam_v;  // [(12+3M)][Pa], [(11+3M)][Pa] x2
     int grad_Pa = 0, grad_M = 0, adam_t = 0;
@@ -458,6 +501,11 @@ extern "C" int gs_trainer_set_views(gs_trainer* t, int n_views, const gs_view* v
     }
     t->h_views.assign(views, views + n_views);
     t->V = n_views;
+    t->VG = build_view_block(views, n_views, g_opt_share != 0, t->h_view_block);
+    {
+        const int* vg = reinterpret_cast<const int*>(t->h_view_block.data() + (size_t)n_views * 2 * sizeof(gs_view));
+        t->h_view_group.assign(vg, vg + n_views);
+    }
     t->total_samples = total_samples;
     t->accumulated = false;
     return GS_OK;
@@ -466,7 +514,7 @@ extern "C" int gs_trainer_set_views(gs_trainer* t, int n_views, const gs_view* v
 static int trainer_dims(gs_trainer* t, Dims* d) {
     int D = 0;
     GS_TRY(effective_degree(t->model->sh_degree, t->model->sh_coeffs, &D));
-    *d = make_dims(t->model->count, t->model->Pa, D, t->model->sh_coeffs, t->W, t->H, t->V, t->Rcap, 1.0f);
+    *d = make_dims(t->model->count, t->model->Pa, D, t->model->sh_coeffs, t->W, t->H, t->V, t->Rcap, 1.0f, t->VG);
     return GS_OK;
 }
 
@@ -497,7 +545,7 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
         d.Rcap = t->train.Rcap;
         Scratch s = t->train.s;
         s.truth = t->truth.as<uint32_t>();
-        GS_HIP(hipMemcpyAsync((void*)s.views, t->h_views.data(), (size_t)V * sizeof(gs_view), hipMemcpyHostToDevice, t->stream));
+        GS_HIP(hipMemcpyAsync((void*)s.views, t->h_view_block.data(), t->h_view_block.size(), hipMemcpyHostToDevice, t->stream));
         GS_HIP(hipMemsetAsync(t->train.zero_block.p, 0, t->train.zero_bytes, t->stream));
         if (P > 0) {
             uint32_t* tmp = t->train.scan_tmp.as<uint32_t>();
@@ -518,12 +566,12 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
         bool overflow = false;
         uint32_t need = 0;
         st.num_rendered = 0; st.max_tile_list = 0;
-        for (int v = 0; v < V; v++) {
-            if (t->h_flags[v * 4 + 0] & 1u) overflow = true;
-            need = std::max(need, t->h_flags[v * 4 + 2]);
-            st.num_rendered += t->h_flags[v * 4 + 2];
-            st.max_tile_list = std::max(st.max_tile_list, (int)t->h_flags[v * 4 + 1]);
+        for (int g = 0; g < t->VG; g++) {
+            if (t->h_flags[g * 4 + 0] & 1u) overflow = true;
+            need = std::max(need, t->h_flags[g * 4 + 2]);
+            st.max_tile_list = std::max(st.max_tile_list, (int)t->h_flags[g * 4 + 1]);
         }
+        for (int v = 0; v < V; v++) st.num_rendered += t->h_flags[t->h_view_group[v] * 4 + 2];  // R of every pass, as the reference counts
         if (!overflow) {
             const float* hl = reinterpret_cast<const float*>(t->h_flags + (size_t)V * 4);
             double L = 0;
@@ -673,7 +721,10 @@ extern "C" int gs_trainer_render(gs_trainer* t, uint32_t* fb, int fb_on_device, 
         GS_TRY(t->preview.ensure(m->count, 1, w, h, rcap));
         Dims d = make_dims(m->count, m->Pa, D, m->sh_coeffs, w, h, 1, t->preview.Rcap, splat_scale);
         Scratch s = t->preview.s;
-        GS_HIP(hipMemcpyAsync((void*)s.views, view, sizeof(gs_view), hipMemcpyHostToDevice, t->stream));
+        std::vector<char> vb;
+        build_view_block(view, 1, false, vb);
+        GS_HIP(hipMemcpyAsync((void*)s.views, vb.data(), vb.size(), hipMemcpyHostToDevice, t->stream));
+        GS_HIP(hipStreamSynchronize(t->stream));  // vb is a stack-lifetime staging buffer
         GS_HIP(hipMemsetAsync(t->preview.zero_block.p, 0, t->preview.zero_bytes, t->stream));
         if (m->count > 0) {
             GS_TRY(stage_project(d, m->planes, s, t->preview.scan_tmp.as<uint32_t>(), t->stream));
@@ -733,7 +784,7 @@ GeomLayout geom_layout(int P, int M, int W = 16, int H = 16) {
         const int T = gx * gy, NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE) * CGROUPS;
         L.scan_tmp = o; o = al(o + (scan_partials_count(L.Pa, 1) + scan_partials_count(T, 1) + scan_partials_count(NST, 1) + 64) * 4);
     }
-    L.view = o; o = al(o + sizeof(gs_view));
+    L.view = o; o = al(o + view_block_bytes(1));
     L.flags = o; o = al(o + 32);
     L.planes = o; o = al(o + (size_t)(11 + 3 * M) * L.Pa * 4);
     L.total = o;
@@ -772,7 +823,7 @@ BinLayout bin_layout(int R) {
 }
 Scratch seam_scratch(char* geom, const GeomLayout& g, char* img, const ImageLayout& im, char* bin, const BinLayout* b) {
     Scratch s{};
-    s.views = reinterpret_cast<const gs_view*>(geom + g.view);
+    set_view_block_pointers(s, geom + g.view, 1);
     s.geom = reinterpret_cast<GeomRec*>(geom + g.record);
     s.tiles_touched = reinterpret_cast<uint32_t*>(geom + g.tiles);
     s.point_offsets = reinterpret_cast<uint32_t*>(geom + g.offsets);
@@ -849,14 +900,23 @@ extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_u
     hipStream_t st = 0;
     Scratch s = seam_scratch(geom, gl, img, il, nullptr, nullptr);
     s.out_color = out_color;
-    // view block assembled on the device from the caller's device pointers
-    char* vb = geom + gl.view;
-    GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, view), viewmatrix, 64, hipMemcpyDeviceToDevice, st));
-    GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, projview), projmatrix, 64, hipMemcpyDeviceToDevice, st));
-    GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, campos), cam_pos, 12, hipMemcpyDeviceToDevice, st));
-    const float tf[2] = { tan_fovx, tan_fovy };
-    GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, tan_fovx), tf, 8, hipMemcpyHostToDevice, st));
-    GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, bg), background, 12, hipMemcpyDeviceToDevice, st));
+    // view block (pass 0 = camera 0) assembled on the device from the caller's device pointers
+    {
+        gs_view zero{};
+        std::vector<char> host;
+        build_view_block(&zero, 1, false, host);
+        GS_HIP(hipMemcpyAsync(geom + gl.view, host.data(), host.size(), hipMemcpyHostToDevice, st));
+        GS_HIP(hipStreamSynchronize(st));
+        for (int copy = 0; copy < 2; copy++) {  // the pass's view and its group's camera are the same struct here
+            char* vb = geom + gl.view + copy * sizeof(gs_view);
+            GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, view), viewmatrix, 64, hipMemcpyDeviceToDevice, st));
+            GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, projview), projmatrix, 64, hipMemcpyDeviceToDevice, st));
+            GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, campos), cam_pos, 12, hipMemcpyDeviceToDevice, st));
+            const float tf[2] = { tan_fovx, tan_fovy };
+            GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, tan_fovx), tf, 8, hipMemcpyHostToDevice, st));
+            GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, bg), background, 12, hipMemcpyDeviceToDevice, st));
+        }
+    }
     GS_HIP(hipMemsetAsync(img + il.zero, 0, il.zero_bytes, st));
     GS_HIP(hipMemsetAsync(geom + gl.flags, 0, 32, st));
     float* planes = reinterpret_cast<float*>(geom + gl.planes);

@@ -14,6 +14,7 @@ namespace gs {
 // ---------------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int option_cull();
+int option_share_passes();
 #define GS_HIP(expr)                                                                           \
     do {                                                                                       \
         hipError_t e__ = (expr);                                                               \
@@ -73,15 +74,20 @@ struct Dims {
     int W, H, N;  // image
     int gx, gy, T;
     int sgx, sgy, NST;  // super-tile grid
-    int V;        // views in this launch
+    int V;        // views (passes) in this launch
+    int VG;       // geometry groups: passes with bit-identical camera parameters share projection, lists and blend
     uint32_t Rcap;  // entries per view the binning arena holds
     float mod;    // scale modifier
     int cull;     // 1: sub-tile alpha>=1/255 box culling on (default); 0: evaluate every staged pair
 };
 
-// Device pointers of the per-view scratch; every array is [V][...] with the strides in Dims.
+// Device pointers of the scratch.  Arrays marked [G] are per geometry group (camera), [V] per pass.
 struct Scratch {
-    const gs_view* views;      // [V]
+    const gs_view* views;      // [V]  per pass (backgrounds differ inside a group)
+    const gs_view* gviews;     // [G]  the camera of each group
+    const int* view_group;     // [V]  group of each pass
+    const int* group_first;    // [G+1] CSR offsets into group_views
+    const int* group_views;    // [V]  passes of each group
     GeomRec* geom;             // [V][Pa]
     uint32_t* tiles_touched;   // [V][Pa]
     uint32_t* point_offsets;   // [V][Pa]  inclusive scan of tiles_touched

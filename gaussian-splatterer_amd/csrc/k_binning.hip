@@ -134,8 +134,8 @@ __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
 }
 
 int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
-    if (d.P == 0 || d.V == 0) return GS_OK;
-    hipLaunchKernelGGL(k_coarse_scatter, dim3((d.P + WG - 1) / WG, d.V), dim3(WG), 0, st, d, s);
+    if (d.P == 0 || d.VG == 0) return GS_OK;
+    hipLaunchKernelGGL(k_coarse_scatter, dim3((d.P + WG - 1) / WG, d.VG), dim3(WG), 0, st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(WG) void k_tile_count(Dims d, Scratch s) {
 }
 
 int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st) {
-    if (d.NST == 0 || d.V == 0) return GS_OK;
-    hipLaunchKernelGGL(k_tile_count, dim3(d.NST, d.V), dim3(WG), 0, st, d, s);
+    if (d.NST == 0 || d.VG == 0) return GS_OK;
+    hipLaunchKernelGGL(k_tile_count, dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
 }
 
 int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
-    if (d.T == 0 || d.V == 0) return GS_OK;
-    hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T, d.V), dim3(WG), SORT_LDS_CAP * sizeof(uint64_t), st, d, s);
+    if (d.T == 0 || d.VG == 0) return GS_OK;
+    hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T, d.VG), dim3(WG), SORT_LDS_CAP * sizeof(uint64_t), st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -347,14 +347,14 @@ int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
 // ranges[tile] = (first, one-past-last), (0,0) for empty tiles — upstream's identifyTileRanges output
 __global__ void k_ranges(Dims d, Scratch s, uint32_t* ranges) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= d.T * d.V) return;
+    if (t >= d.T * d.VG) return;
     const uint32_t n = s.tile_count[t], e = s.tile_end[t];
     ranges[2 * (size_t)t] = n ? e - n : 0;
     ranges[2 * (size_t)t + 1] = n ? e : 0;
 }
 
 int launch_ranges(const Dims& d, const Scratch& s, uint32_t* ranges, hipStream_t st) {
-    const int n = d.T * d.V;
+    const int n = d.T * d.VG;
     if (n == 0) return GS_OK;
     hipLaunchKernelGGL(k_ranges, dim3((n + 255) / 256), dim3(256), 0, st, d, s, ranges);
     GS_HIP(hipGetLastError());

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
     const int i = blockIdx.x * WG + threadIdx.x;
     const int v = blockIdx.y;
     if (i >= d.P) return;
-    const gs_view& vp = s.views[v];
+    const gs_view& vp = s.gviews[v];  // v indexes geometry groups here
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
     GeomRec* rec = s.geom + (size_t)v * st + i;
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
 }
 
 int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st) {
-    if (d.P == 0 || d.V == 0) return GS_OK;
-    dim3 grid((d.P + WG - 1) / WG, d.V);
+    if (d.P == 0 || d.VG == 0) return GS_OK;
+    dim3 grid((d.P + WG - 1) / WG, d.VG);
     switch (d.D) {
         case 0: hipLaunchKernelGGL(k_preprocess<0>, grid, dim3(WG), 0, st, d, params, s); break;
         case 1: hipLaunchKernelGGL(k_preprocess<1>, grid, dim3(WG), 0, st, d, params, s); break;

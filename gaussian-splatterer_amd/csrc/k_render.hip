@@ -63,7 +63,7 @@ template <int N> __device__ inline void stage_entry(StagedTile<N>& t, int slot, 
 __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
 #pragma clang fp contract(fast)
     __shared__ StagedTile<WG> st;
-    const int tile = blockIdx.x, v = blockIdx.y;
+    const int tile = blockIdx.x, v = blockIdx.y;  // v = geometry group (camera)
     if (s.flags[v * 4 + 0] & 1u) return;
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -124,19 +124,23 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
     }
     if (inside) {
         const size_t pix = (size_t)py * d.W + px;
-        const float* bg = s.views[v].bg;
-        float* out = s.out_color + (size_t)v * 3 * d.N;
         s.final_T[(size_t)v * d.N + pix] = T;
         s.n_contrib[(size_t)v * d.N + pix] = last;
-        out[pix] = C0 + T * bg[0];
-        out[(size_t)d.N + pix] = C1 + T * bg[1];
-        out[2 * (size_t)d.N + pix] = C2 + T * bg[2];
+        // every pass of this camera gets its own image: same blend, its own background
+        for (int k = s.group_first[v]; k < s.group_first[v + 1]; k++) {
+            const int u = s.group_views[k];
+            const float* bg = s.views[u].bg;
+            float* out = s.out_color + (size_t)u * 3 * d.N;
+            out[pix] = C0 + T * bg[0];
+            out[(size_t)d.N + pix] = C1 + T * bg[1];
+            out[2 * (size_t)d.N + pix] = C2 + T * bg[2];
+        }
     }
 }
 
 int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t stream) {
-    if (d.T == 0 || d.V == 0) return GS_OK;
-    hipLaunchKernelGGL(k_render_fwd, dim3(d.T, d.V), dim3(WG), 0, stream, d, s);
+    if (d.T == 0 || d.VG == 0) return GS_OK;
+    hipLaunchKernelGGL(k_render_fwd, dim3(d.T, d.VG), dim3(WG), 0, stream, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -278,8 +282,9 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
     __shared__ unsigned long long sTouched[4][BWD_ROUND / 64];
     __shared__ uint32_t sMaxLast;
     __shared__ float sLoss;
-    const int tile = blockIdx.x, v = blockIdx.y;
-    if (s.flags[v * 4 + 0] & 1u) return;
+    const int tile = blockIdx.x, v = blockIdx.y;  // v = pass
+    const int g = s.view_group[v];                // its geometry group: lists, records, T and n_contrib live there
+    if (s.flags[g * 4 + 0] & 1u) return;
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int bx0 = tx * TILE + (wave & 1) * 8, by0 = ty * TILE + (wave >> 1) * 8;
@@ -288,11 +293,11 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
     const float pxf = (float)px, pyf = (float)py;
     const float bxlo = (float)bx0, bxhi = (float)(bx0 + 7), bylo = (float)by0, byhi = (float)(by0 + 7);
 
-    const int n = (int)s.tile_count[(size_t)v * d.T + tile];
-    const uint32_t start = s.tile_end[(size_t)v * d.T + tile] - (uint32_t)n;
-    const uint32_t* __restrict__ plist = s.point_list + (size_t)v * d.Rcap + start;
-    const uint32_t* __restrict__ slist = s.slot_list + (size_t)v * d.Rcap + start;
-    const GeomRec* __restrict__ geom = s.geom + (size_t)v * d.Pa;
+    const int n = (int)s.tile_count[(size_t)g * d.T + tile];
+    const uint32_t start = s.tile_end[(size_t)g * d.T + tile] - (uint32_t)n;
+    const uint32_t* __restrict__ plist = s.point_list + (size_t)g * d.Rcap + start;
+    const uint32_t* __restrict__ slist = s.slot_list + (size_t)g * d.Rcap + start;
+    const GeomRec* __restrict__ geom = s.geom + (size_t)g * d.Pa;
     float* __restrict__ Gv = s.G + (size_t)v * d.Rcap * G_STRIDE;
     const float* bg = s.views[v].bg;
 
@@ -303,8 +308,8 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
     float res2 = 0.0f;
     if (inside) {
         const size_t pix = (size_t)py * d.W + px;
-        T_final = s.final_T[(size_t)v * d.N + pix];
-        last_contributor = s.n_contrib[(size_t)v * d.N + pix];
+        T_final = s.final_T[(size_t)g * d.N + pix];
+        last_contributor = s.n_contrib[(size_t)g * d.N + pix];
         if (s.dL_dpix) {
             const float* g = s.dL_dpix + (size_t)v * 3 * d.N;
             dpx0 = g[pix]; dpx1 = g[(size_t)d.N + pix]; dpx2 = g[2 * (size_t)d.N + pix];

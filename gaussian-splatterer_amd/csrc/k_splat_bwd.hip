@@ -247,8 +247,9 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
     float4* out = rec_out + ((size_t)v * st + i) * 4;
-    const GeomRec* rec = s.geom + (size_t)v * st + i;
-    if ((s.flags[v * 4 + 0] & 1u) || !(rec->radius > 0)) {  // culled: the reference's nine buffers stay zero
+    const int g = s.view_group[v];  // geometry group of this pass: records and slots live there, gradient rows per pass
+    const GeomRec* rec = s.geom + (size_t)g * st + i;
+    if ((s.flags[g * 4 + 0] & 1u) || !(rec->radius > 0)) {  // culled: the reference's nine buffers stay zero
         const float4 z = make_float4(0, 0, 0, 0);
         out[0] = z; out[1] = z; out[2] = z; out[3] = z;
         return;
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     for (int c = 0; c < 3; c++) { mean[c] = params[pl.loc(c) * st + i]; sc[c] = d.mod * params[pl.scale(c) * st + i]; }
 #pragma unroll
     for (int c = 0; c < 4; c++) q[c] = params[pl.rot(c) * st + i];
-    const uint32_t tiles = s.tiles_touched[(size_t)v * st + i];
-    const uint32_t first = s.point_offsets[(size_t)v * st + i] - tiles;
+    const uint32_t tiles = s.tiles_touched[(size_t)g * st + i];
+    const uint32_t first = s.point_offsets[(size_t)g * st + i] - tiles;
     float sum[9];
     gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, first, tiles, sum);
     SplatOut<D> o;

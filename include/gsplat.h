@@ -58,7 +58,10 @@ int gs_version(int* major, int* minor, int* patch);
 int gs_device_count(void);
 /* Process-wide diagnostic switches.  "cull" (default 1): the render kernels skip (splat, 8x8 pixel
  * block) pairs whose alpha >= 1/255 box misses the block; 0 evaluates every staged pair.  Results
- * are bit-identical either way (tests/test_gpu_raster.py checks exactly that). */
+ * are bit-identical either way (tests/test_gpu_raster.py checks exactly that).
+ * "share_camera_passes" (default 1; read by gs_trainer_set_views): passes whose camera parameters are bit-identical
+ * (the reference's white/black pair per camera, src/Trainer.cu:311-318) share projection, tile lists and the
+ * forward blend; 0 recomputes them per pass like the reference.  Results are bit-identical either way. */
 int gs_set_option(const char* name, int value);
 /* Diagnostic: runs the backward kernel's 9-value wave reduce-scatter on one wave64.  in_host[q*64 + lane]
  * (q = 0..8), out_host[lane]: lane 2q of every 16-lane row holds the wave total of value q (q < 8), lane 1

@@ -192,3 +192,27 @@ def test_reference_error_behaviour():
     assert b"no truth data" in L.gs_last_error()
     assert tr.model.count == 0  # placeholder model, src/Trainer.cu:112
     tr.close()
+
+
+def test_camera_pass_sharing_is_bit_identical(orc):
+    """The white and black pass of one camera share projection, tile lists and the forward blend
+    (gs_set_option "share_camera_passes", default on).  Recomputing them per pass like the reference must give
+    bit-identical images, statistics and averaged gradients."""
+    P, M, n_cams, W, H = 1500, 4, 3, 128, 96
+    res = []
+    for share in (1, 0):
+        capi.check(capi.lib().gs_set_option(b"share_camera_passes", share))
+        try:
+            s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 4242)
+            st = tr.train(gs.Project(), stats=True)
+            g = _read_grads(tr, P, M)
+            imgs = [tr.read_image(v) for v in range(2 * n_cams)]
+            res.append((st.num_rendered, st.loss, g, imgs))
+            tr.close()
+        finally:
+            capi.check(capi.lib().gs_set_option(b"share_camera_passes", 1))
+    assert res[0][0] == res[1][0]
+    for k in res[0][2]:
+        assert np.array_equal(res[0][2][k].view(np.uint32), res[1][2][k].view(np.uint32)), k
+    for a, b in zip(res[0][3], res[1][3]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
