@@ -67,7 +67,9 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
 // state and each stage is ONE launch over all views.
 // One device block carries everything that describes the passes of a step: the per-pass view structs, the camera
 // of every geometry group, and the pass <-> group maps.  One host-to-device copy per step.
-static size_t view_block_bytes(int V) { return (size_t)V * 2 * sizeof(gs_view) + ((size_t)3 * V + 1) * sizeof(int); }
+static size_t view_block_bytes(int V) { return (size_t)V * 2 * sizeof(gs_view) + ((size_t)6 * V + 1) * sizeof(int); }
+// int offset of the backward work items {group, pass a, pass b | -1} inside the map area
+static size_t view_block_items_offset(int V) { return (size_t)V * 2 * sizeof(gs_view) + ((size_t)3 * V + 1) * sizeof(int); }
 static void set_view_block_pointers(Scratch& s, char* base, int V) {
     s.views = reinterpret_cast<const gs_view*>(base);
     s.gviews = s.views + V;
@@ -76,7 +78,7 @@ static void set_view_block_pointers(Scratch& s, char* base, int V) {
 }
 // Groups the passes by bit-identical camera (view, projview, campos, tan_fov*): the reference runs a white- and a
 // black-background pass per camera (src/Trainer.cu:311-318) whose projection, tile lists and blend are identical.
-static int build_view_block(const gs_view* views, int V, bool share, std::vector<char>& out) {
+static int build_view_block(const gs_view* views, int V, bool share, std::vector<char>& out, int* n_pairs = nullptr, int* n_singles = nullptr) {
     out.assign(view_block_bytes(V), 0);
     gs_view* pv = reinterpret_cast<gs_view*>(out.data());
     gs_view* gv = pv + V;
@@ -99,6 +101,15 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
         for (int v = 0; v < V; v++) if (vg[v] == g) glist[pos++] = v;
     }
     gfirst[VG] = pos;
+    // backward work items: the passes of a camera two at a time (pairs first, then leftovers)
+    int* items = reinterpret_cast<int*>(out.data() + view_block_items_offset(V));
+    int n2 = 0, n1 = 0;
+    for (int g = 0; g < VG; g++)
+        for (int k = gfirst[g]; k + 1 < gfirst[g + 1]; k += 2) { int* it = items + 3 * n2++; it[0] = g; it[1] = glist[k]; it[2] = glist[k + 1]; }
+    for (int g = 0; g < VG; g++)
+        if ((gfirst[g + 1] - gfirst[g]) & 1) { int* it = items + 3 * (n2 + n1++); it[0] = g; it[1] = glist[gfirst[g + 1] - 1]; it[2] = -1; }
+    if (n_pairs) *n_pairs = n2;
+    if (n_singles) *n_singles = n1;
     return VG;
 }
 
@@ -388,7 +399,7 @@ struct gs_trainer {
     std::vector<gs_view> h_views;
     std::vector<char> h_view_block;  // views | group cameras | maps, uploaded each step
     std::vector<int> h_view_group;
-    int VG = 0;
+    int VG = 0, bwd_pairs = 0, bwd_singles = 0;
     DevBuf truth;                 // [V][N] u32
     DevBuf grad, adam_m, adam_v;  // [(12+3M)][Pa], [(11+3M)][Pa] x2
     int grad_Pa = 0, grad_M = 0, adam_t = 0;
@@ -501,7 +512,7 @@ extern "C" int gs_trainer_set_views(gs_trainer* t, int n_views, const gs_view* v
     }
     t->h_views.assign(views, views + n_views);
     t->V = n_views;
-    t->VG = build_view_block(views, n_views, g_opt_share != 0, t->h_view_block);
+    t->VG = build_view_block(views, n_views, g_opt_share != 0, t->h_view_block, &t->bwd_pairs, &t->bwd_singles);
     {
         const int* vg = reinterpret_cast<const int*>(t->h_view_block.data() + (size_t)n_views * 2 * sizeof(gs_view));
         t->h_view_group.assign(vg, vg + n_views);
@@ -554,7 +565,9 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
             { StageTimer tm(t, 2); GS_TRY(stage_bin(d, s, tmp, t->stream)); }
             { StageTimer tm(t, 3); GS_TRY(launch_tile_build_sort(d, s, t->stream)); }
             { StageTimer tm(t, 4); GS_TRY(launch_render_forward(d, s, t->stream)); }
-            { StageTimer tm(t, 5); GS_TRY(launch_render_backward(d, s, t->stream)); }
+            { StageTimer tm(t, 5);
+              const int* items = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.views) + view_block_items_offset(V));
+              GS_TRY(launch_render_backward(d, s, items, t->bwd_pairs, t->bwd_singles, t->stream)); }
             { StageTimer tm(t, 6); GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), t->stream)); }
         } else {  // empty model: tile lists are empty, the image is the background
             GS_TRY(stage_bin(d, s, t->train.scan_tmp.as<uint32_t>(), t->stream));
@@ -974,7 +987,7 @@ extern "C" int gs_rasterize_backward(int P, int D_in, int M, int R, const float*
     s.dL_dpix = dL_dpix;
     Dims d = make_dims(P, gl.Pa, D, M, width, height, 1, bl.Rcap, scale_modifier);
     hipStream_t st = 0;
-    GS_TRY(launch_render_backward(d, s, st));
+    GS_TRY(launch_render_backward(d, s, reinterpret_cast<const int*>(geom_buffer + gl.view + view_block_items_offset(1)), 0, 1, st));
     SeamGrads g{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
     GS_TRY(launch_splat_backward_seam(d, reinterpret_cast<const float*>(geom_buffer + gl.planes), s, g, st));
     GS_HIP(hipStreamSynchronize(st));

@@ -274,16 +274,26 @@ int launch_debug_reduce9(const float* in, float* out, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
+// One workgroup = one tile of one camera, K passes of that camera at once (K = 2: the reference's white- and
+// black-background pair).  Everything that does not depend on dL/dpixel — pair geometry, exp, alpha, the
+// transmittance recurrence, the accumulated colour behind — is evaluated once and shared; only the dL/dalpha
+// chain, the nine sums and their reduction run per pass.
+template <int K>
+__global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s, const int* __restrict__ items) {
 #pragma clang fp contract(fast)
-    __shared__ StagedTile<BWD_ROUND> st;
-    __shared__ uint32_t sSlot[BWD_ROUND];
-    __shared__ float sAcc[4 * BWD_ROUND * ACC_STRIDE];
-    __shared__ unsigned long long sTouched[4][BWD_ROUND / 64];
+    constexpr int ROUND = (K == 1) ? BWD_ROUND : BWD_ROUND / 2;  // entries staged per round (LDS: ~24 KB either way)
+    __shared__ StagedTile<ROUND> st;
+    __shared__ uint32_t sSlot[ROUND];
+    __shared__ float sAcc[K * 4 * ROUND * ACC_STRIDE];
+    __shared__ unsigned long long sTouched[4][(ROUND + 63) / 64];
     __shared__ uint32_t sMaxLast;
-    __shared__ float sLoss;
-    const int tile = blockIdx.x, v = blockIdx.y;  // v = pass
-    const int g = s.view_group[v];                // its geometry group: lists, records, T and n_contrib live there
+    __shared__ float sLoss[K];
+    const int tile = blockIdx.x;
+    const int* item = items + 3 * blockIdx.y;  // {group, pass 0, pass 1}
+    const int g = item[0];                     // geometry group: lists, records, T and n_contrib live there
+    int vp[K];
+#pragma unroll
+    for (int p = 0; p < K; p++) vp[p] = item[1 + p];
     if (s.flags[g * 4 + 0] & 1u) return;
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -298,32 +308,44 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
     const uint32_t* __restrict__ plist = s.point_list + (size_t)g * d.Rcap + start;
     const uint32_t* __restrict__ slist = s.slot_list + (size_t)g * d.Rcap + start;
     const GeomRec* __restrict__ geom = s.geom + (size_t)g * d.Pa;
-    float* __restrict__ Gv = s.G + (size_t)v * d.Rcap * G_STRIDE;
-    const float* bg = s.views[v].bg;
 
     // per-pixel state
     float T_final = 0.0f;
     uint32_t last_contributor = 0;
-    float dpx0 = 0.0f, dpx1 = 0.0f, dpx2 = 0.0f;
-    float res2 = 0.0f;
+    float dpx[K][3], res2[K], tfbg[K];
+#pragma unroll
+    for (int p = 0; p < K; p++) { dpx[p][0] = dpx[p][1] = dpx[p][2] = 0.0f; res2[p] = 0.0f; }
     if (inside) {
         const size_t pix = (size_t)py * d.W + px;
         T_final = s.final_T[(size_t)g * d.N + pix];
         last_contributor = s.n_contrib[(size_t)g * d.N + pix];
-        if (s.dL_dpix) {
-            const float* g = s.dL_dpix + (size_t)v * 3 * d.N;
-            dpx0 = g[pix]; dpx1 = g[(size_t)d.N + pix]; dpx2 = g[2 * (size_t)d.N + pix];
-        } else {
-            // imageIntToLoss, src/Trainer.cu:33-44: truth/255 - rasterized
-            const uint32_t t = s.truth[(size_t)v * d.N + pix];
-            const float* out = s.out_color + (size_t)v * 3 * d.N;
-            dpx0 = ((float)(t & 0xFF) / 255.0f) - out[pix];
-            dpx1 = ((float)((t >> 8) & 0xFF) / 255.0f) - out[(size_t)d.N + pix];
-            dpx2 = ((float)((t >> 16) & 0xFF) / 255.0f) - out[2 * (size_t)d.N + pix];
-            res2 = dpx0 * dpx0 + dpx1 * dpx1 + dpx2 * dpx2;
+#pragma unroll
+        for (int p = 0; p < K; p++) {
+            const int v = vp[p];
+            if (s.dL_dpix) {
+                const float* gp = s.dL_dpix + (size_t)v * 3 * d.N;
+                dpx[p][0] = gp[pix]; dpx[p][1] = gp[(size_t)d.N + pix]; dpx[p][2] = gp[2 * (size_t)d.N + pix];
+            } else {
+                // imageIntToLoss, src/Trainer.cu:33-44: truth/255 - rasterized
+                const uint32_t t = s.truth[(size_t)v * d.N + pix];
+                const float* out = s.out_color + (size_t)v * 3 * d.N;
+                dpx[p][0] = ((float)(t & 0xFF) / 255.0f) - out[pix];
+                dpx[p][1] = ((float)((t >> 8) & 0xFF) / 255.0f) - out[(size_t)d.N + pix];
+                dpx[p][2] = ((float)((t >> 16) & 0xFF) / 255.0f) - out[2 * (size_t)d.N + pix];
+                res2[p] = dpx[p][0] * dpx[p][0] + dpx[p][1] * dpx[p][1] + dpx[p][2] * dpx[p][2];
+            }
         }
     }
-    if (tid == 0) { sMaxLast = 0; sLoss = 0.0f; }
+#pragma unroll
+    for (int p = 0; p < K; p++) {
+        const float* bg = s.views[vp[p]].bg;
+        tfbg[p] = -T_final * (bg[0] * dpx[p][0] + bg[1] * dpx[p][1] + bg[2] * dpx[p][2]);
+    }
+    if (tid == 0) {
+        sMaxLast = 0;
+#pragma unroll
+        for (int p = 0; p < K; p++) sLoss[p] = 0.0f;
+    }
     __syncthreads();
     // wave-uniform and block-uniform bounds on the traversal
     uint32_t wave_max_last = last_contributor;
@@ -331,23 +353,29 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
     for (int o = 32; o > 0; o >>= 1) wave_max_last = max(wave_max_last, (uint32_t)__shfl_xor((int)wave_max_last, o));
     if (lane == 0) atomicMax(&sMaxLast, wave_max_last);
     if (s.loss && !s.dL_dpix) {
-        const float l = wave_sum_to_lane63(res2);
-        if (lane == 63) atomicAdd(&sLoss, l);
+#pragma unroll
+        for (int p = 0; p < K; p++) {
+            const float l = wave_sum_to_lane63(res2[p]);
+            if (lane == 63) atomicAdd(&sLoss[p], l);
+        }
     }
     __syncthreads();
     const int max_last = (int)sMaxLast;
-    if (s.loss && !s.dL_dpix && tid == 0) atomicAdd(&s.loss[v], sLoss);
+    if (s.loss && !s.dL_dpix && tid < K) atomicAdd(&s.loss[vp[tid]], sLoss[tid]);
     if (n == 0) return;
-    const int rounds = (max_last + BWD_ROUND - 1) / BWD_ROUND;
-    // entries no pixel reaches still own a gradient row: zero it
-    for (int p = rounds * BWD_ROUND + tid; p < n; p += WG) {
-        float4* row = reinterpret_cast<float4*>(Gv + (size_t)slist[p] * G_STRIDE);
-        row[0] = make_float4(0, 0, 0, 0); row[1] = make_float4(0, 0, 0, 0); row[2] = make_float4(0, 0, 0, 0);
+    const int rounds = (max_last + ROUND - 1) / ROUND;
+    // entries no pixel reaches still own a gradient row per pass: zero it
+    for (int e = rounds * ROUND + tid; e < n; e += WG) {
+        const uint32_t slot = slist[e];
+#pragma unroll
+        for (int p = 0; p < K; p++) {
+            float4* row = reinterpret_cast<float4*>(s.G + ((size_t)vp[p] * d.Rcap + slot) * G_STRIDE);
+            row[0] = make_float4(0, 0, 0, 0); row[1] = make_float4(0, 0, 0, 0); row[2] = make_float4(0, 0, 0, 0);
+        }
     }
 
     float T = T_final;
     float ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f;  // accum_rec, already blended with the previously visited entry
-    const float tfbg = -T_final * (bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2);
     const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
     // where this lane parks a reduced value: lane 2q -> q, lane 1 -> 8 (row 0 only)
     const bool writer = lane < 16 && (((lane & 1) == 0) || lane == 1);
@@ -355,17 +383,19 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
     const int fold16 = (lane ^ 16) << 2, fold32 = (lane ^ 32) << 2;  // ds_bpermute byte addresses of the row partners
 
     for (int r = rounds - 1; r >= 0; r--) {
-        const int base = r * BWD_ROUND;
-        const int cnt = min(BWD_ROUND, n - base);
+        const int base = r * ROUND;
+        const int cnt = min(ROUND, n - base);
         __syncthreads();  // previous round's flush has consumed st / sAcc / sTouched
         if (tid < cnt) {
             stage_entry(st, tid, geom + plist[base + tid]);
             sSlot[tid] = slist[base + tid];
         }
         __syncthreads();
-        unsigned long long touched[BWD_ROUND / 64] = { 0ull, 0ull };
+        unsigned long long touched[(ROUND + 63) / 64];
 #pragma unroll
-        for (int sb = BWD_ROUND / 64 - 1; sb >= 0; sb--) {
+        for (int sb = 0; sb < (ROUND + 63) / 64; sb++) touched[sb] = 0ull;
+#pragma unroll
+        for (int sb = (ROUND + 63) / 64 - 1; sb >= 0; sb--) {
             const int sub = sb * 64;
             if (sub >= cnt || (uint32_t)(base + sub) >= wave_max_last) continue;
             const int j = sub + lane;
@@ -390,7 +420,9 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
                 const bool act = (pos < last_contributor) && power <= 0.0f && alpha >= ALPHA_MIN;
                 // Per lane only the colour terms and six moments of u = G * dL_dalpha are formed; the factors
                 // that are constant per splat (opacity, conic, 0.5*W, -0.5) are applied once per entry in the flush.
-                float dchannel_dcolor = 0.0f, u = 0.0f;
+                float dchannel_dcolor = 0.0f, u[K];
+#pragma unroll
+                for (int p = 0; p < K; p++) u[p] = 0.0f;
                 if (act) {
                     const float keep = 1.0f - alpha;
                     const float inv1ma = __builtin_amdgcn_rcpf(keep);
@@ -398,63 +430,75 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s) {
                     dchannel_dcolor = alpha * T;
                     // upstream blends (last_alpha, last_color) into accum_rec BEFORE using it; doing the same blend with
                     // this entry's (alpha, colour) AFTER use is the identical recurrence one step early
-                    float dL_dalpha = (Bc.z - ar0) * dpx0;
-                    dL_dalpha += (Bc.w - ar1) * dpx1;
-                    dL_dalpha += (cbc - ar2) * dpx2;
+                    const float c0 = Bc.z - ar0, c1 = Bc.w - ar1, c2 = cbc - ar2;
                     ar0 = alpha * Bc.z + keep * ar0;
                     ar1 = alpha * Bc.w + keep * ar1;
                     ar2 = alpha * cbc + keep * ar2;
-                    dL_dalpha = dL_dalpha * T + tfbg * inv1ma;   // tfbg = -T_final * (bg . dL_dpix)
-                    u = G * dL_dalpha;
+                    const float GT = G * T, Gi = G * inv1ma;
+#pragma unroll
+                    for (int p = 0; p < K; p++) {
+                        float dL = c0 * dpx[p][0];
+                        dL += c1 * dpx[p][1];
+                        dL += c2 * dpx[p][2];
+                        u[p] = dL * GT + tfbg[p] * Gi;  // G * (dL_dalpha * T + tfbg / (1 - alpha)),  tfbg = -T_final * (bg . dL_dpix)
+                    }
                 }
                 if (__ballot(act) != 0ull) {
                     // inactive lanes contribute exact zeros: dchannel_dcolor = u = 0 there
-                    const float ux = u * dx, uy = u * dy;
-                    float red = wave_reduce_scatter9_rows(dchannel_dcolor * dpx0, dchannel_dcolor * dpx1, dchannel_dcolor * dpx2, ux, uy,
-                                                          ux * dx, ux * dy, uy * dy, u);
-                    red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold16, __builtin_bit_cast(int, red)));
-                    red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold32, __builtin_bit_cast(int, red)));
-                    if (writer) sAcc[(wave * BWD_ROUND + jj) * ACC_STRIDE + wslot] = red;
+#pragma unroll
+                    for (int p = 0; p < K; p++) {
+                        const float ux = u[p] * dx, uy = u[p] * dy;
+                        float red = wave_reduce_scatter9_rows(dchannel_dcolor * dpx[p][0], dchannel_dcolor * dpx[p][1],
+                                                              dchannel_dcolor * dpx[p][2], ux, uy, ux * dx, ux * dy, uy * dy, u[p]);
+                        red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold16, __builtin_bit_cast(int, red)));
+                        red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold32, __builtin_bit_cast(int, red)));
+                        if (writer) sAcc[((p * 4 + wave) * ROUND + jj) * ACC_STRIDE + wslot] = red;
+                    }
                     touched[sb] |= 1ull << kk;
                 }
             }
         }
         if (lane == 0) {
 #pragma unroll
-            for (int sb = 0; sb < BWD_ROUND / 64; sb++) sTouched[wave][sb] = touched[sb];
+            for (int sb = 0; sb < (ROUND + 63) / 64; sb++) sTouched[wave][sb] = touched[sb];
         }
         __syncthreads();
         if (tid < cnt) {
-            float sum[ACC_STRIDE];
-#pragma unroll
-            for (int q = 0; q < ACC_STRIDE; q++) sum[q] = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 4; w++) {  // fixed order over the four waves; only slots written this round are read
-                if ((sTouched[w][tid >> 6] >> (tid & 63)) & 1ull) {
-                    const float* a = &sAcc[(w * BWD_ROUND + tid) * ACC_STRIDE];
-#pragma unroll
-                    for (int q = 0; q < ACC_STRIDE; q++) sum[q] += a[q];
-                }
-            }
             // moments -> the reference's nine sums (dx = mean2D.x - pixel.x as upstream):
             //   dL_dmean2D.x = -0.5 W op (conA * S[u dx] + conB * S[u dy]),  .y = -0.5 H op (conC * S[u dy] + conB * S[u dx])
             //   dL_dconic    = -0.5 op (S[u dx dx], S[u dx dy], S[u dy dy]),  dL_dopacity = S[u]
             const float4 Af = st.A[tid], Bf = st.B[tid];
-            const float op = Bf.y;
-            const float gmx = -ddelx_dx * op * (Af.z * sum[3] + Af.w * sum[4]);
-            const float gmy = -ddely_dy * op * (Bf.x * sum[4] + Af.w * sum[3]);
-            const float hop = -0.5f * op;
-            float4* row = reinterpret_cast<float4*>(Gv + (size_t)sSlot[tid] * G_STRIDE);
-            row[0] = make_float4(sum[0], sum[1], sum[2], gmx);
-            row[1] = make_float4(gmy, hop * sum[5], hop * sum[6], hop * sum[7]);
-            row[2] = make_float4(sum[8], 0.0f, 0.0f, 0.0f);
+            const float op = Bf.y, hop = -0.5f * op;
+            const uint32_t slot = sSlot[tid];
+#pragma unroll
+            for (int p = 0; p < K; p++) {
+                float sum[ACC_STRIDE];
+#pragma unroll
+                for (int q = 0; q < ACC_STRIDE; q++) sum[q] = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {  // fixed order over the four waves; only slots written this round are read
+                    if ((sTouched[w][tid >> 6] >> (tid & 63)) & 1ull) {
+                        const float* a = &sAcc[((p * 4 + w) * ROUND + tid) * ACC_STRIDE];
+#pragma unroll
+                        for (int q = 0; q < ACC_STRIDE; q++) sum[q] += a[q];
+                    }
+                }
+                const float gmx = -ddelx_dx * op * (Af.z * sum[3] + Af.w * sum[4]);
+                const float gmy = -ddely_dy * op * (Bf.x * sum[4] + Af.w * sum[3]);
+                float4* row = reinterpret_cast<float4*>(s.G + ((size_t)vp[p] * d.Rcap + slot) * G_STRIDE);
+                row[0] = make_float4(sum[0], sum[1], sum[2], gmx);
+                row[1] = make_float4(gmy, hop * sum[5], hop * sum[6], hop * sum[7]);
+                row[2] = make_float4(sum[8], 0.0f, 0.0f, 0.0f);
+            }
         }
     }
 }
 
-int launch_render_backward(const Dims& d, const Scratch& s, hipStream_t stream) {
-    if (d.T == 0 || d.V == 0) return GS_OK;
-    hipLaunchKernelGGL(k_render_bwd, dim3(d.T, d.V), dim3(WG), 0, stream, d, s);
+// items: n2 pairs {group, pass a, pass b} followed by n1 singles {group, pass, -1} (device array of 3*(n2+n1) ints)
+int launch_render_backward(const Dims& d, const Scratch& s, const int* items, int n2, int n1, hipStream_t stream) {
+    if (d.T == 0) return GS_OK;
+    if (n2 > 0) hipLaunchKernelGGL(k_render_bwd<2>, dim3(d.T, n2), dim3(WG), 0, stream, d, s, items);
+    if (n1 > 0) hipLaunchKernelGGL(k_render_bwd<1>, dim3(d.T, n1), dim3(WG), 0, stream, d, s, items + 3 * n2);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
