@@ -186,6 +186,14 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         step_bytes = sum(stage_bytes(k, P, M, N, R_mean, V_local) for k in kern) + (48 + 12 * M) * P
         ms_per_step = elapsed / args.steps * 1e3
+        traffic = None
+        try:  # HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (same command, separate runs)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            k = pmc.get(dom)
+            if k and args.config == 3 and not args.views and world == 1:
+                traffic = k["fetch_bytes_x2"] + k["write_bytes"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "train steps/sec (fwd+bwd+Adam), 100k splats x 16 views @1024^2, 1->8 GPU" if args.config == 3 else
                       f"train steps/sec (fwd+bwd+update), BASELINE config {args.config}",
@@ -204,9 +212,11 @@ def main():
                        "views_per_gpu": V_local, "width": W, "height": H, "update": args.update,
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "collective": (args.collective + " all-reduce of %d fp32" % ((12 + 3 * M) * P)) if use_dist else "none",
-                       "mean_num_rendered_per_view": R_mean, "max_tile_list": st.max_tile_list},
+                       "mean_num_rendered_per_view": R_mean, "max_tile_list": st.max_tile_list,
+                       "camera_pass_sharing": "on (default): the white/black passes of a camera share projection, tile lists and "
+                                              "the forward blend and run one fused backward; bit-identical to per-pass recomputation"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
                          "step_algorithmic_GB": step_bytes / 1e9,
                          "step_achieved_GBs": step_bytes / (ms_per_step * 1e-3) / 1e9,

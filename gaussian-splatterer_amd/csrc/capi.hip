@@ -565,10 +565,11 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
             { StageTimer tm(t, 2); GS_TRY(stage_bin(d, s, tmp, t->stream)); }
             { StageTimer tm(t, 3); GS_TRY(launch_tile_build_sort(d, s, t->stream)); }
             { StageTimer tm(t, 4); GS_TRY(launch_render_forward(d, s, t->stream)); }
-            { StageTimer tm(t, 5);
-              const int* items = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.views) + view_block_items_offset(V));
-              GS_TRY(launch_render_backward(d, s, items, t->bwd_pairs, t->bwd_singles, t->stream)); }
-            { StageTimer tm(t, 6); GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), t->stream)); }
+            const int* items = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.views) + view_block_items_offset(V));
+            { StageTimer tm(t, 5); GS_TRY(launch_render_backward(d, s, items, t->bwd_pairs, t->bwd_singles, t->stream)); }
+            { StageTimer tm(t, 6);
+              GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), items, t->bwd_pairs,
+                                               t->bwd_singles, t->stream)); }
         } else {  // empty model: tile lists are empty, the image is the background
             GS_TRY(stage_bin(d, s, t->train.scan_tmp.as<uint32_t>(), t->stream));
             GS_TRY(launch_render_forward(d, s, t->stream));

@@ -124,7 +124,8 @@ int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_backward(const Dims& d, const Scratch& s, const int* items, int n_pairs, int n_singles, hipStream_t st);
 // Trainer form: loops the views, writes the averaged-gradient planes (incl. var) once.
-int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad_planes, hipStream_t st);
+int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad_planes, const int* items,
+                              int n_pairs, int n_singles, hipStream_t st);
 // Seam form: one view, reference-shaped AoS outputs with the reference's += / = discipline.
 struct SeamGrads { float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot; };
 int launch_splat_backward_seam(const Dims& d, const float* params, const Scratch& s, const SeamGrads& g, hipStream_t st);

@@ -236,18 +236,22 @@ template <int D> __device__ inline void sh_basis(float X, float Y, float Z, floa
     }
 }
 
-// Trainer stage 1: one thread per (view, splat) — fully parallel (V*P threads).  Sums the splat's gradient rows
-// and runs the per-splat chain; the result is ONE 64-byte record per (view, splat):
+// Trainer stage 1: one thread per (pass, splat) — fully parallel.  Sums the splat's gradient rows of that pass and
+// runs the per-splat chain; the result is ONE 64-byte record per (pass, splat):
 //   mean(3) scale(3) rot(4) opacity(1) dL_dRGB(3, clamp-masked) pad(2).   Culled splats write zeros.
+// (Fusing the two passes of a camera into one thread was measured slower: 175 VGPRs, 2 waves/SIMD.)
+// Work items are the backward's {group, pass a, pass b}; `which` selects the pass of the item.
 template <int D>
-__global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __restrict__ params, Scratch s, float4* __restrict__ rec_out) {
+__global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __restrict__ params, Scratch s, float4* __restrict__ rec_out,
+                                                       const int* __restrict__ items, int which) {
     const int i = blockIdx.x * WG + threadIdx.x;
-    const int v = blockIdx.y;
     if (i >= d.P) return;
+    const int* item = items + 3 * blockIdx.y;
+    const int g = item[0];          // geometry group: records and slots live there
+    const int v = item[1 + which];  // pass: gradient rows and the output record
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
     float4* out = rec_out + ((size_t)v * st + i) * 4;
-    const int g = s.view_group[v];  // geometry group of this pass: records and slots live there, gradient rows per pass
     const GeomRec* rec = s.geom + (size_t)g * st + i;
     if ((s.flags[g * 4 + 0] & 1u) || !(rec->radius > 0)) {  // culled: the reference's nine buffers stay zero
         const float4 z = make_float4(0, 0, 0, 0);
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     SplatOut<D> o;
     float dRGB[3];
     auto sh_at = [&](int k, int c) { return params[pl.sh(k, c) * st + i]; };  // streamed: no 48-register SH array
-    splat_backward_core<D, false>(s.views[v], d.W, d.H, mean, sc, q, sh_at, rec->flags, sum, sum[3], sum[4], sum[5], sum[6], sum[7], o, dRGB);
+    splat_backward_core<D, false>(s.gviews[g], d.W, d.H, mean, sc, q, sh_at, rec->flags, sum, sum[3], sum[4], sum[5], sum[6], sum[7], o, dRGB);
     out[0] = make_float4(o.mean[0], o.mean[1], o.mean[2], o.scale[0]);
     out[1] = make_float4(o.scale[1], o.scale[2], o.rot[0], o.rot[1]);
     out[2] = make_float4(o.rot[2], o.rot[3], sum[8], dRGB[0]);
@@ -323,19 +327,27 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __
     grad[pl.var() * st + i] = var;
 }
 
-int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, hipStream_t stream) {
-    if (d.P == 0) return GS_OK;
-    dim3 g1((d.P + WG - 1) / WG, d.V), g2((d.P + WG - 1) / WG);
+template <int D>
+static void launch_splat_avg_d(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, const int* items, int n2,
+                               int n1, hipStream_t stream) {
+    const int bx = (d.P + WG - 1) / WG;
     float4* rec = reinterpret_cast<float4*>(s.splat_grads);
+    if (n2 > 0) {
+        hipLaunchKernelGGL(k_splat_bwd_view<D>, dim3(bx, n2), dim3(WG), 0, stream, d, params, s, rec, items, 0);
+        hipLaunchKernelGGL(k_splat_bwd_view<D>, dim3(bx, n2), dim3(WG), 0, stream, d, params, s, rec, items, 1);
+    }
+    if (n1 > 0) hipLaunchKernelGGL(k_splat_bwd_view<D>, dim3(bx, n1), dim3(WG), 0, stream, d, params, s, rec, items + 3 * n2, 0);
+    hipLaunchKernelGGL(k_splat_bwd_reduce<D>, dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad);
+}
+
+int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, const int* items,
+                              int n_pairs, int n_singles, hipStream_t stream) {
+    if (d.P == 0) return GS_OK;
     switch (d.D) {
-        case 0: hipLaunchKernelGGL(k_splat_bwd_view<0>, g1, dim3(WG), 0, stream, d, params, s, rec);
-                hipLaunchKernelGGL(k_splat_bwd_reduce<0>, g2, dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad); break;
-        case 1: hipLaunchKernelGGL(k_splat_bwd_view<1>, g1, dim3(WG), 0, stream, d, params, s, rec);
-                hipLaunchKernelGGL(k_splat_bwd_reduce<1>, g2, dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad); break;
-        case 2: hipLaunchKernelGGL(k_splat_bwd_view<2>, g1, dim3(WG), 0, stream, d, params, s, rec);
-                hipLaunchKernelGGL(k_splat_bwd_reduce<2>, g2, dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad); break;
-        default: hipLaunchKernelGGL(k_splat_bwd_view<3>, g1, dim3(WG), 0, stream, d, params, s, rec);
-                 hipLaunchKernelGGL(k_splat_bwd_reduce<3>, g2, dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad); break;
+        case 0: launch_splat_avg_d<0>(d, params, s, samples, grad, items, n_pairs, n_singles, stream); break;
+        case 1: launch_splat_avg_d<1>(d, params, s, samples, grad, items, n_pairs, n_singles, stream); break;
+        case 2: launch_splat_avg_d<2>(d, params, s, samples, grad, items, n_pairs, n_singles, stream); break;
+        default: launch_splat_avg_d<3>(d, params, s, samples, grad, items, n_pairs, n_singles, stream); break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;
