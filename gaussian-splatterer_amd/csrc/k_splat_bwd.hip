@@ -240,13 +240,16 @@ template <int D> __device__ inline void sh_basis(float X, float Y, float Z, floa
 // runs the per-splat chain; the result is ONE 64-byte record per (pass, splat):
 //   mean(3) scale(3) rot(4) opacity(1) dL_dRGB(3, clamp-masked) pad(2).   Culled splats write zeros.
 // (Fusing the two passes of a camera into one thread was measured slower: 175 VGPRs, 2 waves/SIMD.)
-// Work items are the backward's {group, pass a, pass b}; `which` selects the pass of the item.
+// Work items are the backward's {group, pass a, pass b}.
 template <int D>
 __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __restrict__ params, Scratch s, float4* __restrict__ rec_out,
-                                                       const int* __restrict__ items, int which) {
+                                                       const int* __restrict__ items, int n_pairs) {
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
-    const int* item = items + 3 * blockIdx.y;
+    // blockIdx.y enumerates passes: the two passes of every pair item first, then the single items
+    const int y = blockIdx.y;
+    const int which = y < 2 * n_pairs ? (y & 1) : 0;
+    const int* item = items + 3 * (y < 2 * n_pairs ? (y >> 1) : (y - n_pairs));
     const int g = item[0];          // geometry group: records and slots live there
     const int v = item[1 + which];  // pass: gradient rows and the output record
     const Planes pl{ d.M };
@@ -332,11 +335,7 @@ static void launch_splat_avg_d(const Dims& d, const float* params, const Scratch
                                int n1, hipStream_t stream) {
     const int bx = (d.P + WG - 1) / WG;
     float4* rec = reinterpret_cast<float4*>(s.splat_grads);
-    if (n2 > 0) {
-        hipLaunchKernelGGL(k_splat_bwd_view<D>, dim3(bx, n2), dim3(WG), 0, stream, d, params, s, rec, items, 0);
-        hipLaunchKernelGGL(k_splat_bwd_view<D>, dim3(bx, n2), dim3(WG), 0, stream, d, params, s, rec, items, 1);
-    }
-    if (n1 > 0) hipLaunchKernelGGL(k_splat_bwd_view<D>, dim3(bx, n1), dim3(WG), 0, stream, d, params, s, rec, items + 3 * n2, 0);
+    if (2 * n2 + n1 > 0) hipLaunchKernelGGL(k_splat_bwd_view<D>, dim3(bx, 2 * n2 + n1), dim3(WG), 0, stream, d, params, s, rec, items, n2);
     hipLaunchKernelGGL(k_splat_bwd_reduce<D>, dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad);
 }
 
