@@ -25,6 +25,7 @@ static int g_opt_cull = 1;
 int option_cull() { return g_opt_cull; }
 static int g_opt_share = 1;
 int option_share_passes() { return g_opt_share; }
+static int g_opt_arena = 0;  // initial binning-arena entries per camera (0 = default max(2^20, 16 P))
 
 // grow-only device buffer
 struct DevBuf {
@@ -262,6 +263,7 @@ extern "C" int gs_set_option(const char* name, int value) {
     if (!name) return GS_ERR_INVALID_ARGUMENT;
     if (strcmp(name, "cull") == 0) { g_opt_cull = value != 0; return GS_OK; }
     if (strcmp(name, "share_camera_passes") == 0) { g_opt_share = value != 0; return GS_OK; }
+    if (strcmp(name, "arena_entries") == 0) { g_opt_arena = value > 0 ? value : 0; return GS_OK; }
     set_error("gs_set_option: unknown option '%s'", name);
     return GS_ERR_INVALID_ARGUMENT;
 }
@@ -542,7 +544,7 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
     // gradient planes (+ var), sized to the model's plane stride
     GS_TRY(t->grad.ensure((size_t)(pl.count() + 1) * m->Pa * 4));
     t->grad_Pa = m->Pa; t->grad_M = M;
-    if (t->Rcap == 0) t->Rcap = (uint32_t)std::max<long long>(1 << 20, 16LL * P);
+    if (t->Rcap == 0) t->Rcap = g_opt_arena ? (uint32_t)g_opt_arena : (uint32_t)std::max<long long>(1 << 20, 16LL * P);
     if (t->h_flags_cap < (size_t)V * 20) {
         if (t->h_flags) (void)hipHostFree(t->h_flags);
         t->h_flags = nullptr;

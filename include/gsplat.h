@@ -61,7 +61,9 @@ int gs_device_count(void);
  * are bit-identical either way (tests/test_gpu_raster.py checks exactly that).
  * "share_camera_passes" (default 1; read by gs_trainer_set_views): passes whose camera parameters are bit-identical
  * (the reference's white/black pair per camera, src/Trainer.cu:311-318) share projection, tile lists and the
- * forward blend; 0 recomputes them per pass like the reference.  Results are bit-identical either way. */
+ * forward blend; 0 recomputes them per pass like the reference.  Results are bit-identical either way.
+ * "arena_entries" (default 0 = max(2^20, 16*P)): initial capacity, in (splat, tile) entries per camera, of the binning
+ * arena of trainers created afterwards; when a step needs more the arena grows and the step is replayed. */
 int gs_set_option(const char* name, int value);
 /* Diagnostic: runs the backward kernel's 9-value wave reduce-scatter on one wave64.  in_host[q*64 + lane]
  * (q = 0..8), out_host[lane]: lane 2q of every 16-lane row holds the wave total of value q (q < 8), lane 1

@@ -216,3 +216,26 @@ def test_camera_pass_sharing_is_bit_identical(orc):
         assert np.array_equal(res[0][2][k].view(np.uint32), res[1][2][k].view(np.uint32)), k
     for a, b in zip(res[0][3], res[1][3]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_arena_overflow_grows_and_replays(orc):
+    """A binning arena that is too small is detected on the device, grown on the host and the step replayed before
+    the update is applied: results equal the run with an ample arena, and the statistics report the regrow."""
+    P, M, n_cams, W, H = 1200, 4, 2, 128, 128
+    res = []
+    for arena in (0, 1100):   # 1100 entries per camera is far below the ~6000 this scene needs
+        capi.check(capi.lib().gs_set_option(b"arena_entries", arena))
+        try:
+            s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 99)
+            st = tr.train(gs.Project(), stats=True)
+            res.append((st.arena_regrows, st.num_rendered, _read_grads(tr, P, M), _download(tr)))
+            st2 = tr.train(gs.Project(), stats=True)   # the grown arena is kept
+            assert st2.arena_regrows == 0
+            tr.close()
+        finally:
+            capi.check(capi.lib().gs_set_option(b"arena_entries", 0))
+    assert res[0][0] == 0 and res[1][0] >= 1 and res[0][1] == res[1][1] and res[1][1] // (2 * n_cams) > 1100
+    for k in res[0][2]:
+        assert np.array_equal(res[0][2][k].view(np.uint32), res[1][2][k].view(np.uint32)), k
+    for k in ("loc", "sh", "scale", "opac", "rot"):
+        assert np.array_equal(res[0][3][k].view(np.uint32), res[1][3][k].view(np.uint32)), k
