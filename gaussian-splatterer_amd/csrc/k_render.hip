@@ -46,15 +46,26 @@ __device__ inline bool block_reaches(float cx, float cy, float a, float b, float
     return (tau >= 0.0f) && !(qmin > tau);
 }
 
+// Staged entries carry the conic pre-scaled for the blend loop: the exponent is evaluated directly in base 2,
+//   log2(G) = dx * (ha*dx + nb*dy) + hc*dy*dy,   ha = -0.5*log2e*conic.x, nb = -log2e*conic.y, hc = -0.5*log2e*conic.z,
+// five VALU instructions instead of seven plus the log2e multiply in front of v_exp_f32; the scaling is done once
+// per staged entry instead of once per (entry, pixel) pair.  tau is scaled by log2e as well.
+constexpr float LOG2E = 1.4426950408889634f;
 template <int N> struct StagedTile {  // three 16-byte-strided arrays: one scalar address serves all reads of an entry
-    float4 A[N];  // x, y, conA, conB
-    float4 B[N];  // conC, opacity, r, g
-    float4 C[N];  // b, tau (cull threshold), -, depth
+    float4 A[N];  // x, y, ha, nb
+    float4 B[N];  // hc, opacity, r, g
+    float4 C[N];  // b, tau*log2e (cull threshold), -, depth
 };
 
 template <int N> __device__ inline void stage_entry(StagedTile<N>& t, int slot, const GeomRec* __restrict__ r) {
     const float4* q = reinterpret_cast<const float4*>(r);
-    t.A[slot] = q[0]; t.B[slot] = q[1]; t.C[slot] = q[2];
+    float4 a = q[0], b = q[1], c = q[2];
+    a.z *= -0.5f * LOG2E; a.w *= -LOG2E; b.x *= -0.5f * LOG2E; c.y *= LOG2E;
+    t.A[slot] = a; t.B[slot] = b; t.C[slot] = c;
+}
+// the conic back from a staged entry (flush of the backward kernel); exact up to one rounding
+__device__ inline void unscaled_conic(const float4& A, const float4& B, float& conA, float& conB, float& conC) {
+    conA = A.z * (-2.0f / LOG2E); conB = A.w * (-1.0f / LOG2E); conC = B.x * (-2.0f / LOG2E);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
             bool hit = false;
             if (j < cnt) {
                 const float4 a = st.A[j];
-                hit = block_reaches(a.x, a.y, a.z, a.w, st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
+                hit = block_reaches(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
             }
             unsigned long long mask = __ballot(hit);
             while (mask) {
@@ -107,8 +118,8 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
                 const float4 A = st.A[jj], B = st.B[jj];
                 const float cb = st.C[jj].x;
                 const float dx = A.x - pxf, dy = A.y - pyf;
-                const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                float alpha = fminf(ALPHA_MAX, B.y * __expf(power));
+                const float power = dx * (A.z * dx + A.w * dy) + B.x * dy * dy;  // log2 of the Gaussian weight
+                float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(power));
                 alpha = (power <= 0.0f) ? alpha : 0.0f;
                 alpha = (alpha >= ALPHA_MIN) ? alpha : 0.0f;
                 alpha *= live;
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s, const int*
             bool hit = false;
             if (j < cnt && (uint32_t)(base + j) < wave_max_last) {
                 const float4 a = st.A[j];
-                hit = block_reaches(a.x, a.y, a.z, a.w, st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
+                hit = block_reaches(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
             }
             unsigned long long mask = __ballot(hit);
             while (mask) {
@@ -414,8 +425,8 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s, const int*
                 asm volatile("" ::"v"(Bc.z), "v"(Bc.w), "v"(cbc));  // issue all three LDS reads up front, not inside the branch
                 const uint32_t pos = (uint32_t)(base + jj);  // upstream's `contributor` after its decrement
                 const float dx = Ac.x - pxf, dy = Ac.y - pyf;
-                const float power = -0.5f * (Ac.z * dx * dx + Bc.x * dy * dy) - Ac.w * dx * dy;
-                const float G = __expf(power);
+                const float power = dx * (Ac.z * dx + Ac.w * dy) + Bc.x * dy * dy;  // log2 of the Gaussian weight
+                const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(ALPHA_MAX, Bc.y * G);
                 const bool act = (pos < last_contributor) && power <= 0.0f && alpha >= ALPHA_MIN;
                 // Per lane only the colour terms and six moments of u = G * dL_dalpha are formed; the factors
@@ -469,6 +480,8 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s, const int*
             //   dL_dconic    = -0.5 op (S[u dx dx], S[u dx dy], S[u dy dy]),  dL_dopacity = S[u]
             const float4 Af = st.A[tid], Bf = st.B[tid];
             const float op = Bf.y, hop = -0.5f * op;
+            float conA, conB, conC;
+            unscaled_conic(Af, Bf, conA, conB, conC);
             const uint32_t slot = sSlot[tid];
 #pragma unroll
             for (int p = 0; p < K; p++) {
@@ -483,8 +496,8 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s, const int*
                         for (int q = 0; q < ACC_STRIDE; q++) sum[q] += a[q];
                     }
                 }
-                const float gmx = -ddelx_dx * op * (Af.z * sum[3] + Af.w * sum[4]);
-                const float gmy = -ddely_dy * op * (Bf.x * sum[4] + Af.w * sum[3]);
+                const float gmx = -ddelx_dx * op * (conA * sum[3] + conB * sum[4]);
+                const float gmy = -ddely_dy * op * (conC * sum[4] + conB * sum[3]);
                 float4* row = reinterpret_cast<float4*>(s.G + ((size_t)vp[p] * d.Rcap + slot) * G_STRIDE);
                 row[0] = make_float4(sum[0], sum[1], sum[2], gmx);
                 row[1] = make_float4(gmy, hop * sum[5], hop * sum[6], hop * sum[7]);

@@ -89,6 +89,7 @@ template <class R> struct ViewState {
     std::vector<R> final_T;
     std::vector<uint32_t> n_contrib;
     std::vector<float> margin;  // per-pixel fragility: min relative distance to a discrete threshold
+    std::vector<float> splat_margin;  // per-splat fragility: min margin over the pixels the splat is blended at
     int R_total = 0;
 };
 
@@ -254,6 +255,14 @@ template <class R> void render_forward(ViewState<R>& g, const R* bg, R* out_colo
     const int W = g.W, H = g.H;
     const size_t N = (size_t)W * H;
     g.final_T.assign(N, 0); g.n_contrib.assign(N, 0); g.margin.assign(N, 1.0f);
+    g.splat_margin.assign(g.P, 1.0f);
+    // lock-free min on non-negative floats (their bit patterns order like unsigned integers); tiles run in parallel
+    auto splat_min = [&](uint32_t id, float m) {
+        uint32_t* p = reinterpret_cast<uint32_t*>(&g.splat_margin[id]);
+        uint32_t nb; std::memcpy(&nb, &m, 4);
+        uint32_t cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+        while (nb < cur && !__atomic_compare_exchange_n(p, &cur, nb, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    };
     const int T = g.gx * g.gy;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int tile = 0; tile < T; tile++) {
@@ -273,10 +282,12 @@ template <class R> void render_forward(ViewState<R>& g, const R* bg, R* out_colo
                     const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                     if (power > R(0.0)) continue;
                     const R alpha = std::min(R(0.99), co[3] * std::exp(power));
-                    marg = std::min(marg, (float)(std::fabs(alpha - R(1.0 / 255.0)) * R(255.0)));
+                    const float ma = (float)(std::fabs(alpha - R(1.0 / 255.0)) * R(255.0));
+                    marg = std::min(marg, ma);
                     if (alpha < R(1.0) / R(255.0)) continue;
                     const R test_T = Tt * (R(1.0) - alpha);
-                    marg = std::min(marg, (float)(std::fabs(test_T - R(0.0001)) * R(10000.0)));
+                    const float mt = (float)(std::fabs(test_T - R(0.0001)) * R(10000.0));
+                    marg = std::min(marg, mt);
                     if (test_T < R(0.0001)) break;  // done: this entry is NOT applied
                     for (int c = 0; c < 3; c++) C[c] += g.rgb[3 * (size_t)id + c] * alpha * Tt;
                     Tt = test_T;
@@ -284,6 +295,16 @@ template <class R> void render_forward(ViewState<R>& g, const R* bg, R* out_colo
                 }
                 const size_t pix = (size_t)py * W + px;
                 g.final_T[pix] = Tt; g.n_contrib[pix] = last; g.margin[pix] = marg;
+                // A flipped decision at this pixel moves T / the colour recurrence of EVERY splat blended here, not
+                // only the one that flipped: the pixel's fragility is inherited by all entries that (nearly) reach it.
+                if (marg < 1e-2f)
+                    for (uint32_t k = beg; k < end; k++) {
+                        const uint32_t id = g.point_list[k];
+                        const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+                        const R* co = &g.conic_opacity[4 * (size_t)id];
+                        const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power <= R(0.0) && co[3] * std::exp(power) >= R(0.99 / 255.0)) splat_min(id, marg);
+                    }
                 for (int c = 0; c < 3; c++) out_color[c * N + pix] = C[c] + Tt * bg[c];
             }
     }
@@ -656,7 +677,7 @@ long orc_get(orc_state* s, const char* name, void* dst, long cap_bytes) {
     ORC_FIELD(depth) ORC_FIELD(means2D) ORC_FIELD(cov3D) ORC_FIELD(conic_opacity) ORC_FIELD(rgb) ORC_FIELD(radii)
     ORC_FIELD(tiles_touched) ORC_FIELD(point_offsets) ORC_FIELD(rect) ORC_FIELD(clamped) ORC_FIELD(keys_unsorted)
     ORC_FIELD(keys) ORC_FIELD(vals_unsorted) ORC_FIELD(point_list) ORC_FIELD(ranges) ORC_FIELD(final_T)
-    ORC_FIELD(n_contrib) ORC_FIELD(margin)
+    ORC_FIELD(n_contrib) ORC_FIELD(margin) ORC_FIELD(splat_margin)
 #undef ORC_FIELD
     if (!found || (long)bytes > cap_bytes) return -1;
     if (bytes) std::memcpy(dst, src, bytes);

@@ -58,7 +58,7 @@ _FIELDS = {
     "rgb": np.float32, "radii": np.int32, "tiles_touched": np.uint32, "point_offsets": np.uint32,
     "rect": np.uint32, "clamped": np.uint8, "keys_unsorted": np.uint64, "keys": np.uint64,
     "vals_unsorted": np.uint32, "point_list": np.uint32, "ranges": np.uint32, "final_T": np.float32,
-    "n_contrib": np.uint32, "margin": np.float32,
+    "n_contrib": np.uint32, "margin": np.float32, "splat_margin": np.float32,
 }
 
 

@@ -90,6 +90,12 @@ def test_backward_parity(orc, P, M, D, W, H, seed):
     g = sr.backward(dpix)
     og = r.backward(dpix, want_abs=True)
     abs9 = og["abs9"]  # per splat sum|term| of the nine pixel-stage sums
+    # Splats that take part in a (pixel, splat) pair within 1e-3 relative of one of the blend's discrete thresholds
+    # (alpha = 1/255, T = 1e-4) can gain or lose a whole pixel through a 1-ulp exp difference: the oracle flags them
+    # (`splat_margin`, inherited by every splat blended at such a pixel) and they are excluded; every other splat must
+    # meet the bar with no outliers.
+    firm = r.get("splat_margin") > 1e-3
+    assert firm.mean() > 0.9
     # pixel-stage sums: error budget is relative to sum|term| (fp32 summation), 1e-4 of it
     idx = {"dL_dcolor": ([0, 1, 2], 3, [0, 1, 2]), "dL_dmean2D": ([3, 4], 3, [0, 1]), "dL_dconic": ([5, 6, 7], 4, [0, 1, 3]),
            "dL_dopacity": ([8], 1, [0])}
@@ -98,11 +104,11 @@ def test_backward_parity(orc, P, M, D, W, H, seed):
         want = og[name].reshape(P, stride)
         for q, c in zip(qs, cols):
             tol = 1e-4 * np.maximum(abs9[:, q], 1e-3 * abs9[:, q].max() + 1e-30)
-            bad = np.abs(got[:, c].astype(np.float64) - want[:, c]) > tol
-            assert bad.mean() <= 0.002, (name, c, int(bad.sum()))
+            bad = (np.abs(got[:, c].astype(np.float64) - want[:, c]) > tol) & firm
+            assert not bad.any(), (name, c, int(bad.sum()))
     # per-splat chain outputs: 1e-4 relative to the array scale
-    for name in ["dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"]:
-        assert_close_rel(name, g[name], og[name], rtol=1e-4, floor=None, max_bad_frac=0.002)
+    for name, stride in [("dL_dmean3D", 3), ("dL_dcov3D", 6), ("dL_dsh", 3 * M), ("dL_dscale", 3), ("dL_drot", 4)]:
+        assert_close_rel(name, g[name].reshape(P, stride)[firm], og[name].reshape(P, stride)[firm], rtol=1e-4, floor=None, max_bad_frac=0.002)
     # culled splats: all nine buffers exactly zero (src/Trainer.cu:366-375 + radii>0 guard)
     culled = r.get("radii") <= 0
     if culled.any():
