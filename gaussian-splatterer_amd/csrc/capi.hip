@@ -115,7 +115,7 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
 }
 
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, zero_block, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads;
+    DevBuf views, geom, tiles, offsets, tloss, zero_block, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads;
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
     Scratch s{};
@@ -141,6 +141,7 @@ struct ScratchSet {
         GS_TRY(coarse_end.ensure(v * NST * 4));
         GS_TRY(tile_count.ensure(v * T * 4));
         GS_TRY(tile_end.ensure(v * T * 4));
+        GS_TRY(tloss.ensure(v * T * 4));
         GS_TRY(clist.ensure(v * Rcap * 16));
         GS_TRY(cdepth.ensure(v * Rcap * 4));
         GS_TRY(ids.ensure(v * Rcap * 4));
@@ -150,7 +151,9 @@ struct ScratchSet {
         GS_TRY(color.ensure(v * 3 * N * 4));
         GS_TRY(finalT.ensure(v * N * 4));
         GS_TRY(ncontrib.ensure(v * N * 4));
-        GS_TRY(scan_tmp.ensure((scan_partials_count(Pa, (int)v) + scan_partials_count(T, (int)v) + scan_partials_count(NST, (int)v) + 64) * 4));
+        // [block_sums: v x splat_blocks(Pa)] [partials of the three-phase scan, used only past g_scan_single_max items]
+        GS_TRY(scan_tmp.ensure((v * splat_blocks(Pa) + scan_partials_count(std::max(T, NST), (int)v) + 64) * 4));
+        s.block_sums = scan_tmp.as<uint32_t>();
         if (want_splat_grads) GS_TRY(sgrads.ensure(v * Pa * 64));
         s.splat_grads = sgrads.as<float>();
         set_view_block_pointers(s, views.as<char>(), (int)v);
@@ -160,7 +163,8 @@ struct ScratchSet {
         s.coarse_count = zero_block.as<uint32_t>();
         s.coarse_cursor = s.coarse_count + v * NST;
         s.flags = s.coarse_cursor + v * NST;
-        s.loss = reinterpret_cast<float*>(s.flags + v * 4);
+        s.loss_total = reinterpret_cast<float*>(s.flags + v * 4);
+        s.loss = tloss.as<float>();
         s.coarse_end = coarse_end.as<uint32_t>();
         s.tile_count = tile_count.as<uint32_t>();
         s.tile_end = tile_end.as<uint32_t>();
@@ -178,28 +182,28 @@ struct ScratchSet {
         return GS_OK;
     }
     void release() {
-        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &zero_block, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &color,
+        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &zero_block, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &color,
                            &finalT, &ncontrib, &scan_tmp, &sgrads })
             b->release();
     }
 };
 
-// projection + the per-splat and per-super-tile scans (everything that does not need the binning arena)
-static int stage_project(const Dims& d, const float* params, const Scratch& s, uint32_t* scan_tmp, hipStream_t st) {
+// projection + everything that does not need the binning arena: the block prefixes of the offsets scan (entry count and
+// overflow bit land in flags) and the super-tile scan.  Runs for P == 0 too (the scans then define empty lists).
+static int stage_project(const Dims& d, const float* params, const Scratch& s, hipStream_t st) {
     GS_TRY(launch_preprocess(d, params, s, st));
-    GS_TRY(launch_scan_u32(s.tiles_touched, s.point_offsets, d.P, d.Pa, d.V, scan_tmp, st));
+    GS_TRY(launch_project_scans(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), st));
     return GS_OK;
 }
-// coarse scan + scatter, per-tile counts + scan.  Runs for P == 0 too (the scans then define empty lists).
-static int stage_bin(const Dims& d, const Scratch& s, uint32_t* scan_tmp, hipStream_t st) {
-    GS_TRY(launch_scan_u32(s.coarse_count, s.coarse_end, d.NST * CGROUPS, d.NST * CGROUPS, d.V, scan_tmp + scan_partials_count(d.Pa, d.V), st));
+// coarse scatter (finishes the offsets scan), per-tile counts + scan
+static int stage_bin(const Dims& d, const Scratch& s, hipStream_t st) {
     GS_TRY(launch_coarse_scatter(d, s, st));
     GS_TRY(launch_tile_count(d, s, st));
-    GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.V, scan_tmp + scan_partials_count(d.Pa, d.V) + scan_partials_count(d.NST * CGROUPS, d.V), st));
+    GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.VG, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), st));
     return GS_OK;
 }
-static int stage_bin_render(const Dims& d, const Scratch& s, uint32_t* scan_tmp, hipStream_t st) {
-    GS_TRY(stage_bin(d, s, scan_tmp, st));
+static int stage_bin_render(const Dims& d, const Scratch& s, hipStream_t st) {
+    GS_TRY(stage_bin(d, s, st));
     GS_TRY(launch_tile_build_sort(d, s, st));
     GS_TRY(launch_render_forward(d, s, st));
     return GS_OK;
@@ -264,6 +268,7 @@ extern "C" int gs_set_option(const char* name, int value) {
     if (strcmp(name, "cull") == 0) { g_opt_cull = value != 0; return GS_OK; }
     if (strcmp(name, "share_camera_passes") == 0) { g_opt_share = value != 0; return GS_OK; }
     if (strcmp(name, "arena_entries") == 0) { g_opt_arena = value > 0 ? value : 0; return GS_OK; }
+    if (strcmp(name, "scan_single_max") == 0) { gs::g_scan_single_max = value > 0 ? value : (1 << 16); return GS_OK; }
     set_error("gs_set_option: unknown option '%s'", name);
     return GS_ERR_INVALID_ARGUMENT;
 }
@@ -349,6 +354,7 @@ extern "C" int gs_model_clone(const gs_model* src, gs_model** out) {
     gs_model* m = nullptr;
     GS_TRY(model_alloc(src->capacity, src->sh_degree, src->sh_coeffs, src->count, &m));
     const size_t bytes = (size_t)(11 + 3 * src->sh_coeffs) * src->Pa * sizeof(float);
+    (void)hipDeviceSynchronize();  // a trainer may still be updating the source on its own (non-blocking) stream
     hipError_t e = hipMemcpy(m->planes, src->planes, bytes, hipMemcpyDeviceToDevice);
     if (e != hipSuccess) { gs_model_destroy(m); set_error("clone copy failed: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
     *out = m;
@@ -361,6 +367,7 @@ extern "C" int gs_model_download(const gs_model* m, float* loc, float* sh, float
     if (count == 0) return GS_OK;
     if (!loc || !sh || !scale || !opac || !rot) { set_error("gs_model_download: null destination"); return GS_ERR_INVALID_ARGUMENT; }
     const size_t nf = (size_t)count * (11 + 3 * M);
+    GS_HIP(hipDeviceSynchronize());  // a trainer may still be updating these planes on its own (non-blocking) stream
     float* stage = nullptr;
     GS_HIP(hipMalloc((void**)&stage, nf * sizeof(float)));
     float* dl = stage; float* dsh = dl + 3 * (size_t)count; float* dsc = dsh + 3 * (size_t)M * count;
@@ -409,6 +416,9 @@ struct gs_trainer {
     ScratchSet train, preview;
     uint32_t* h_flags = nullptr;  // pinned, [V][4] + loss[V]
     size_t h_flags_cap = 0;
+    hipEvent_t ev_flags = nullptr;   // recorded behind the early copy of the overflow flags
+    const void* views_on_device = nullptr;  // where the current view block was last uploaded (null: must upload)
+    bool stats_stale = false;        // `last` lacks the device-side numbers (loss, list lengths) of the newest step
     uint32_t Rcap = 0;
     gs_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
@@ -418,7 +428,10 @@ struct gs_trainer {
     bool profiling = false;
     struct Pending { int stage; hipEvent_t a, b; };
     std::vector<Pending> pending;
-    std::vector<hipEvent_t> event_pool;
+    std::vector<hipEvent_t> event_pool, marks;
+    hipEvent_t prev_mark = nullptr, stage_start = nullptr;
+    int prev_mark_stage = -1;
+    unsigned profiling_mask = 0;  // bit s: stage s is timed
     double stage_ms[GS_STAGE_COUNT] = { 0 };
     long long stage_launches[GS_STAGE_COUNT] = { 0 };
 };
@@ -432,26 +445,37 @@ hipEvent_t prof_event(gs_trainer* t) {
     else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
     return e;
 }
-struct StageTimer {  // records an event pair around one stage on the trainer's stream when profiling is on
-    gs_trainer* t; int stage; hipEvent_t a = nullptr;
-    StageTimer(gs_trainer* t_, int stage_) : t(t_), stage(stage_) {
-        if (t->profiling && (a = prof_event(t))) (void)hipEventRecord(a, t->stream);
-    }
-    ~StageTimer() {
-        if (!a) return;
-        hipEvent_t b = prof_event(t);
-        if (!b) { t->event_pool.push_back(a); return; }
-        (void)hipEventRecord(b, t->stream);
-        t->pending.push_back({ stage, a, b });
-    }
-};
+// Per-stage timing on the trainer's stream.  An event costs ~3 us of stream time on MI355X, so a stage's start
+// reuses the end event of the stage that ran directly before it when that one was timed too, and stages outside
+// the profiling mask record nothing at all.
+void prof_stage_begin(gs_trainer* t, int stage, int stage_before) {
+    if (!(t->profiling_mask >> stage & 1u)) return;
+    if (t->prev_mark && t->prev_mark_stage == stage_before) { t->stage_start = t->prev_mark; return; }
+    hipEvent_t e = prof_event(t);
+    t->stage_start = e;
+    if (!e) return;
+    (void)hipEventRecord(e, t->stream);
+    t->marks.push_back(e);
+}
+void prof_stage_end(gs_trainer* t, int stage) {
+    if (!(t->profiling_mask >> stage & 1u) || !t->stage_start) return;
+    hipEvent_t e = prof_event(t);
+    if (!e) { t->prev_mark = nullptr; return; }
+    (void)hipEventRecord(e, t->stream);
+    t->marks.push_back(e);
+    t->pending.push_back({ stage, t->stage_start, e });
+    t->prev_mark = e; t->prev_mark_stage = stage;
+    t->stage_start = nullptr;
+}
 void prof_resolve(gs_trainer* t) {  // caller has synchronised the stream
     for (auto& p : t->pending) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { t->stage_ms[p.stage] += ms; t->stage_launches[p.stage]++; }
-        t->event_pool.push_back(p.a); t->event_pool.push_back(p.b);
     }
     t->pending.clear();
+    for (hipEvent_t e : t->marks) t->event_pool.push_back(e);
+    t->marks.clear();
+    t->prev_mark = nullptr; t->stage_start = nullptr;
 }
 }  // namespace
 
@@ -480,6 +504,7 @@ extern "C" int gs_trainer_destroy(gs_trainer* t) {
     t->truth.release(); t->grad.release(); t->adam_m.release(); t->adam_v.release();
     t->train.release(); t->preview.release();
     if (t->h_flags) (void)hipHostFree(t->h_flags);
+    if (t->ev_flags) (void)hipEventDestroy(t->ev_flags);
     prof_resolve(t);
     for (hipEvent_t e : t->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(t->stream);
@@ -521,6 +546,8 @@ extern "C" int gs_trainer_set_views(gs_trainer* t, int n_views, const gs_view* v
     }
     t->total_samples = total_samples;
     t->accumulated = false;
+    t->views_on_device = nullptr;
+    t->stats_stale = false;
     return GS_OK;
 }
 
@@ -531,14 +558,44 @@ static int trainer_dims(gs_trainer* t, Dims* d) {
     return GS_OK;
 }
 
-extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
-    if (!t) return GS_ERR_INVALID_ARGUMENT;
+// The device-side numbers of the newest step (loss, entry counts, longest tile list) are fetched on demand, so a step
+// nobody asks about costs no end-of-step synchronisation.
+static int resolve_stats(gs_trainer* t) {
+    GS_HIP(hipStreamSynchronize(t->stream));
+    prof_resolve(t);
+    if (!t->stats_stale) return GS_OK;
+    const int V = t->V;
+    if (t->model && t->model->count > 0) {  // an empty model ran no backward pass: its loss statistic stays zero
+        Dims d;
+        GS_TRY(trainer_dims(t, &d));
+        GS_TRY(launch_loss_sum(d, t->train.s, t->stream));
+        GS_HIP(hipStreamSynchronize(t->stream));
+    }
+    GS_HIP(hipMemcpy(t->h_flags, t->train.s.flags, (size_t)V * 20, hipMemcpyDeviceToHost));
+    gs_step_stats& st = t->last;
+    st.num_rendered = 0; st.max_tile_list = 0;
+    for (int g = 0; g < t->VG; g++) st.max_tile_list = std::max(st.max_tile_list, (int)t->h_flags[g * 4 + 1]);
+    for (int v = 0; v < V; v++) st.num_rendered += t->h_flags[t->h_view_group[v] * 4 + 2];  // R of every pass, as the reference counts
+    const float* hl = reinterpret_cast<const float*>(t->h_flags + (size_t)V * 4);
+    double L = 0;
+    for (int v = 0; v < V; v++) L += hl[v];
+    st.loss = (float)L;
+    t->stats_stale = false;
+    return GS_OK;
+}
+
+// Launches one iteration's projection, binning, forward, loss and backward for all passes and leaves the averaged
+// gradients in t->grad.  The only host wait is on the arena-overflow flags, which the device publishes right after the
+// projection (a few tens of microseconds into the step, while the rest of the step is already queued behind it): on
+// return the stream is still busy.  An overflowing arena is grown and the iteration replayed.
+static int accumulate_async(gs_trainer* t) {
     if (t->V == 0) { set_error("Can't run training iteration, no truth data available!"); return GS_ERR_NO_TRUTH; }
     if (!t->model) return GS_ERR_NO_MODEL;
     GS_HIP(hipSetDevice(t->device));
     gs_model* m = t->model;
     const int P = m->count, M = m->sh_coeffs, V = t->V;
     const Planes pl{ M };
+    if (t->pending.size() > 4096) { GS_HIP(hipStreamSynchronize(t->stream)); prof_resolve(t); }
     gs_step_stats st{};
     st.count_before = st.count_after = P; st.views = V;
     // gradient planes (+ var), sized to the model's plane stride
@@ -546,11 +603,13 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
     t->grad_Pa = m->Pa; t->grad_M = M;
     if (t->Rcap == 0) t->Rcap = g_opt_arena ? (uint32_t)g_opt_arena : (uint32_t)std::max<long long>(1 << 20, 16LL * P);
     if (t->h_flags_cap < (size_t)V * 20) {
+        GS_HIP(hipStreamSynchronize(t->stream));
         if (t->h_flags) (void)hipHostFree(t->h_flags);
         t->h_flags = nullptr;
         GS_HIP(hipHostMalloc((void**)&t->h_flags, (size_t)V * 20));
         t->h_flags_cap = (size_t)V * 20;
     }
+    if (!t->ev_flags) GS_HIP(hipEventCreateWithFlags(&t->ev_flags, hipEventDisableTiming));
     for (;;) {
         Dims d;
         GS_TRY(trainer_dims(t, &d));
@@ -558,50 +617,63 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
         d.Rcap = t->train.Rcap;
         Scratch s = t->train.s;
         s.truth = t->truth.as<uint32_t>();
-        GS_HIP(hipMemcpyAsync((void*)s.views, t->h_view_block.data(), t->h_view_block.size(), hipMemcpyHostToDevice, t->stream));
-        GS_HIP(hipMemsetAsync(t->train.zero_block.p, 0, t->train.zero_bytes, t->stream));
-        if (P > 0) {
-            uint32_t* tmp = t->train.scan_tmp.as<uint32_t>();
-            { StageTimer tm(t, 0); GS_TRY(launch_preprocess(d, m->planes, s, t->stream)); }
-            { StageTimer tm(t, 1); GS_TRY(launch_scan_u32(s.tiles_touched, s.point_offsets, d.P, d.Pa, d.V, tmp, t->stream)); }
-            { StageTimer tm(t, 2); GS_TRY(stage_bin(d, s, tmp, t->stream)); }
-            { StageTimer tm(t, 3); GS_TRY(launch_tile_build_sort(d, s, t->stream)); }
-            { StageTimer tm(t, 4); GS_TRY(launch_render_forward(d, s, t->stream)); }
-            const int* items = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.views) + view_block_items_offset(V));
-            { StageTimer tm(t, 5); GS_TRY(launch_render_backward(d, s, items, t->bwd_pairs, t->bwd_singles, t->stream)); }
-            { StageTimer tm(t, 6);
-              GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), items, t->bwd_pairs,
-                                               t->bwd_singles, t->stream)); }
-        } else {  // empty model: tile lists are empty, the image is the background
-            GS_TRY(stage_bin(d, s, t->train.scan_tmp.as<uint32_t>(), t->stream));
-            GS_TRY(launch_render_forward(d, s, t->stream));
+        if (t->views_on_device != (const void*)s.views) {  // the view block only changes with gs_trainer_set_views
+            GS_HIP(hipMemcpyAsync((void*)s.views, t->h_view_block.data(), t->h_view_block.size(), hipMemcpyHostToDevice, t->stream));
+            t->views_on_device = (const void*)s.views;
         }
-        GS_HIP(hipMemcpyAsync(t->h_flags, s.flags, (size_t)V * 20, hipMemcpyDeviceToHost, t->stream));
-        GS_HIP(hipStreamSynchronize(t->stream));
-        prof_resolve(t);
+        GS_HIP(hipMemsetAsync(t->train.zero_block.p, 0, t->train.zero_bytes, t->stream));
+        prof_stage_begin(t, 0, -1);
+        GS_TRY(launch_preprocess(d, m->planes, s, t->stream));
+        prof_stage_end(t, 0);
+        prof_stage_begin(t, 1, 0);
+        GS_TRY(launch_project_scans(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), t->stream));
+        GS_HIP(hipMemcpyAsync(t->h_flags, s.flags, (size_t)t->VG * 16, hipMemcpyDeviceToHost, t->stream));
+        GS_HIP(hipEventRecord(t->ev_flags, t->stream));
+        prof_stage_end(t, 1);  // the scans and the publication of their overflow verdict
+        prof_stage_begin(t, 2, 1);
+        GS_TRY(stage_bin(d, s, t->stream));
+        prof_stage_end(t, 2);
+        prof_stage_begin(t, 3, 2);
+        GS_TRY(launch_tile_build_sort(d, s, t->stream));
+        prof_stage_end(t, 3);
+        prof_stage_begin(t, 4, 3);
+        GS_TRY(launch_render_forward(d, s, t->stream));
+        prof_stage_end(t, 4);
+        if (P > 0) {  // an empty model has no gradients: its image is the background, its loss the residual against it
+            const int* items = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.views) + view_block_items_offset(V));
+            prof_stage_begin(t, 5, 4);
+            GS_TRY(launch_render_backward(d, s, items, t->bwd_pairs, t->bwd_singles, t->stream));
+            prof_stage_end(t, 5);
+            prof_stage_begin(t, 6, 5);
+            GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), items, t->bwd_pairs,
+                                             t->bwd_singles, t->stream));
+            prof_stage_end(t, 6);
+        }
+        GS_HIP(hipEventSynchronize(t->ev_flags));
         bool overflow = false;
         uint32_t need = 0;
-        st.num_rendered = 0; st.max_tile_list = 0;
         for (int g = 0; g < t->VG; g++) {
             if (t->h_flags[g * 4 + 0] & 1u) overflow = true;
             need = std::max(need, t->h_flags[g * 4 + 2]);
-            st.max_tile_list = std::max(st.max_tile_list, (int)t->h_flags[g * 4 + 1]);
         }
-        for (int v = 0; v < V; v++) st.num_rendered += t->h_flags[t->h_view_group[v] * 4 + 2];  // R of every pass, as the reference counts
-        if (!overflow) {
-            const float* hl = reinterpret_cast<const float*>(t->h_flags + (size_t)V * 4);
-            double L = 0;
-            for (int v = 0; v < V; v++) L += hl[v];
-            st.loss = (float)L;
-            break;
-        }
+        if (!overflow) break;
+        GS_HIP(hipStreamSynchronize(t->stream));  // the overflowed groups' later stages are no-ops; drain them before regrowing
+        prof_resolve(t);
         t->Rcap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)need + need / 4 + 1024);
         st.arena_regrows++;
         if (st.arena_regrows > 8) { set_error("binning arena failed to converge"); return GS_ERR_INTERNAL; }
     }
     t->last = st;
+    t->stats_stale = true;
     t->accumulated = true;
-    if (stats) *stats = st;
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    GS_TRY(accumulate_async(t));
+    GS_TRY(resolve_stats(t));  // callers of the split API read the gradient buffer next: hand it over complete
+    if (stats) *stats = t->last;
     return GS_OK;
 }
 
@@ -646,7 +718,6 @@ extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, g
     GS_HIP(hipSetDevice(t->device));
     gs_model* m = t->model;
     const Planes pl{ m->sh_coeffs };
-    gs_step_stats st = t->last;
     if (h->update_rule == GS_UPDATE_ADAM) {
         const size_t bytes = (size_t)pl.count() * m->Pa * 4;
         if (!t->adam_valid) {
@@ -660,24 +731,29 @@ extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, g
         set_error("unknown update rule %d", h->update_rule);
         return GS_ERR_INVALID_ARGUMENT;
     }
-    { StageTimer tm(t, 7);
-      GS_TRY(launch_update(pl, m->count, m->Pa, m->planes, t->grad.as<float>(), t->adam_m.as<float>(), t->adam_v.as<float>(),
-                           t->adam_t, *h, t->stream)); }
+    prof_stage_begin(t, 7, t->allreduce ? 8 : 6);
+    GS_TRY(launch_update(pl, m->count, m->Pa, m->planes, t->grad.as<float>(), t->adam_m.as<float>(), t->adam_v.as<float>(),
+                         t->adam_t, *h, t->stream));
+    prof_stage_end(t, 7);
     t->accumulated = false;
-    if (densify) GS_TRY(trainer_densify(t, h, &st));
-    if (stats) { GS_HIP(hipStreamSynchronize(t->stream)); *stats = st; }
-    t->last = st;
+    if (densify) {
+        GS_TRY(resolve_stats(t));
+        GS_TRY(trainer_densify(t, h, &t->last));
+    }
+    if (stats) { GS_TRY(resolve_stats(t)); *stats = t->last; }
     return GS_OK;
 }
 
 extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs_step_stats* stats) {
     if (!t || !h) return GS_ERR_INVALID_ARGUMENT;
-    GS_TRY(gs_trainer_accumulate(t, nullptr));
+    GS_TRY(accumulate_async(t));
     if (t->allreduce) {
         float* buf = nullptr; size_t n = 0;
         GS_TRY(gs_trainer_grad_buffer(t, &buf, &n));
         int rc;
-        { StageTimer tm(t, 8); rc = t->allreduce(buf, n, (void*)t->stream, t->allreduce_user); }
+        prof_stage_begin(t, 8, 6);
+        rc = t->allreduce(buf, n, (void*)t->stream, t->allreduce_user);
+        prof_stage_end(t, 8);
         if (rc != 0) { set_error("all-reduce hook failed with %d", rc); return GS_ERR_INTERNAL; }
     }
     return gs_trainer_apply(t, h, densify, stats);
@@ -704,6 +780,8 @@ extern "C" int gs_trainer_set_profiling(gs_trainer* t, int enable) {
     GS_HIP(hipStreamSynchronize(t->stream));
     prof_resolve(t);
     t->profiling = enable != 0;
+    t->profiling_mask = enable == 1 ? ~0u : (unsigned)enable >> 1;
+    t->prev_mark = nullptr; t->stage_start = nullptr;
     for (int i = 0; i < GS_STAGE_COUNT; i++) { t->stage_ms[i] = 0; t->stage_launches[i] = 0; }
     return GS_OK;
 }
@@ -742,13 +820,8 @@ extern "C" int gs_trainer_render(gs_trainer* t, uint32_t* fb, int fb_on_device, 
         GS_HIP(hipMemcpyAsync((void*)s.views, vb.data(), vb.size(), hipMemcpyHostToDevice, t->stream));
         GS_HIP(hipStreamSynchronize(t->stream));  // vb is a stack-lifetime staging buffer
         GS_HIP(hipMemsetAsync(t->preview.zero_block.p, 0, t->preview.zero_bytes, t->stream));
-        if (m->count > 0) {
-            GS_TRY(stage_project(d, m->planes, s, t->preview.scan_tmp.as<uint32_t>(), t->stream));
-            GS_TRY(stage_bin_render(d, s, t->preview.scan_tmp.as<uint32_t>(), t->stream));
-        } else {
-            GS_TRY(stage_bin(d, s, t->preview.scan_tmp.as<uint32_t>(), t->stream));
-            GS_TRY(launch_render_forward(d, s, t->stream));
-        }
+        GS_TRY(stage_project(d, m->planes, s, t->stream));  // an empty model gives empty lists and the background image
+        GS_TRY(stage_bin_render(d, s, t->stream));
         uint32_t flags[4];
         GS_HIP(hipMemcpyAsync(flags, s.flags, 16, hipMemcpyDeviceToHost, t->stream));
         GS_HIP(hipStreamSynchronize(t->stream));
@@ -798,7 +871,7 @@ GeomLayout geom_layout(int P, int M, int W = 16, int H = 16) {
     {
         const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
         const int T = gx * gy, NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE) * CGROUPS;
-        L.scan_tmp = o; o = al(o + (scan_partials_count(L.Pa, 1) + scan_partials_count(T, 1) + scan_partials_count(NST, 1) + 64) * 4);
+        L.scan_tmp = o; o = al(o + (splat_blocks(L.Pa) + scan_partials_count(std::max(T, NST), 1) + 64) * 4);
     }
     L.view = o; o = al(o + view_block_bytes(1));
     L.flags = o; o = al(o + 32);
@@ -843,6 +916,7 @@ Scratch seam_scratch(char* geom, const GeomLayout& g, char* img, const ImageLayo
     s.geom = reinterpret_cast<GeomRec*>(geom + g.record);
     s.tiles_touched = reinterpret_cast<uint32_t*>(geom + g.tiles);
     s.point_offsets = reinterpret_cast<uint32_t*>(geom + g.offsets);
+    s.block_sums = reinterpret_cast<uint32_t*>(geom + g.scan_tmp);
     s.flags = reinterpret_cast<uint32_t*>(geom + g.flags);
     s.coarse_count = reinterpret_cast<uint32_t*>(img + im.coarse_count);
     s.coarse_cursor = reinterpret_cast<uint32_t*>(img + im.coarse_cursor);
@@ -937,13 +1011,13 @@ extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_u
     GS_HIP(hipMemsetAsync(geom + gl.flags, 0, 32, st));
     float* planes = reinterpret_cast<float*>(geom + gl.planes);
     GS_TRY(launch_aos_to_soa(P, gl.Pa, M, means3D, shs, scales, opacities, rotations, planes, st));
-    Dims d = make_dims(P, gl.Pa, D, M, width, height, 1, 1, scale_modifier);
+    Dims d = make_dims(P, gl.Pa, D, M, width, height, 1, 0xFFFFFFFFu, scale_modifier);  // no arena yet: nothing can overflow
     int R = 0;
+    GS_TRY(stage_project(d, planes, s, st));
     if (P > 0) {
-        GS_TRY(stage_project(d, planes, s, reinterpret_cast<uint32_t*>(geom + gl.scan_tmp), st));
         // the reference reads num_rendered back here too (a device->host sync)
         uint32_t r32 = 0;
-        GS_HIP(hipMemcpyAsync(&r32, s.point_offsets + (P - 1), 4, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipMemcpyAsync(&r32, s.flags + 2, 4, hipMemcpyDeviceToHost, st));
         GS_HIP(hipStreamSynchronize(st));
         R = (int)r32;
     }
@@ -953,7 +1027,7 @@ extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_u
     s = seam_scratch(geom, gl, img, il, bin, &bl);
     s.out_color = out_color;
     d.Rcap = bl.Rcap;
-    GS_TRY(stage_bin_render(d, s, reinterpret_cast<uint32_t*>(geom + gl.scan_tmp), st));  // P == 0: empty lists, background image
+    GS_TRY(stage_bin_render(d, s, st));  // P == 0: empty lists, background image
     GS_TRY(launch_ranges(d, s, reinterpret_cast<uint32_t*>(img + il.ranges), st));
     GS_HIP(hipStreamSynchronize(st));
     if (num_rendered) *num_rendered = R;

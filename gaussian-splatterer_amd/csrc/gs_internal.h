@@ -91,6 +91,7 @@ struct Scratch {
     GeomRec* geom;             // [V][Pa]
     uint32_t* tiles_touched;   // [V][Pa]
     uint32_t* point_offsets;   // [V][Pa]  inclusive scan of tiles_touched
+    uint32_t* block_sums;      // [G][splat_blocks(Pa)] tiles_touched summed per 256-splat block, then its exclusive prefix
     uint32_t* coarse_count;    // [V][NST*CGROUPS] splats per (super-tile, splat group) (zeroed each step)
     uint32_t* coarse_cursor;   // [V][NST*CGROUPS] (zeroed each step)
     uint32_t* coarse_end;      // [V][NST*CGROUPS] inclusive scan of coarse_count (super-tile major: a super-tile's list is contiguous)
@@ -109,19 +110,28 @@ struct Scratch {
     const uint32_t* truth;     // [V][N] or null
     const float* dL_dpix;      // [V][3][N] or null (then loss = truth/255 - colour is fused)
     uint32_t* flags;           // [V][4]: 0 overflow, 1 max tile list
-    float* loss;               // [V] sum of residual^2 (only when truth != null)
+    float* loss;               // [V][T] per-tile sum of residual^2 (only when truth != null); launch_loss_sum folds it
+    float* loss_total;         // [V]
 };
 
 // ---------------------------------------------------------------------------------------------
 // kernel launchers (one translation unit each)
 // ---------------------------------------------------------------------------------------------
 int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st);
+// after preprocess, one launch: prefix of the per-block tile sums (-> flags: num_rendered, arena overflow) and the
+// inclusive scan of the super-tile counters
+int launch_project_scans(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st);
+// batched inclusive scan of u32: one workgroup per batch entry up to g_scan_single_max items, three phases beyond
 int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int batch, uint32_t* partials, hipStream_t st);
 size_t scan_partials_count(int n, int batch);
+extern int g_scan_single_max;
+__host__ __device__ inline int splat_blocks(int Pa) { return (Pa + WG - 1) / WG; }
 int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t st);
+// loss_total[v] = sum over tiles of loss[v][tile], in a fixed order (the statistic is reproducible bit for bit)
+int launch_loss_sum(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_backward(const Dims& d, const Scratch& s, const int* items, int n_pairs, int n_singles, hipStream_t st);
 // Trainer form: loops the views, writes the averaged-gradient planes (incl. var) once.
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad_planes, const int* items,

@@ -16,7 +16,7 @@
 namespace gs {
 
 // ---------------------------------------------------------------------------------------------
-// batched inclusive scan of u32 (three phases; block = 256 threads x 16 items)
+// batched inclusive scans of u32 (block = 256 threads x 16 items)
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_BLOCK = WG * SCAN_ITEMS;
@@ -86,36 +86,99 @@ __global__ __launch_bounds__(WG) void k_scan_final(const uint32_t* __restrict__ 
     for (int k = 0; k < SCAN_ITEMS; k++) { run += v[k]; if (base + k < n) dst[base + k] = run; }
 }
 
+// One workgroup scans one batch entry, SCAN_BLOCK items per trip with a running carry.  The scans of a step are short
+// (super-tile counters, tile counts: 4096 items per view at 1024x1024), so a single launch per scan beats the
+// three-phase form, whose three launches cost more than the work.
+__device__ inline void scan_single(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n) {
+    uint32_t carry = 0;
+    for (int base0 = 0; base0 < n; base0 += SCAN_BLOCK) {
+        const int base = base0 + threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (base + k < n) ? src[base + k] : 0; sum += v[k]; }
+        uint32_t total;
+        uint32_t run = carry + block_excl_scan(sum, &total);
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { run += v[k]; if (base + k < n) dst[base + k] = run; }
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_scan_single(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n, int stride) {
+    scan_single(in + (size_t)blockIdx.x * stride, out + (size_t)blockIdx.x * stride, n);
+}
+
+int g_scan_single_max = 1 << 16;
+
 int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int batch, uint32_t* partials, hipStream_t st) {
     if (n == 0 || batch == 0) return GS_OK;
-    const int nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nb, batch), dim3(WG), 0, st, in, n, stride, partials);
-    hipLaunchKernelGGL(k_scan_partials, dim3(batch), dim3(WG), 0, st, partials, nb);
-    hipLaunchKernelGGL(k_scan_final, dim3(nb, batch), dim3(WG), 0, st, in, out, n, stride, (const uint32_t*)partials);
+    if (n <= g_scan_single_max) {
+        hipLaunchKernelGGL(k_scan_single, dim3(batch), dim3(WG), 0, st, in, out, n, stride);
+    } else {
+        const int nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        hipLaunchKernelGGL(k_scan_reduce, dim3(nb, batch), dim3(WG), 0, st, in, n, stride, partials);
+        hipLaunchKernelGGL(k_scan_partials, dim3(batch), dim3(WG), 0, st, partials, nb);
+        hipLaunchKernelGGL(k_scan_final, dim3(nb, batch), dim3(WG), 0, st, in, out, n, stride, (const uint32_t*)partials);
+    }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
 
+// After preprocess, per geometry group: blockIdx.y == 0 turns the per-block tile sums into exclusive prefixes and
+// publishes the group's entry count (flags[2]) and the arena-overflow bit (flags[0]); blockIdx.y == 1 scans the
+// super-tile counters (unless they are too many for one workgroup: then launch_project_scans scans them separately).
+__global__ __launch_bounds__(WG) void k_project_scans(Dims d, Scratch s) {
+    const int v = blockIdx.x;
+    if (blockIdx.y == 0) {
+        const int nb = (d.P + WG - 1) / WG;
+        uint32_t* p = s.block_sums + (size_t)v * splat_blocks(d.Pa);
+        uint32_t carry = 0;
+        for (int base = 0; base < nb; base += WG) {
+            const int idx = base + threadIdx.x;
+            const uint32_t x = idx < nb ? p[idx] : 0;
+            uint32_t total;
+            const uint32_t ex = block_excl_scan(x, &total);
+            if (idx < nb) p[idx] = carry + ex;
+            carry += total;
+        }
+        if (threadIdx.x == 0) {
+            s.flags[v * 4 + 2] = carry;  // num_rendered of this group
+            if (carry > d.Rcap) s.flags[v * 4 + 0] = 1u;  // arena too small: the later stages skip the group, the host grows and replays
+        }
+    } else {
+        const int n = d.NST * CGROUPS;
+        scan_single(s.coarse_count + (size_t)v * n, s.coarse_end + (size_t)v * n, n);
+    }
+}
+
+int launch_project_scans(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st) {
+    if (d.VG == 0) return GS_OK;
+    const int n = d.NST * CGROUPS;
+    const bool fused = n <= g_scan_single_max;
+    hipLaunchKernelGGL(k_project_scans, dim3(d.VG, fused ? 2 : 1), dim3(WG), 0, st, d, s);
+    GS_HIP(hipGetLastError());
+    if (!fused) GS_TRY(launch_scan_u32(s.coarse_count, s.coarse_end, n, n, d.VG, partials, st));
+    return GS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
-// coarse scatter: one thread per (view, splat); one candidate record per super-tile the splat touches
+// coarse scatter: one thread per (view, splat); finishes the offsets scan, then one candidate record per super-tile
+// the splat touches
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
     const int i = blockIdx.x * WG + threadIdx.x;
     const int v = blockIdx.y;
-    if (i >= d.P) return;
     const size_t pv = (size_t)v * d.Pa;
-    const uint32_t tiles = s.tiles_touched[pv + i];
-    if (i == d.P - 1) s.flags[v * 4 + 2] = s.point_offsets[pv + i];  // num_rendered of this view
-    if (tiles == 0) return;
+    const uint32_t tiles = i < d.P ? s.tiles_touched[pv + i] : 0u;
+    // finish the offsets scan inside the block: exclusive prefix of the block (k_project_scans) + in-block scan
+    const uint32_t slot_base = s.block_sums[(size_t)v * splat_blocks(d.Pa) + blockIdx.x] + block_excl_scan(tiles, nullptr);
+    if (i >= d.P) return;
+    s.point_offsets[pv + i] = slot_base + tiles;
+    if (tiles == 0 || (s.flags[v * 4 + 0] & 1u)) return;
     const GeomRec* rec = s.geom + pv + i;
     const uint32_t rmin = rec->rect_min, rmax = rec->rect_max;
     const uint32_t depth = __float_as_uint(rec->depth);
-    const uint32_t slot_base = s.point_offsets[pv + i] - tiles;
-    const uint32_t total = s.point_offsets[pv + d.P - 1];
-    if (total > d.Rcap) {  // arena too small for this view: flag it, the host grows and replays
-        if ((threadIdx.x & 63) == 0 || slot_base == 0) atomicOr(&s.flags[v * 4 + 0], 1u);
-        return;
-    }
     const size_t cg = (size_t)v * d.NST * CGROUPS + (blockIdx.x % CGROUPS);  // same group as in preprocess
     const uint32_t* cend = s.coarse_end + cg;
     const uint32_t* ccnt = s.coarse_count + cg;

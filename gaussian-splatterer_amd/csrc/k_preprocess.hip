@@ -17,11 +17,9 @@ __device__ __constant__ float SH_C3[7] = { -0.5900435899266435f, 2.8906114426405
                                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                            -0.5900435899266435f };
 
+// one (view, splat): writes the record and tiles_touched, counts the splat into its super-tiles; returns tiles_touched
 template <int D>
-__global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restrict__ params, Scratch s) {
-    const int i = blockIdx.x * WG + threadIdx.x;
-    const int v = blockIdx.y;
-    if (i >= d.P) return;
+__device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict__ params, const Scratch& s, int i, int v) {
     const gs_view& vp = s.gviews[v];  // v indexes geometry groups here
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
@@ -108,7 +106,7 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
     if (!visible) {
         rec->radius = 0;
         *tt = 0;
-        return;
+        return 0u;
     }
 
     // colour from SH
@@ -167,7 +165,8 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
     g.rect_min = (uint32_t)rminx | ((uint32_t)rminy << 16);
     g.rect_max = (uint32_t)rmaxx | ((uint32_t)rmaxy << 16);
     *rec = g;
-    *tt = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx));
+    const uint32_t ntiles = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx));
+    *tt = ntiles;
 
     // coarse binning: count the splat once per 64x64-px super-tile it touches (~1.5 scattered atomics per
     // splat instead of ~7 per-tile ones; scattered device atomics run at only ~20 G/s on MI355X, and same-address
@@ -176,6 +175,23 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
     const int sx0 = rminx / STILE, sx1 = (rmaxx - 1) / STILE + 1, sy0 = rminy / STILE, sy1 = (rmaxy - 1) / STILE + 1;
     for (int sy = sy0; sy < sy1; sy++)
         for (int sx = sx0; sx < sx1; sx++) atomicAdd(&cc[(sy * d.sgx + sx) * CGROUPS], 1u);
+    return ntiles;
+}
+
+template <int D>
+__global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restrict__ params, Scratch s) {
+    __shared__ uint32_t wsum[WG / 64];
+    const int i = blockIdx.x * WG + threadIdx.x;
+    const int v = blockIdx.y;
+    uint32_t n = 0;
+    if (i < d.P) n = preprocess_one<D>(d, params, s, i, v);
+    // the block's share of the offsets scan (k_project_scans turns the block sums into prefixes, the coarse
+    // scatter finishes the scan inside each block): no separate pass over tiles_touched
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) s.block_sums[(size_t)v * splat_blocks(d.Pa) + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st) {

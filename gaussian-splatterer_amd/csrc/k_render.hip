@@ -298,7 +298,7 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s, const int*
     __shared__ float sAcc[K * 4 * ROUND * ACC_STRIDE];
     __shared__ unsigned long long sTouched[4][(ROUND + 63) / 64];
     __shared__ uint32_t sMaxLast;
-    __shared__ float sLoss[K];
+    __shared__ float sLoss[K][4];
     const int tile = blockIdx.x;
     const int* item = items + 3 * blockIdx.y;  // {group, pass 0, pass 1}
     const int g = item[0];                     // geometry group: lists, records, T and n_contrib live there
@@ -352,11 +352,7 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s, const int*
         const float* bg = s.views[vp[p]].bg;
         tfbg[p] = -T_final * (bg[0] * dpx[p][0] + bg[1] * dpx[p][1] + bg[2] * dpx[p][2]);
     }
-    if (tid == 0) {
-        sMaxLast = 0;
-#pragma unroll
-        for (int p = 0; p < K; p++) sLoss[p] = 0.0f;
-    }
+    if (tid == 0) sMaxLast = 0;
     __syncthreads();
     // wave-uniform and block-uniform bounds on the traversal
     uint32_t wave_max_last = last_contributor;
@@ -367,12 +363,13 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s, const int*
 #pragma unroll
         for (int p = 0; p < K; p++) {
             const float l = wave_sum_to_lane63(res2[p]);
-            if (lane == 63) atomicAdd(&sLoss[p], l);
+            if (lane == 63) sLoss[p][wave] = l;
         }
     }
     __syncthreads();
     const int max_last = (int)sMaxLast;
-    if (s.loss && !s.dL_dpix && tid < K) atomicAdd(&s.loss[vp[tid]], sLoss[tid]);
+    if (s.loss && !s.dL_dpix && tid < K)  // fixed summation order: the loss statistic is reproducible too
+        s.loss[(size_t)vp[tid] * d.T + tile] = (sLoss[tid][0] + sLoss[tid][1]) + (sLoss[tid][2] + sLoss[tid][3]);
     if (n == 0) return;
     const int rounds = (max_last + ROUND - 1) / ROUND;
     // entries no pixel reaches still own a gradient row per pass: zero it
@@ -505,6 +502,27 @@ __global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s, const int*
             }
         }
     }
+}
+
+__global__ __launch_bounds__(WG) void k_loss_sum(Dims d, Scratch s) {
+    __shared__ float part[WG];
+    const int v = blockIdx.x;
+    const float* src = s.loss + (size_t)v * d.T;
+    float acc = 0.0f;
+    for (int t = threadIdx.x; t < d.T; t += WG) acc += src[t];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = WG / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) s.loss_total[v] = part[0];
+}
+int launch_loss_sum(const Dims& d, const Scratch& s, hipStream_t stream) {
+    if (d.V == 0 || !s.loss || !s.loss_total) return GS_OK;
+    hipLaunchKernelGGL(k_loss_sum, dim3(d.V), dim3(WG), 0, stream, d, s);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
 }
 
 // items: n2 pairs {group, pass a, pass b} followed by n1 singles {group, pass, -1} (device array of 3*(n2+n1) ints)

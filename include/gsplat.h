@@ -63,7 +63,9 @@ int gs_device_count(void);
  * (the reference's white/black pair per camera, src/Trainer.cu:311-318) share projection, tile lists and the
  * forward blend; 0 recomputes them per pass like the reference.  Results are bit-identical either way.
  * "arena_entries" (default 0 = max(2^20, 16*P)): initial capacity, in (splat, tile) entries per camera, of the binning
- * arena of trainers created afterwards; when a step needs more the arena grows and the step is replayed. */
+ * arena of trainers created afterwards; when a step needs more the arena grows and the step is replayed.
+ * "scan_single_max" (default 65536): the per-view scans of super-tile counters and tile counts run as one workgroup
+ * per view up to this many items and as a three-phase scan beyond; results are identical either way. */
 int gs_set_option(const char* name, int value);
 /* Diagnostic: runs the backward kernel's 9-value wave reduce-scatter on one wave64.  in_host[q*64 + lane]
  * (q = 0..8), out_host[lane]: lane 2q of every 16-lane row holds the wave total of value q (q < 8), lane 1
@@ -201,6 +203,8 @@ int gs_trainer_render(gs_trainer* trainer, uint32_t* framebuffer, int fb_on_devi
 /* Per-stage device timing with HIP events recorded on the trainer's stream (evidence for the
  * roofline report; off by default).  Stage i is named gs_stage_name(i): preprocess, scan, scatter,
  * tile_sort, render_forward, render_backward, splat_backward, update, collective.
+ * enable: 0 off, 1 every stage, otherwise a stage mask shifted left by one (bit i+1 times stage i only:
+ * an event costs ~3 us of stream time, so timing one kernel over a long run should not pay for all nine).
  * gs_trainer_stage_times returns the sums (ms) and launch counts since profiling was switched on. */
 #define GS_STAGE_COUNT 9
 int gs_trainer_set_profiling(gs_trainer* trainer, int enable);

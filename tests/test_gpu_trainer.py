@@ -239,3 +239,22 @@ def test_arena_overflow_grows_and_replays(orc):
         assert np.array_equal(res[0][2][k].view(np.uint32), res[1][2][k].view(np.uint32)), k
     for k in ("loc", "sh", "scale", "opac", "rot"):
         assert np.array_equal(res[0][3][k].view(np.uint32), res[1][3][k].view(np.uint32)), k
+
+
+def test_scan_forms_agree(orc):
+    """The per-view scans (super-tile counters, tile counts) have a one-workgroup form and a three-phase form for
+    very large images (gs_set_option "scan_single_max"); forcing the three-phase form must not change a bit."""
+    P, M, n_cams, W, H = 1500, 4, 2, 1040, 520   # 65 x 33 tiles: several scan blocks, ragged edges
+    res = []
+    for limit in (0, 256):
+        capi.check(capi.lib().gs_set_option(b"scan_single_max", limit))
+        try:
+            s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 31)
+            st = tr.train(gs.Project(), stats=True)
+            res.append((st.num_rendered, st.max_tile_list, st.loss, _read_grads(tr, P, M)))
+            tr.close()
+        finally:
+            capi.check(capi.lib().gs_set_option(b"scan_single_max", 0))
+    assert res[0][:3] == res[1][:3] and res[0][0] > 0
+    for k in res[0][3]:
+        assert np.array_equal(res[0][3][k].view(np.uint32), res[1][3][k].view(np.uint32)), k
