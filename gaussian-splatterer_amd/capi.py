@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsplat_mi355.so")
+LIB_PATH = os.environ.get("GSPLAT_MI355_LIB") or os.path.join(_HERE, "libgsplat_mi355.so")  # override: kernel-tuning builds only
 
 GS_OK = 0
 GS_UPDATE_SGD_CLAMP, GS_UPDATE_ADAM = 0, 1

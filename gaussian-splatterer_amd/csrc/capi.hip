@@ -115,7 +115,7 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
 }
 
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, tloss, zero_block, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads;
+    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads;
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
     Scratch s{};
@@ -142,6 +142,7 @@ struct ScratchSet {
         GS_TRY(tile_count.ensure(v * T * 4));
         GS_TRY(tile_end.ensure(v * T * 4));
         GS_TRY(tloss.ensure(v * T * 4));
+        GS_TRY(torder.ensure(v * T * 4));
         GS_TRY(clist.ensure(v * Rcap * 16));
         GS_TRY(cdepth.ensure(v * Rcap * 4));
         GS_TRY(ids.ensure(v * Rcap * 4));
@@ -165,6 +166,7 @@ struct ScratchSet {
         s.flags = s.coarse_cursor + v * NST;
         s.loss_total = reinterpret_cast<float*>(s.flags + v * 4);
         s.loss = tloss.as<float>();
+        s.tile_order = torder.as<uint32_t>();
         s.coarse_end = coarse_end.as<uint32_t>();
         s.tile_count = tile_count.as<uint32_t>();
         s.tile_end = tile_end.as<uint32_t>();
@@ -182,7 +184,7 @@ struct ScratchSet {
         return GS_OK;
     }
     void release() {
-        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &zero_block, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &color,
+        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &color,
                            &finalT, &ncontrib, &scan_tmp, &sgrads })
             b->release();
     }
@@ -195,11 +197,11 @@ static int stage_project(const Dims& d, const float* params, const Scratch& s, h
     GS_TRY(launch_project_scans(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), st));
     return GS_OK;
 }
-// coarse scatter (finishes the offsets scan), per-tile counts + scan
+// coarse scatter (finishes the offsets scan), per-tile counts, their scan and the longest-first tile order
 static int stage_bin(const Dims& d, const Scratch& s, hipStream_t st) {
     GS_TRY(launch_coarse_scatter(d, s, st));
     GS_TRY(launch_tile_count(d, s, st));
-    GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.VG, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), st));
+    GS_TRY(launch_tile_scan_order(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), st));
     return GS_OK;
 }
 static int stage_bin_render(const Dims& d, const Scratch& s, hipStream_t st) {
@@ -879,7 +881,7 @@ GeomLayout geom_layout(int P, int M, int W = 16, int H = 16) {
     L.total = o;
     return L;
 }
-struct ImageLayout { size_t zero, coarse_count, coarse_cursor, coarse_end, tile_count, tile_end, ranges, final_T, n_contrib, scan_tmp, total; int T, NST; size_t zero_bytes; };
+struct ImageLayout { size_t zero, coarse_count, coarse_cursor, coarse_end, tile_count, tile_end, tile_order, ranges, final_T, n_contrib, scan_tmp, total; int T, NST; size_t zero_bytes; };
 ImageLayout image_layout(int W, int H) {
     ImageLayout L; const size_t N = (size_t)W * H;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -890,6 +892,7 @@ ImageLayout image_layout(int W, int H) {
     L.coarse_end = o; o = al(o + (size_t)L.NST * 4);
     L.tile_count = o; o = al(o + (size_t)L.T * 4);
     L.tile_end = o; o = al(o + (size_t)L.T * 4);
+    L.tile_order = o; o = al(o + (size_t)L.T * 4);
     L.ranges = o; o = al(o + (size_t)L.T * 8);
     L.final_T = o; o = al(o + N * 4);
     L.n_contrib = o; o = al(o + N * 4);
@@ -923,6 +926,7 @@ Scratch seam_scratch(char* geom, const GeomLayout& g, char* img, const ImageLayo
     s.coarse_end = reinterpret_cast<uint32_t*>(img + im.coarse_end);
     s.tile_count = reinterpret_cast<uint32_t*>(img + im.tile_count);
     s.tile_end = reinterpret_cast<uint32_t*>(img + im.tile_end);
+    s.tile_order = reinterpret_cast<uint32_t*>(img + im.tile_order);
     s.final_T = reinterpret_cast<float*>(img + im.final_T);
     s.n_contrib = reinterpret_cast<uint32_t*>(img + im.n_contrib);
     if (bin && b) {

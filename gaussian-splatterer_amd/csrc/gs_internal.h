@@ -99,6 +99,7 @@ struct Scratch {
     uint32_t* coarse_depth;    // [V][Rcap] depth bits of the same entries
     uint32_t* tile_count;      // [V][T]
     uint32_t* tile_end;        // [V][T]   inclusive scan of tile_count
+    uint32_t* tile_order;      // [V][T]   tiles by descending entry count: the order workgroups take them in
     uint32_t* id_of_slot;      // [V][Rcap] (only tiles longer than the rank-sort limit use it)
     uint32_t* point_list;      // [V][Rcap]  sorted splat ids
     uint32_t* slot_list;       // [V][Rcap]  sorted slots
@@ -128,6 +129,7 @@ extern int g_scan_single_max;
 __host__ __device__ inline int splat_blocks(int Pa) { return (Pa + WG - 1) / WG; }
 int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st);
+int launch_tile_scan_order(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st);
 int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t st);
 // loss_total[v] = sum over tiles of loss[v][tile], in a fixed order (the statistic is reproducible bit for bit)

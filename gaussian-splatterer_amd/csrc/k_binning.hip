@@ -241,6 +241,43 @@ int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// longest-list-first tile order.  The per-tile kernels take tiles in this order, so the heaviest workgroups start
+// first and the tail of a launch is made of light ones (a one-camera launch is only ~3 waves of workgroups deep:
+// row-major order leaves the CUs that drew a heavy tile last running alone).  Counting sort on min(count, 1023) / 4.
+// ---------------------------------------------------------------------------------------------
+constexpr int ORDER_BINS = 256;
+template <bool SCAN>
+__global__ __launch_bounds__(WG) void k_tile_scan_order(Dims d, Scratch s) {
+    __shared__ uint32_t hist[ORDER_BINS], start[ORDER_BINS];
+    const int v = blockIdx.x;
+    const uint32_t* cnt = s.tile_count + (size_t)v * d.T;
+    uint32_t* order = s.tile_order + (size_t)v * d.T;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < d.T; t += WG) atomicAdd(&hist[ORDER_BINS - 1 - min(cnt[t], 1023u) / 4], 1u);  // bin 0 = longest
+    if (SCAN) scan_single(cnt, s.tile_end + (size_t)v * d.T, d.T);  // tile_end: the same workgroup has the counts in cache
+    __syncthreads();
+    const uint32_t h = hist[threadIdx.x];
+    const uint32_t ex = block_excl_scan(h, nullptr);
+    start[threadIdx.x] = ex;
+    __syncthreads();
+    for (int t = threadIdx.x; t < d.T; t += WG) order[atomicAdd(&start[ORDER_BINS - 1 - min(cnt[t], 1023u) / 4], 1u)] = (uint32_t)t;
+}
+// tile_end = inclusive scan of tile_count, tile_order = tiles by descending count; one launch unless the scan is too long
+int launch_tile_scan_order(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st) {
+    if (d.T == 0 || d.VG == 0) return GS_OK;
+    static_assert(ORDER_BINS == WG, "one bin per thread");
+    if (d.T <= g_scan_single_max) {
+        hipLaunchKernelGGL(k_tile_scan_order<true>, dim3(d.VG), dim3(WG), 0, st, d, s);
+    } else {
+        GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.VG, partials, st));
+        hipLaunchKernelGGL(k_tile_scan_order<false>, dim3(d.VG), dim3(WG), 0, st, d, s);
+    }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-tile gather + sort on the unique 64-bit key: the tile's workgroup scans its super-tile's candidates,
 // compacts the overlapping ones into LDS, and sorts: counting-rank sort for n <= SORT_LDS_CAP (2048), bitonic in
 // global scratch (the not yet used gradient-row buffer G) beyond — the "tile-list spill path".
@@ -266,7 +303,8 @@ __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
     uint64_t* sk = reinterpret_cast<uint64_t*>(smem_raw);
     __shared__ uint32_t sid[RANK_MAX];
     __shared__ uint32_t fill;
-    const int tile = blockIdx.x, v = blockIdx.y;
+    const int v = blockIdx.y;
+    const int tile = (int)s.tile_order[(size_t)v * d.T + blockIdx.x];
     if (s.flags[v * 4 + 0] & 1u) return;  // overflowed view: nothing was scattered
     const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
     if (n == 0) return;

@@ -26,6 +26,9 @@ constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_STOP = 0.0001f;
 constexpr int ACC_STRIDE = 9;
 constexpr int BWD_ROUND = 128;  // entries staged per backward round
+#ifndef GS_BWD_ROUND_K2
+#define GS_BWD_ROUND_K2 (BWD_ROUND / 2)  // tuning hook (tools/build_variant.sh)
+#endif
 
 // Exact "can this splat reach alpha >= 1/255 anywhere in the 8x8 block" test: the minimum of the conic's
 // quadratic form q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy over the block rectangle (centre inside -> 0, else
@@ -74,7 +77,8 @@ __device__ inline void unscaled_conic(const float4& A, const float4& B, float& c
 __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
 #pragma clang fp contract(fast)
     __shared__ StagedTile<WG> st;
-    const int tile = blockIdx.x, v = blockIdx.y;  // v = geometry group (camera)
+    const int v = blockIdx.y;  // v = geometry group (camera)
+    const int tile = (int)s.tile_order[(size_t)v * d.T + blockIdx.x];
     if (s.flags[v * 4 + 0] & 1u) return;
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -289,19 +293,22 @@ int launch_debug_reduce9(const float* in, float* out, hipStream_t st) {
 // black-background pair).  Everything that does not depend on dL/dpixel — pair geometry, exp, alpha, the
 // transmittance recurrence, the accumulated colour behind — is evaluated once and shared; only the dL/dalpha
 // chain, the nine sums and their reduction run per pass.
+#ifndef GS_BWD_ATTR
+#define GS_BWD_ATTR
+#endif
 template <int K>
-__global__ __launch_bounds__(WG) void k_render_bwd(Dims d, Scratch s, const int* __restrict__ items) {
+__global__ __launch_bounds__(WG) GS_BWD_ATTR void k_render_bwd(Dims d, Scratch s, const int* __restrict__ items) {
 #pragma clang fp contract(fast)
-    constexpr int ROUND = (K == 1) ? BWD_ROUND : BWD_ROUND / 2;  // entries staged per round (LDS: ~24 KB either way)
+    constexpr int ROUND = (K == 1) ? BWD_ROUND : GS_BWD_ROUND_K2;  // entries staged per round (LDS: ~24 KB either way)
     __shared__ StagedTile<ROUND> st;
     __shared__ uint32_t sSlot[ROUND];
     __shared__ float sAcc[K * 4 * ROUND * ACC_STRIDE];
     __shared__ unsigned long long sTouched[4][(ROUND + 63) / 64];
     __shared__ uint32_t sMaxLast;
     __shared__ float sLoss[K][4];
-    const int tile = blockIdx.x;
     const int* item = items + 3 * blockIdx.y;  // {group, pass 0, pass 1}
     const int g = item[0];                     // geometry group: lists, records, T and n_contrib live there
+    const int tile = (int)s.tile_order[(size_t)g * d.T + blockIdx.x];
     int vp[K];
 #pragma unroll
     for (int p = 0; p < K; p++) vp[p] = item[1 + p];
