@@ -115,7 +115,7 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
 }
 
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads;
+    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads;
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
     Scratch s{};
@@ -133,11 +133,13 @@ struct ScratchSet {
         GS_TRY(offsets.ensure(v * Pa * 4));
         {
             const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-            NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE) * CGROUPS;  // counters, not super-tiles
+            NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE);
         }
-        // zero block: coarse_count | coarse_cursor | flags | loss   (cleared by one memset per step)
-        zero_bytes = v * NST * 4 * 2 + v * 16 + v * 4;
+        // zero block: flags | loss totals   (cleared by one memset per step)
+        zero_bytes = v * 16 + v * 4;
         GS_TRY(zero_block.ensure(zero_bytes));
+        GS_TRY(wghist.ensure(v * splat_blocks(Pa) * NST * 4));
+        GS_TRY(coarse_count.ensure(v * NST * 4));
         GS_TRY(coarse_end.ensure(v * NST * 4));
         GS_TRY(tile_count.ensure(v * T * 4));
         GS_TRY(tile_end.ensure(v * T * 4));
@@ -161,9 +163,9 @@ struct ScratchSet {
         s.geom = geom.as<GeomRec>();
         s.tiles_touched = tiles.as<uint32_t>();
         s.point_offsets = offsets.as<uint32_t>();
-        s.coarse_count = zero_block.as<uint32_t>();
-        s.coarse_cursor = s.coarse_count + v * NST;
-        s.flags = s.coarse_cursor + v * NST;
+        s.wg_hist = wghist.as<uint32_t>();
+        s.coarse_count = coarse_count.as<uint32_t>();
+        s.flags = zero_block.as<uint32_t>();
         s.loss_total = reinterpret_cast<float*>(s.flags + v * 4);
         s.loss = tloss.as<float>();
         s.tile_order = torder.as<uint32_t>();
@@ -184,7 +186,7 @@ struct ScratchSet {
         return GS_OK;
     }
     void release() {
-        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &color,
+        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &wghist, &coarse_count, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &color,
                            &finalT, &ncontrib, &scan_tmp, &sgrads })
             b->release();
     }
@@ -193,7 +195,12 @@ struct ScratchSet {
 // projection + everything that does not need the binning arena: the block prefixes of the offsets scan (entry count and
 // overflow bit land in flags) and the super-tile scan.  Runs for P == 0 too (the scans then define empty lists).
 static int stage_project(const Dims& d, const float* params, const Scratch& s, hipStream_t st) {
+    if (d.NST > MAX_SUPER_TILES) {
+        set_error("image of %dx%d has %d super-tiles; this build bins up to %d (e.g. 8192x4096)", d.W, d.H, d.NST, MAX_SUPER_TILES);
+        return GS_ERR_INVALID_ARGUMENT;
+    }
     GS_TRY(launch_preprocess(d, params, s, st));
+    GS_TRY(launch_coarse_colscan(d, s, st));
     GS_TRY(launch_project_scans(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), st));
     return GS_OK;
 }
@@ -486,6 +493,13 @@ extern "C" int gs_trainer_create(int width, int height, gs_trainer** out) {
         set_error("gs_trainer_create: bad resolution %dx%d", width, height);
         return GS_ERR_INVALID_ARGUMENT;
     }
+    {
+        const Dims dd = make_dims(0, 64, 0, 1, width, height, 1, 1, 1.0f);
+        if (dd.NST > MAX_SUPER_TILES) {
+            set_error("gs_trainer_create: %dx%d has %d super-tiles; this build bins up to %d (e.g. 8192x4096)", width, height, dd.NST, MAX_SUPER_TILES);
+            return GS_ERR_INVALID_ARGUMENT;
+        }
+    }
     GS_TRY(require_device());
     gs_trainer* t = new gs_trainer();
     t->W = width; t->H = height;
@@ -628,6 +642,7 @@ static int accumulate_async(gs_trainer* t) {
         GS_TRY(launch_preprocess(d, m->planes, s, t->stream));
         prof_stage_end(t, 0);
         prof_stage_begin(t, 1, 0);
+        GS_TRY(launch_coarse_colscan(d, s, t->stream));
         GS_TRY(launch_project_scans(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), t->stream));
         GS_HIP(hipMemcpyAsync(t->h_flags, s.flags, (size_t)t->VG * 16, hipMemcpyDeviceToHost, t->stream));
         GS_HIP(hipEventRecord(t->ev_flags, t->stream));
@@ -863,7 +878,7 @@ namespace {
 struct Field { const char* name; size_t off, bytes; };
 inline size_t al(size_t x) { return round_up_sz(x, 256); }
 
-struct GeomLayout { size_t record, tiles, offsets, scan_tmp, view, flags, planes, total; int Pa; };
+struct GeomLayout { size_t record, tiles, offsets, scan_tmp, wg_hist, view, flags, planes, total; int Pa; };
 GeomLayout geom_layout(int P, int M, int W = 16, int H = 16) {
     GeomLayout L; L.Pa = std::max(64, round_up(P, 64));
     size_t o = 0;
@@ -872,8 +887,9 @@ GeomLayout geom_layout(int P, int M, int W = 16, int H = 16) {
     L.offsets = o; o = al(o + (size_t)L.Pa * 4);
     {
         const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-        const int T = gx * gy, NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE) * CGROUPS;
+        const int T = gx * gy, NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE);
         L.scan_tmp = o; o = al(o + (splat_blocks(L.Pa) + scan_partials_count(std::max(T, NST), 1) + 64) * 4);
+        L.wg_hist = o; o = al(o + (size_t)splat_blocks(L.Pa) * NST * 4);
     }
     L.view = o; o = al(o + view_block_bytes(1));
     L.flags = o; o = al(o + 32);
@@ -881,14 +897,14 @@ GeomLayout geom_layout(int P, int M, int W = 16, int H = 16) {
     L.total = o;
     return L;
 }
-struct ImageLayout { size_t zero, coarse_count, coarse_cursor, coarse_end, tile_count, tile_end, tile_order, ranges, final_T, n_contrib, scan_tmp, total; int T, NST; size_t zero_bytes; };
+struct ImageLayout { size_t coarse_count, coarse_end, tile_count, tile_end, tile_order, ranges, final_T, n_contrib, scan_tmp, total; int T, NST; };
 ImageLayout image_layout(int W, int H) {
     ImageLayout L; const size_t N = (size_t)W * H;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     L.T = gx * gy;
-    L.NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE) * CGROUPS;  // counters
+    L.NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE);
     size_t o = 0;
-    L.zero = o; L.coarse_count = o; o += (size_t)L.NST * 4; L.coarse_cursor = o; o += (size_t)L.NST * 4; L.zero_bytes = o; o = al(o);
+    L.coarse_count = o; o = al(o + (size_t)L.NST * 4);
     L.coarse_end = o; o = al(o + (size_t)L.NST * 4);
     L.tile_count = o; o = al(o + (size_t)L.T * 4);
     L.tile_end = o; o = al(o + (size_t)L.T * 4);
@@ -922,7 +938,7 @@ Scratch seam_scratch(char* geom, const GeomLayout& g, char* img, const ImageLayo
     s.block_sums = reinterpret_cast<uint32_t*>(geom + g.scan_tmp);
     s.flags = reinterpret_cast<uint32_t*>(geom + g.flags);
     s.coarse_count = reinterpret_cast<uint32_t*>(img + im.coarse_count);
-    s.coarse_cursor = reinterpret_cast<uint32_t*>(img + im.coarse_cursor);
+    s.wg_hist = reinterpret_cast<uint32_t*>(geom + g.wg_hist);
     s.coarse_end = reinterpret_cast<uint32_t*>(img + im.coarse_end);
     s.tile_count = reinterpret_cast<uint32_t*>(img + im.tile_count);
     s.tile_end = reinterpret_cast<uint32_t*>(img + im.tile_end);
@@ -1011,7 +1027,6 @@ extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_u
             GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, bg), background, 12, hipMemcpyDeviceToDevice, st));
         }
     }
-    GS_HIP(hipMemsetAsync(img + il.zero, 0, il.zero_bytes, st));
     GS_HIP(hipMemsetAsync(geom + gl.flags, 0, 32, st));
     float* planes = reinterpret_cast<float*>(geom + gl.planes);
     GS_TRY(launch_aos_to_soa(P, gl.Pa, M, means3D, shs, scales, opacities, rotations, planes, st));

@@ -37,7 +37,7 @@ constexpr int WG = 256;            // workgroup = 4 wave64
 constexpr int G_STRIDE = 12;       // floats per (splat,tile) gradient slot (9 used, 48-byte rows)
 constexpr int SORT_LDS_CAP = 2048; // entries a tile sorts in LDS; longer lists take the global path
 constexpr int STILE = 4;           // a super-tile is STILE x STILE tiles (64x64 px): the coarse binning unit
-constexpr int CGROUPS = 16;        // each super-tile has CGROUPS counters (by splat workgroup) to spread same-address atomics
+constexpr int MAX_SUPER_TILES = 8192;  // the binning keeps one LDS counter per super-tile (32 KB): images up to e.g. 8192 x 4096
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
@@ -92,9 +92,10 @@ struct Scratch {
     uint32_t* tiles_touched;   // [V][Pa]
     uint32_t* point_offsets;   // [V][Pa]  inclusive scan of tiles_touched
     uint32_t* block_sums;      // [G][splat_blocks(Pa)] tiles_touched summed per 256-splat block, then its exclusive prefix
-    uint32_t* coarse_count;    // [V][NST*CGROUPS] splats per (super-tile, splat group) (zeroed each step)
-    uint32_t* coarse_cursor;   // [V][NST*CGROUPS] (zeroed each step)
-    uint32_t* coarse_end;      // [V][NST*CGROUPS] inclusive scan of coarse_count (super-tile major: a super-tile's list is contiguous)
+    uint32_t* wg_hist;         // [G][splat_blocks(Pa)][NST] candidates per (256-splat block, super-tile); k_coarse_colscan turns
+                               //     every super-tile's column into its exclusive prefix over the blocks
+    uint32_t* coarse_count;    // [G][NST] candidates per super-tile
+    uint32_t* coarse_end;      // [G][NST] inclusive scan of coarse_count
     uint4* coarse_list;        // [V][Rcap] {splat id, rect_min, rect_max, first slot} per (splat, super-tile)
     uint32_t* coarse_depth;    // [V][Rcap] depth bits of the same entries
     uint32_t* tile_count;      // [V][T]
@@ -121,6 +122,7 @@ struct Scratch {
 int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st);
 // after preprocess, one launch: prefix of the per-block tile sums (-> flags: num_rendered, arena overflow) and the
 // inclusive scan of the super-tile counters
+int launch_coarse_colscan(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_project_scans(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st);
 // batched inclusive scan of u32: one workgroup per batch entry up to g_scan_single_max items, three phases beyond
 int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int batch, uint32_t* partials, hipStream_t st);

@@ -125,6 +125,32 @@ int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int ba
     return GS_OK;
 }
 
+// Column scan of the (splat block x super-tile) count matrix: one WAVE per super-tile walks the column over the
+// blocks, replaces every count by the exclusive prefix of its column and writes the column total (the super-tile's
+// candidate count).  With the scan of the totals this gives every block its private output range per super-tile:
+// the scatter needs LDS cursors only.
+__global__ __launch_bounds__(WG) void k_coarse_colscan(Dims d, Scratch s) {
+    const int st = blockIdx.x * (WG / 64) + (threadIdx.x >> 6), v = blockIdx.y, lane = threadIdx.x & 63;
+    if (st >= d.NST) return;
+    const int nb = (d.P + WG - 1) / WG;
+    uint32_t* col = s.wg_hist + (size_t)v * splat_blocks(d.Pa) * d.NST + st;
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+        const int b = b0 + lane;
+        const uint32_t x = b < nb ? col[(size_t)b * d.NST] : 0u;
+        const uint32_t inc = wave_incl_scan(x);
+        if (b < nb) col[(size_t)b * d.NST] = carry + inc - x;
+        carry += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) s.coarse_count[(size_t)v * d.NST + st] = carry;
+}
+int launch_coarse_colscan(const Dims& d, const Scratch& s, hipStream_t st) {
+    if (d.NST == 0 || d.VG == 0) return GS_OK;
+    hipLaunchKernelGGL(k_coarse_colscan, dim3((d.NST + WG / 64 - 1) / (WG / 64), d.VG), dim3(WG), 0, st, d, s);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
 // After preprocess, per geometry group: blockIdx.y == 0 turns the per-block tile sums into exclusive prefixes and
 // publishes the group's entry count (flags[2]) and the arena-overflow bit (flags[0]); blockIdx.y == 1 scans the
 // super-tile counters (unless they are too many for one workgroup: then launch_project_scans scans them separately).
@@ -147,14 +173,13 @@ __global__ __launch_bounds__(WG) void k_project_scans(Dims d, Scratch s) {
             if (carry > d.Rcap) s.flags[v * 4 + 0] = 1u;  // arena too small: the later stages skip the group, the host grows and replays
         }
     } else {
-        const int n = d.NST * CGROUPS;
-        scan_single(s.coarse_count + (size_t)v * n, s.coarse_end + (size_t)v * n, n);
+        scan_single(s.coarse_count + (size_t)v * d.NST, s.coarse_end + (size_t)v * d.NST, d.NST);
     }
 }
 
 int launch_project_scans(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st) {
     if (d.VG == 0) return GS_OK;
-    const int n = d.NST * CGROUPS;
+    const int n = d.NST;
     const bool fused = n <= g_scan_single_max;
     hipLaunchKernelGGL(k_project_scans, dim3(d.VG, fused ? 2 : 1), dim3(WG), 0, st, d, s);
     GS_HIP(hipGetLastError());
@@ -167,30 +192,35 @@ int launch_project_scans(const Dims& d, const Scratch& s, uint32_t* partials, hi
 // the splat touches
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
+    extern __shared__ uint32_t sm[];
+    uint32_t* base = sm;            // [NST] first output position of this block in every super-tile's list
+    uint32_t* cur = sm + d.NST;     // [NST] entries of this block placed so far
     const int i = blockIdx.x * WG + threadIdx.x;
     const int v = blockIdx.y;
     const size_t pv = (size_t)v * d.Pa;
+    {
+        const uint32_t* cend = s.coarse_end + (size_t)v * d.NST;
+        const uint32_t* ccnt = s.coarse_count + (size_t)v * d.NST;
+        const uint32_t* row = s.wg_hist + ((size_t)v * splat_blocks(d.Pa) + blockIdx.x) * d.NST;
+        for (int k = threadIdx.x; k < d.NST; k += WG) { base[k] = cend[k] - ccnt[k] + row[k]; cur[k] = 0; }
+    }
     const uint32_t tiles = i < d.P ? s.tiles_touched[pv + i] : 0u;
     // finish the offsets scan inside the block: exclusive prefix of the block (k_project_scans) + in-block scan
-    const uint32_t slot_base = s.block_sums[(size_t)v * splat_blocks(d.Pa) + blockIdx.x] + block_excl_scan(tiles, nullptr);
+    const uint32_t slot_base = s.block_sums[(size_t)v * splat_blocks(d.Pa) + blockIdx.x] + block_excl_scan(tiles, nullptr);  // syncs: base/cur are ready
     if (i >= d.P) return;
     s.point_offsets[pv + i] = slot_base + tiles;
     if (tiles == 0 || (s.flags[v * 4 + 0] & 1u)) return;
     const GeomRec* rec = s.geom + pv + i;
     const uint32_t rmin = rec->rect_min, rmax = rec->rect_max;
     const uint32_t depth = __float_as_uint(rec->depth);
-    const size_t cg = (size_t)v * d.NST * CGROUPS + (blockIdx.x % CGROUPS);  // same group as in preprocess
-    const uint32_t* cend = s.coarse_end + cg;
-    const uint32_t* ccnt = s.coarse_count + cg;
-    uint32_t* cur = s.coarse_cursor + cg;
     uint4* list = s.coarse_list + (size_t)v * d.Rcap;
     uint32_t* dl = s.coarse_depth + (size_t)v * d.Rcap;
     const int x0 = rmin & 0xffff, y0 = rmin >> 16, x1 = rmax & 0xffff, y1 = rmax >> 16;
     const int sx0 = x0 / STILE, sx1 = (x1 - 1) / STILE + 1, sy0 = y0 / STILE, sy1 = (y1 - 1) / STILE + 1;
     for (int sy = sy0; sy < sy1; sy++)
         for (int sx = sx0; sx < sx1; sx++) {
-            const int st = (sy * d.sgx + sx) * CGROUPS;
-            const uint32_t pos = cend[st] - ccnt[st] + atomicAdd(&cur[st], 1u);
+            const int st = sy * d.sgx + sx;
+            const uint32_t pos = base[st] + atomicAdd(&cur[st], 1u);  // LDS: the block owns [base, base + its count)
             list[pos] = make_uint4((uint32_t)i, rmin, rmax, slot_base);
             dl[pos] = depth;
         }
@@ -198,7 +228,7 @@ __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
 
 int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.P == 0 || d.VG == 0) return GS_OK;
-    hipLaunchKernelGGL(k_coarse_scatter, dim3((d.P + WG - 1) / WG, d.VG), dim3(WG), 0, st, d, s);
+    hipLaunchKernelGGL(k_coarse_scatter, dim3((d.P + WG - 1) / WG, d.VG), dim3(WG), 2 * (size_t)d.NST * sizeof(uint32_t), st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -213,9 +243,9 @@ __global__ __launch_bounds__(WG) void k_tile_count(Dims d, Scratch s) {
     if (threadIdx.x < STILE * STILE) cnt[threadIdx.x] = 0;
     __syncthreads();
     if (!(s.flags[v * 4 + 0] & 1u)) {
-        const size_t c0 = ((size_t)v * d.NST + st) * CGROUPS;  // the super-tile's CGROUPS sub-lists are contiguous
-        const uint32_t cstart = s.coarse_end[c0] - s.coarse_count[c0];
-        const uint32_t nc = s.coarse_end[c0 + CGROUPS - 1] - cstart;
+        const size_t c0 = (size_t)v * d.NST + st;
+        const uint32_t nc = s.coarse_count[c0];
+        const uint32_t cstart = s.coarse_end[c0] - nc;
         const uint4* list = s.coarse_list + (size_t)v * d.Rcap + cstart;
         const int tx0 = stx * STILE, ty0 = sty * STILE;
         for (uint32_t c = threadIdx.x; c < nc; c += WG) {
@@ -241,6 +271,60 @@ int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// per-tile scatter: the super-tile's workgroup walks its candidates a second time and appends every (candidate, tile)
+// entry to the tile's segment [tile_end - tile_count, tile_end) — LDS cursors, no global atomics.  Entries land
+// unsorted: key (depth_bits << 32 | slot) in the not yet used gradient-row buffer (u64 index 2 * start + pos: the
+// segment doubles as the in-place area of the long-list bitonic sort), splat id in point_list.  The per-tile sort
+// then reads exactly its own entries; before, every tile re-scanned all candidates of its super-tile (16 scans).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_tile_scatter(Dims d, Scratch s) {
+    __shared__ uint32_t cur[STILE * STILE], first[STILE * STILE], big[STILE * STILE];
+    const int st = blockIdx.x, v = blockIdx.y;
+    if (s.flags[v * 4 + 0] & 1u) return;
+    const int stx = st % d.sgx, sty = st / d.sgx;
+    const int tx0 = stx * STILE, ty0 = sty * STILE;
+    if (threadIdx.x < STILE * STILE) {
+        const int tx = tx0 + (threadIdx.x % STILE), ty = ty0 + (threadIdx.x / STILE);
+        uint32_t n = 0, e = 0;
+        if (tx < d.gx && ty < d.gy) { n = s.tile_count[(size_t)v * d.T + ty * d.gx + tx]; e = s.tile_end[(size_t)v * d.T + ty * d.gx + tx]; }
+        cur[threadIdx.x] = 0; first[threadIdx.x] = e - n; big[threadIdx.x] = n > (uint32_t)SORT_LDS_CAP;
+    }
+    __syncthreads();
+    const size_t c0 = (size_t)v * d.NST + st;
+    const uint32_t nc = s.coarse_count[c0];
+    const uint32_t cstart = s.coarse_end[c0] - nc;
+    const uint4* __restrict__ list = s.coarse_list + (size_t)v * d.Rcap + cstart;
+    const uint32_t* __restrict__ dlist = s.coarse_depth + (size_t)v * d.Rcap + cstart;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(s.G + (size_t)v * d.Rcap * G_STRIDE);
+    uint32_t* pl = s.point_list + (size_t)v * d.Rcap;
+    uint32_t* ids = s.id_of_slot + (size_t)v * d.Rcap;
+    for (uint32_t c = threadIdx.x; c < nc; c += WG) {
+        const uint4 e = list[c];
+        const uint64_t dz = (uint64_t)dlist[c] << 32;
+        const int rx0 = e.y & 0xffff, ry0 = e.y >> 16, rx1 = e.z & 0xffff, ry1 = e.z >> 16;
+        const int x0 = max(rx0, tx0), x1 = min(rx1, tx0 + STILE);
+        const int y0 = max(ry0, ty0), y1 = min(ry1, ty0 + STILE);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const int tl = (y - ty0) * STILE + (x - tx0);
+                const uint32_t slot = e.w + (uint32_t)((y - ry0) * (rx1 - rx0) + (x - rx0));
+                const uint32_t pos = atomicAdd(&cur[tl], 1u);  // order is irrelevant: the key is unique
+                const uint32_t f = first[tl];
+                keys[2 * (size_t)f + pos] = dz | slot;
+                pl[f + pos] = e.x;
+                if (big[tl]) ids[slot] = e.x;  // the long-list path looks the id up by slot after sorting keys only
+            }
+    }
+}
+
+int launch_tile_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
+    if (d.NST == 0 || d.VG == 0) return GS_OK;
+    hipLaunchKernelGGL(k_tile_scatter, dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // longest-list-first tile order.  The per-tile kernels take tiles in this order, so the heaviest workgroups start
 // first and the tail of a launch is made of light ones (a one-camera launch is only ~3 waves of workgroups deep:
 // row-major order leaves the CUs that drew a heavy tile last running alone).  Counting sort on min(count, 1023) / 4.
@@ -254,7 +338,16 @@ __global__ __launch_bounds__(WG) void k_tile_scan_order(Dims d, Scratch s) {
     uint32_t* order = s.tile_order + (size_t)v * d.T;
     hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < d.T; t += WG) atomicAdd(&hist[ORDER_BINS - 1 - min(cnt[t], 1023u) / 4], 1u);  // bin 0 = longest
+    uint32_t longest = 0;
+    for (int t = threadIdx.x; t < d.T; t += WG) {
+        const uint32_t c = cnt[t];
+        longest = max(longest, c);
+        atomicAdd(&hist[ORDER_BINS - 1 - min(c, 1023u) / 4], 1u);  // bin 0 = longest
+    }
+    // statistic: the longest tile list of the group (one same-address global atomic per TILE would serialise)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&s.flags[v * 4 + 1], longest);
     if (SCAN) scan_single(cnt, s.tile_end + (size_t)v * d.T, d.T);  // tile_end: the same workgroup has the counts in cache
     __syncthreads();
     const uint32_t h = hist[threadIdx.x];
@@ -278,9 +371,9 @@ int launch_tile_scan_order(const Dims& d, const Scratch& s, uint32_t* partials, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-tile gather + sort on the unique 64-bit key: the tile's workgroup scans its super-tile's candidates,
-// compacts the overlapping ones into LDS, and sorts: counting-rank sort for n <= SORT_LDS_CAP (2048), bitonic in
-// global scratch (the not yet used gradient-row buffer G) beyond — the "tile-list spill path".
+// per-tile sort on the unique 64-bit key: the tile's workgroup loads its entries (k_tile_scatter) into LDS and sorts:
+// counting-rank sort for n <= 128, depth-bucketed rank sort up to SORT_LDS_CAP (2048), bitonic in global scratch (the
+// not yet used gradient-row buffer G) beyond — the "tile-list spill path".
 // ---------------------------------------------------------------------------------------------
 __device__ inline void bitonic_sort(uint64_t* a, uint32_t n2) {
     for (uint32_t k = 2; k <= n2; k <<= 1)
@@ -296,62 +389,36 @@ __device__ inline void bitonic_sort(uint64_t* a, uint32_t n2) {
         }
 }
 
+#ifndef GS_RANK_DIRECT_MAX
+#define GS_RANK_DIRECT_MAX 128  // tuning hook (tools/build_variant.sh)
+#endif
 constexpr uint32_t RANK_MAX = SORT_LDS_CAP;  // every list that fits LDS is rank-sorted (measured faster than LDS bitonic up to 2048)
 
 __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint64_t* sk = reinterpret_cast<uint64_t*>(smem_raw);
     __shared__ uint32_t sid[RANK_MAX];
-    __shared__ uint32_t fill;
     const int v = blockIdx.y;
     const int tile = (int)s.tile_order[(size_t)v * d.T + blockIdx.x];
     if (s.flags[v * 4 + 0] & 1u) return;  // overflowed view: nothing was scattered
     const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
     if (n == 0) return;
     const uint32_t start = s.tile_end[(size_t)v * d.T + tile] - n;
-    const int tx = tile % d.gx, ty = tile / d.gx;
-    const int st = (ty / STILE) * d.sgx + (tx / STILE);
-    const size_t c0 = ((size_t)v * d.NST + st) * CGROUPS;
-    const uint32_t cstart = s.coarse_end[c0] - s.coarse_count[c0];
-    const uint32_t nc = s.coarse_end[c0 + CGROUPS - 1] - cstart;
-    const uint4* __restrict__ list = s.coarse_list + (size_t)v * d.Rcap + cstart;
-    const uint32_t* __restrict__ dlist = s.coarse_depth + (size_t)v * d.Rcap + cstart;
     uint32_t* ids = s.id_of_slot + (size_t)v * d.Rcap;
     uint32_t* pl = s.point_list + (size_t)v * d.Rcap + start;
     uint32_t* sl = s.slot_list + (size_t)v * d.Rcap + start;
-    if (threadIdx.x == 0) { atomicMax(&s.flags[v * 4 + 1], n); fill = 0; }
     const bool by_rank = n <= RANK_MAX;
     uint32_t n2 = 2;
     while (n2 < n) n2 <<= 1;
-    uint64_t* a = sk;
-    if (n > (uint32_t)SORT_LDS_CAP) a = reinterpret_cast<uint64_t*>(s.G + (size_t)v * d.Rcap * G_STRIDE) + 2 * (size_t)start;  // n2 < 2n
-    __syncthreads();
-    // gather: every candidate of the super-tile whose tile rectangle contains (tx, ty).  Four independent
-    // candidate loads per thread are in flight at once (the scan is latency-bound: ~600 candidates per tile).
-    for (uint32_t c0 = threadIdx.x; c0 < nc; c0 += 4 * WG) {
-        uint4 e[4];
-        uint32_t dz[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t c = c0 + k * WG;
-            e[k] = c < nc ? list[c] : make_uint4(0, 0, 0, 0);  // empty rectangle: never a hit
-            dz[k] = c < nc ? dlist[c] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x0 = e[k].y & 0xffff, y0 = e[k].y >> 16, x1 = e[k].z & 0xffff, y1 = e[k].z >> 16;
-            if (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) {
-                const uint32_t slot = e[k].w + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-                const uint32_t pos = atomicAdd(&fill, 1u);  // order is irrelevant: the key is unique
-                a[pos] = ((uint64_t)dz[k] << 32) | slot;
-                if (by_rank) sid[pos] = e[k].x; else ids[slot] = e[k].x;
-            }
-        }
+    // the tile's unsorted keys (k_tile_scatter); long lists are sorted in place there (n2 < 2n slots reserved)
+    uint64_t* a = reinterpret_cast<uint64_t*>(s.G + (size_t)v * d.Rcap * G_STRIDE) + 2 * (size_t)start;
+    if (by_rank) {
+        for (uint32_t t = threadIdx.x; t < n; t += WG) { sk[t] = a[t]; sid[t] = pl[t]; }
     }
     if (by_rank) {
         __syncthreads();
         constexpr uint32_t NB = 64, KPT = SORT_LDS_CAP / WG;  // depth buckets; keys per thread
-        if (n <= 128) {
+        if (n <= GS_RANK_DIRECT_MAX) {
             // counting-rank sort: rank = #keys smaller is the final position (keys are unique); every thread ranks its
             // key against the whole list with broadcast 16-byte LDS reads
             const uint32_t ne = (n + 1) & ~1u;
@@ -440,6 +507,7 @@ __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
 
 int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.T == 0 || d.VG == 0) return GS_OK;
+    GS_TRY(launch_tile_scatter(d, s, st));
     hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T, d.VG), dim3(WG), SORT_LDS_CAP * sizeof(uint64_t), st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;

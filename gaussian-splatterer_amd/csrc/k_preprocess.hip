@@ -19,7 +19,8 @@ __device__ __constant__ float SH_C3[7] = { -0.5900435899266435f, 2.8906114426405
 
 // one (view, splat): writes the record and tiles_touched, counts the splat into its super-tiles; returns tiles_touched
 template <int D>
-__device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict__ params, const Scratch& s, int i, int v) {
+__device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict__ params, const Scratch& s, int i, int v,
+                                          uint32_t* hist) {
     const gs_view& vp = s.gviews[v];  // v indexes geometry groups here
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
@@ -168,23 +169,24 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict
     const uint32_t ntiles = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx));
     *tt = ntiles;
 
-    // coarse binning: count the splat once per 64x64-px super-tile it touches (~1.5 scattered atomics per
-    // splat instead of ~7 per-tile ones; scattered device atomics run at only ~20 G/s on MI355X, and same-address
-    // ones serialise at ~1 per microsecond, hence CGROUPS counters per super-tile)
-    uint32_t* cc = s.coarse_count + (size_t)v * d.NST * CGROUPS + (blockIdx.x % CGROUPS);
+    // coarse binning: count the splat once per 64x64-px super-tile it touches, in the workgroup's LDS histogram.
+    // (Global atomics for this cost 125 us of a 165 us launch: MI355X retires only ~10 G scattered atomics/s.)
     const int sx0 = rminx / STILE, sx1 = (rmaxx - 1) / STILE + 1, sy0 = rminy / STILE, sy1 = (rmaxy - 1) / STILE + 1;
     for (int sy = sy0; sy < sy1; sy++)
-        for (int sx = sx0; sx < sx1; sx++) atomicAdd(&cc[(sy * d.sgx + sx) * CGROUPS], 1u);
+        for (int sx = sx0; sx < sx1; sx++) atomicAdd(&hist[sy * d.sgx + sx], 1u);
     return ntiles;
 }
 
 template <int D>
 __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restrict__ params, Scratch s) {
+    extern __shared__ uint32_t hist[];  // [NST] candidates of this block per super-tile
     __shared__ uint32_t wsum[WG / 64];
     const int i = blockIdx.x * WG + threadIdx.x;
     const int v = blockIdx.y;
+    for (int k = threadIdx.x; k < d.NST; k += WG) hist[k] = 0;
+    __syncthreads();
     uint32_t n = 0;
-    if (i < d.P) n = preprocess_one<D>(d, params, s, i, v);
+    if (i < d.P) n = preprocess_one<D>(d, params, s, i, v, hist);
     // the block's share of the offsets scan (k_project_scans turns the block sums into prefixes, the coarse
     // scatter finishes the scan inside each block): no separate pass over tiles_touched
 #pragma unroll
@@ -192,16 +194,20 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
     __syncthreads();
     if (threadIdx.x == 0) s.block_sums[(size_t)v * splat_blocks(d.Pa) + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // the block's row of the (block x super-tile) count matrix: the binning needs no global atomics at all
+    uint32_t* row = s.wg_hist + ((size_t)v * splat_blocks(d.Pa) + blockIdx.x) * d.NST;
+    for (int k = threadIdx.x; k < d.NST; k += WG) row[k] = hist[k];
 }
 
 int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st) {
     if (d.P == 0 || d.VG == 0) return GS_OK;
     dim3 grid((d.P + WG - 1) / WG, d.VG);
+    const size_t lds = (size_t)d.NST * sizeof(uint32_t);
     switch (d.D) {
-        case 0: hipLaunchKernelGGL(k_preprocess<0>, grid, dim3(WG), 0, st, d, params, s); break;
-        case 1: hipLaunchKernelGGL(k_preprocess<1>, grid, dim3(WG), 0, st, d, params, s); break;
-        case 2: hipLaunchKernelGGL(k_preprocess<2>, grid, dim3(WG), 0, st, d, params, s); break;
-        default: hipLaunchKernelGGL(k_preprocess<3>, grid, dim3(WG), 0, st, d, params, s); break;
+        case 0: hipLaunchKernelGGL(k_preprocess<0>, grid, dim3(WG), lds, st, d, params, s); break;
+        case 1: hipLaunchKernelGGL(k_preprocess<1>, grid, dim3(WG), lds, st, d, params, s); break;
+        case 2: hipLaunchKernelGGL(k_preprocess<2>, grid, dim3(WG), lds, st, d, params, s); break;
+        default: hipLaunchKernelGGL(k_preprocess<3>, grid, dim3(WG), lds, st, d, params, s); break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;
