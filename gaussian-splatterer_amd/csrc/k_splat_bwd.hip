@@ -269,10 +269,18 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     const uint32_t tiles = s.tiles_touched[(size_t)g * st + i];
     const uint32_t first = s.point_offsets[(size_t)g * st + i] - tiles;
     float sum[9];
+#ifdef GS_EXP_NO_GATHER  // timing experiments only (tools/build_variant.sh)
+    gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, first, tiles ? 1u : 0u, sum);
+#else
     gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, first, tiles, sum);
+#endif
     SplatOut<D> o;
     float dRGB[3];
+#ifdef GS_EXP_NO_SH
+    auto sh_at = [&](int k, int c) { return (float)(k + c); };
+#else
     auto sh_at = [&](int k, int c) { return params[pl.sh(k, c) * st + i]; };  // streamed: no 48-register SH array
+#endif
     splat_backward_core<D, false>(s.gviews[g], d.W, d.H, mean, sc, q, sh_at, rec->flags, sum, sum[3], sum[4], sum[5], sum[6], sum[7], o, dRGB);
     out[0] = make_float4(o.mean[0], o.mean[1], o.mean[2], o.scale[0]);
     out[1] = make_float4(o.scale[1], o.scale[2], o.rot[0], o.rot[1]);
