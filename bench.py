@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--update", choices=["adam", "sgd"], default="adam")
     ap.add_argument("--collective", choices=["torch", "rccl"], default="torch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-views", type=int, default=2, help="views of the workload the CPU baseline leg times")
+    ap.add_argument("--cpu-views", type=int, default=16, help="views of the workload the CPU baseline leg times")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and the collective hook even with one rank (plumbing test)")
     ap.add_argument("--no-stage-events", action="store_true", help="diagnostic only: time the steps without the per-stage HIP events (no roofline object)")
     ap.add_argument("--views", type=int, default=0, help="diagnostic only: override the number of views per step (not the metric's config)")
