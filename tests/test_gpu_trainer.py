@@ -258,3 +258,22 @@ def test_scan_forms_agree(orc):
     assert res[0][:3] == res[1][:3] and res[0][0] > 0
     for k in res[0][3]:
         assert np.array_equal(res[0][3][k].view(np.uint32), res[1][3][k].view(np.uint32)), k
+
+
+def test_steps_without_stats_run_ahead_and_agree(orc):
+    """gs_trainer_step without a stats request returns while the device is still working (the host only waits for the
+    early overflow verdict).  Six such steps back to back must leave exactly the model that six observed steps leave,
+    and the statistics fetched afterwards are those of the last step."""
+    P, M, n_cams, W, H = 3000, 4, 2, 160, 96
+    proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=2e-3, lrSh=5e-3, lrScale=5e-4, lrOpacity=5e-3, lrRotation=1e-3)
+    res = []
+    for observed in (True, False):
+        s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 77)
+        for _ in range(5):
+            tr.train(proj, stats=observed)
+        st = tr.train(proj, stats=True)
+        res.append((st.loss, st.num_rendered, st.max_tile_list, _download(tr)))
+        tr.close()
+    assert res[0][:3] == res[1][:3]
+    for k in ("loc", "sh", "scale", "opac", "rot"):
+        assert np.array_equal(res[0][3][k].view(np.uint32), res[1][3][k].view(np.uint32)), k
