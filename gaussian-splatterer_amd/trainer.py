@@ -153,6 +153,25 @@ class Trainer:
         capi.check(capi.lib().gs_trainer_step(self.handle, C.byref(h), int(bool(densify)), C.byref(st) if stats else None))
         return st if stats else None
 
+    def accumulate(self, stats=False):
+        """First half of train() (src/Trainer.cu:303-425): every pass's forward, loss, backward and gradient averaging.
+        The averaged gradients are complete in grad_buffer() on return; the data-parallel driver reduces them here."""
+        if not self.truthFrameBuffersW:
+            raise RuntimeError("Can't run training iteration, no truth data available!")
+        if self._views_dirty:
+            self._upload_views()
+        st = capi.gs_step_stats()
+        capi.check(capi.lib().gs_trainer_accumulate(self.handle, C.byref(st) if stats else None))
+        return st if stats else None
+
+    def apply(self, project, densify=False, stats=False):
+        """Second half of train() (src/Trainer.cu:427-542): the update and, when asked, densify/prune."""
+        project.iterations += 1
+        h = project.hyper()
+        st = capi.gs_step_stats()
+        capi.check(capi.lib().gs_trainer_apply(self.handle, C.byref(h), int(bool(densify)), C.byref(st) if stats else None))
+        return st if stats else None
+
     def render(self, sizeX, sizeY, splatScale, camera, background=(0.0, 0.0, 0.0)):
         """Trainer::render, src/Trainer.cu:148-216; returns the RGBA8 framebuffer as uint32[sizeY, sizeX]."""
         import math

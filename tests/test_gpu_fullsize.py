@@ -1,0 +1,177 @@
+"""BASELINE.json's FULL sizes (cfg2: 10k splats, 8 passes @512^2; cfg3: 100k splats, 16 passes @1024^2, SH degree 3)
+on the GPU, checked through properties that do not need the oracle to run at that size:
+
+* the sorted tile lists ARE a stable sort of (tile, depth) over the emitted (splat, tile) pairs (sortedness, stability,
+  multiset equality with tiles_touched, ranges partition [0, R));
+* white-background image minus black-background image = final_T, exactly the blend identity of Appendix A.6;
+* the backward is linear in dL/dpixel: doubling the input doubles every output BIT FOR BIT (power-of-two scaling is
+  exact in fp32), through the same reductions;
+* culling on/off, camera-pass sharing on/off and repeated runs agree bit for bit; the split API equals the fused step;
+* the model survives upload -> download unchanged, a clone equals its source.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gsplat_amd as gs
+from gsplat_amd import capi
+from util import REC_DTYPE, SeamRaster, make_scene, view_parts
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(idx):
+    P, M, V, W, H = gs.synth.CONFIGS[idx]
+    D = gs.synth.sh_degree_for(M)
+    s = gs.synth.random_splats(P, M, gs.synth.seed_for(idx))
+    cams = gs.camera.get_cameras(max(V // 2, 1))
+    return P, M, D, V, W, H, s, cams
+
+
+def _product_truths(s_truth, D, cams, W, H):
+    """Truth images rendered by the product's own preview path (content is irrelevant to these properties)."""
+    host = gs.ModelSplatsHost.fromVectors(s_truth["loc"], s_truth["sh"], s_truth["scale"], s_truth["opac"], s_truth["rot"])
+    host.shDegree = D
+    tr = gs.Trainer(W, H)
+    tr.model = gs.ModelSplatsDevice(host)
+    fw = [tr.render(W, H, 1.0, c, background=(1.0, 1.0, 1.0)).reshape(-1) for c in cams]
+    fb = [tr.render(W, H, 1.0, c, background=(0.0, 0.0, 0.0)).reshape(-1) for c in cams]
+    tr.close()
+    return fw, fb
+
+
+def _trainer(idx):
+    P, M, D, V, W, H, s, cams = _cfg(idx)
+    t = gs.synth.random_splats(max(P // 2, 1), M, gs.synth.seed_for(idx) + 1000)
+    fw, fb = _product_truths(t, D, cams, W, H)
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = D
+    tr = gs.Trainer(W, H)
+    tr.model = gs.ModelSplatsDevice(host)
+    tr.captureTruths(cams, fw, fb)
+    return tr, s, P, M
+
+
+def _download(tr):
+    h = gs.ModelSplatsHost.fromDevice(tr.model)
+    return dict(loc=h.locations.copy(), sh=h.shs.copy(), scale=h.scales.copy(), opac=h.opacities.copy(), rot=h.rotations.copy())
+
+
+def _grads(tr):
+    ptr, n = tr.grad_buffer()
+    tr.synchronize()
+    buf = np.empty(n, np.float32)
+    capi.check(capi.lib().gs_memcpy_d2h(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n * 4))
+    return buf
+
+
+@pytest.mark.parametrize("idx", [2, 3])
+def test_lists_are_the_stable_sort_and_blend_identity(idx):
+    P, M, D, V, W, H, s, cams = _cfg(idx)
+    views = gs.camera.train_views(cams, W, H)
+    n_cams = len(cams)
+    vw, vb = view_parts(views[1]), view_parts(views[n_cams + 1])   # camera 1, white and black background
+    sr = SeamRaster()
+    out_w, R = sr.forward(s, D, M, vw, W, H)
+    tt = sr.field("geometry", "tiles_touched", np.uint32)
+    po = sr.field("geometry", "point_offsets", np.uint32)
+    rec = sr.field("geometry", "record", np.uint8).view(REC_DTYPE)
+    pl = sr.field("binning", "point_list", np.uint32)
+    ranges = sr.field("image", "ranges", np.uint32).reshape(-1, 2).astype(np.int64)
+    assert R > P and int(tt.sum(dtype=np.int64)) == R == int(po[-1])
+    assert np.array_equal(np.cumsum(tt, dtype=np.uint64).astype(np.uint32), po)
+    # ranges: non-empty tiles partition [0, R) in tile order
+    ne = ranges[ranges[:, 1] > ranges[:, 0]]
+    assert ne[0, 0] == 0 and ne[-1, 1] == R and np.array_equal(ne[1:, 0], ne[:-1, 1])
+    # every splat appears once per tile it touches, inside its rectangle
+    assert np.array_equal(np.bincount(pl, minlength=P).astype(np.uint32), tt)
+    gx = (W + 15) // 16
+    lens = (ranges[:, 1] - ranges[:, 0]).clip(min=0)
+    tile_of_entry = np.repeat(np.arange(len(ranges)), lens)
+    tx, ty = tile_of_entry % gx, tile_of_entry // gx
+    r0, r1 = rec["rect_min"][pl], rec["rect_max"][pl]
+    assert np.all((tx >= (r0 & 0xffff)) & (tx < (r1 & 0xffff)) & (ty >= (r0 >> 16)) & (ty < (r1 >> 16)))
+    # sorted by (tile, depth bits), ties in ascending splat id: upstream's stable radix sort of (tile << 32 | depth)
+    key = (tile_of_entry.astype(np.uint64) << np.uint64(32)) | rec["depth"][pl].view(np.uint32).astype(np.uint64)
+    assert np.all(key[1:] >= key[:-1])
+    tie = key[1:] == key[:-1]
+    assert np.all(pl[1:][tie] > pl[:-1][tie])
+    fT = sr.field("image", "final_T", np.float32)
+    ncon = sr.field("image", "n_contrib", np.uint32)
+    assert fT.min() >= 0.0 and fT.max() <= 1.0
+    px_tile = (np.arange(H)[:, None] // 16) * gx + (np.arange(W)[None, :] // 16)
+    assert np.all(ncon.reshape(H, W) <= lens[px_tile])
+    # blend identity: the two backgrounds differ by exactly T per channel (fp32: one rounding of C + T*bg)
+    sb = SeamRaster()
+    out_b, Rb = sb.forward(s, D, M, vb, W, H)
+    assert Rb == R and np.array_equal(sb.field("binning", "point_list", np.uint32), pl)
+    for c in range(3):
+        assert np.abs((out_w[c] - out_b[c]).reshape(-1) - fT).max() <= 2e-7 * max(1.0, float(out_w[c].max()))
+
+
+def test_backward_is_exactly_linear_under_doubling_cfg3():
+    P, M, D, V, W, H, s, cams = _cfg(3)
+    views = gs.camera.train_views(cams, W, H)
+    sr = SeamRaster()
+    sr.forward(s, D, M, view_parts(views[0]), W, H)
+    rng = np.random.default_rng(5)
+    dpix = rng.uniform(-1, 1, (3, H, W)).astype(np.float32)
+    g1 = sr.backward(dpix)
+    g2 = sr.backward(2.0 * dpix)
+    again = sr.backward(dpix)
+    for k in g1:
+        assert np.array_equal(g1[k].view(np.uint32), again[k].view(np.uint32)), k            # reproducible
+        assert np.array_equal((2.0 * g1[k]).view(np.uint32), g2[k].view(np.uint32)), k       # linear, exactly
+    assert np.abs(g1["dL_dmean3D"]).max() > 0 and np.isfinite(g1["dL_dsh"]).all()
+
+
+@pytest.mark.parametrize("option", ["cull", "share_camera_passes"])
+def test_switches_do_not_change_a_bit_at_cfg3(option):
+    res = []
+    for value in (1, 0):
+        capi.check(capi.lib().gs_set_option(option.encode(), value))
+        try:
+            tr, s, P, M = _trainer(3)
+            st = tr.train(gs.Project(updateRule=capi.GS_UPDATE_ADAM), stats=True)
+            res.append((st.num_rendered, st.max_tile_list, st.loss, _grads(tr), _download(tr)))
+            tr.close()
+        finally:
+            capi.check(capi.lib().gs_set_option(option.encode(), 1))
+    assert res[0][:3] == res[1][:3]
+    assert np.array_equal(res[0][3].view(np.uint32), res[1][3].view(np.uint32))
+    for k in res[0][4]:
+        assert np.array_equal(res[0][4][k].view(np.uint32), res[1][4][k].view(np.uint32)), k
+
+
+def test_step_is_reproducible_and_equals_the_split_api_cfg3():
+    proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM)
+    models = []
+    for mode in ("fused", "fused", "split"):
+        tr, s, P, M = _trainer(3)
+        for _ in range(3):
+            if mode == "fused":
+                tr.train(proj)
+            else:
+                tr.accumulate()
+                tr.apply(proj)
+        models.append(_download(tr))
+        tr.close()
+    for other in models[1:]:
+        for k in models[0]:
+            assert np.array_equal(models[0][k].view(np.uint32), other[k].view(np.uint32)), k
+    assert not np.array_equal(models[0]["loc"], s["loc"].reshape(-1))   # the steps did move the model
+
+
+@pytest.mark.parametrize("idx", [2, 3])
+def test_model_round_trip_full_size(idx):
+    P, M, D, V, W, H, s, cams = _cfg(idx)
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    dev = gs.ModelSplatsDevice(host)
+    clone = gs.ModelSplatsDevice(dev)
+    for d in (dev, clone):
+        back = gs.ModelSplatsHost.fromDevice(d)
+        assert back.count == P and back.shCoeffs == M
+        for name, want in [("locations", s["loc"]), ("shs", s["sh"]), ("scales", s["scale"]), ("opacities", s["opac"]), ("rotations", s["rot"])]:
+            got = getattr(back, name)[:want.size]
+            assert np.array_equal(np.asarray(got).view(np.uint32), np.asarray(want, np.float32).reshape(-1).view(np.uint32)), name
