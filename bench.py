@@ -175,6 +175,13 @@ def main():
     capi.check(L.gs_trainer_stage_times(tr.handle, ms, launches))
     capi.check(L.gs_trainer_set_profiling(tr.handle, 0))
     st = tr.train(proj, densify=False, stats=True) if st is None else st
+    # untimed, reported separately: one step WITH densify/prune, as the driver loop runs every 200th iteration
+    densify_ms = None
+    if not use_dist:
+        tr.synchronize()
+        t_d = time.perf_counter()
+        st_d = tr.train(proj, densify=True, stats=True)
+        densify_ms = (time.perf_counter() - t_d) * 1e3
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -239,6 +246,8 @@ def main():
                          "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
             "stages_note": "all-stage table: HIP events over %d extra steps run after the timed region (timing every stage costs ~3 us of stream time per event)" % min(args.steps, 10),
+            "densify_step": None if densify_ms is None else {"ms": round(densify_ms, 3), "count_before": st_d.count_before, "count_after": st_d.count_after,
+                             "note": "one extra step with densify/prune after the timed region (the driver loop does this every 200th iteration); includes the step itself"},
             "setup_seconds": round(setup_s, 2),
         }
         if not args.no_cpu_baseline and world == 1:

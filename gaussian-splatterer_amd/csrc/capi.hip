@@ -703,24 +703,38 @@ extern "C" int gs_trainer_grad_buffer(gs_trainer* t, float** p, size_t* n) {
     return GS_OK;
 }
 
+// Densify / prune on the device (k_densify.hip): classify + three prefix sums, one read-back of the three totals to
+// size the new planes, one emit pass.  The model object keeps its identity (callers hold the pointer).
 static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) {
     gs_model* m = t->model;
     const int M = m->sh_coeffs, cap = m->capacity, count = m->count;
-    GS_HIP(hipStreamSynchronize(t->stream));
-    std::vector<float> loc((size_t)cap * 3), sh((size_t)cap * 3 * M), scale((size_t)cap * 3), opac((size_t)cap), rot((size_t)cap * 4);
-    GS_TRY(gs_model_download(m, loc.data(), sh.data(), scale.data(), opac.data(), rot.data()));
-    const Planes pl{ M };
-    std::vector<float> var((size_t)count), gl((size_t)count * 3), plane((size_t)count);
-    const float* g = t->grad.as<float>();
-    GS_HIP(hipMemcpy(var.data(), g + (size_t)pl.var() * t->grad_Pa, (size_t)count * 4, hipMemcpyDeviceToHost));
-    for (int c = 0; c < 3; c++) {
-        GS_HIP(hipMemcpy(plane.data(), g + (size_t)pl.loc(c) * t->grad_Pa, (size_t)count * 4, hipMemcpyDeviceToHost));
-        for (int i = 0; i < count; i++) gl[3 * (size_t)i + c] = plane[i];
-    }
-    const int n2 = densify_host(loc.data(), sh.data(), scale.data(), opac.data(), rot.data(), count, cap, M, var.data(), gl.data(), *h);
+    st->count_after = count;
+    if (count == 0) return GS_OK;
+    const int fs = round_up(count, 64);
+    DevBuf work;  // flags[3][fs] | ranks[3][fs] | scan partials
+    const size_t npart = scan_partials_count(count, 3) + 64;
+    GS_TRY(work.ensure(((size_t)6 * fs + npart) * 4));
+    uint32_t* flags = work.as<uint32_t>();
+    uint32_t* ranks = flags + (size_t)3 * fs;
+    uint32_t* partials = ranks + (size_t)3 * fs;
+    int rc = launch_densify_classify(count, m->Pa, M, m->planes, t->grad.as<float>(), *h, flags, ranks, fs, partials, t->stream);
+    uint32_t totals[3] = { 0, 0, 0 };
+    for (int k = 0; k < 3 && rc == GS_OK; k++)
+        if (hipMemcpyAsync(&totals[k], ranks + (size_t)k * fs + (count - 1), 4, hipMemcpyDeviceToHost, t->stream) != hipSuccess) rc = GS_ERR_HIP;
+    if (rc == GS_OK && hipStreamSynchronize(t->stream) != hipSuccess) rc = GS_ERR_HIP;
+    if (rc != GS_OK) { work.release(); if (rc == GS_ERR_HIP) set_error("densify failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
+    const int n_split = (int)totals[0], n_clone = (int)totals[1], kept = (int)totals[2];
+    const int splits_done = std::min(n_split, std::max(0, cap - count));
+    const int clones_done = std::min(n_clone, std::max(0, cap - count - splits_done));
+    const int n2 = kept + splits_done + clones_done;
     gs_model* fresh = nullptr;
-    GS_TRY(gs_model_create(cap, m->sh_degree, M, n2, loc.data(), sh.data(), scale.data(), opac.data(), rot.data(), &fresh));
-    // keep the gs_model object's identity (callers hold the pointer): swap the new planes in
+    rc = model_alloc(cap, m->sh_degree, M, n2, &fresh);
+    if (rc == GS_OK && hipDeviceSynchronize() != hipSuccess) rc = GS_ERR_HIP;  // model_alloc clears the planes on the null stream; ours does not wait for it
+    if (rc == GS_OK) rc = launch_densify_emit(count, m->Pa, M, m->planes, t->grad.as<float>(), *h, flags, ranks, fs, splits_done, clones_done, kept,
+                                              fresh->Pa, fresh->planes, t->stream);
+    if (rc == GS_OK && hipStreamSynchronize(t->stream) != hipSuccess) { rc = GS_ERR_HIP; set_error("densify failed: %s", hipGetErrorString(hipGetLastError())); }
+    work.release();
+    if (rc != GS_OK) { if (fresh) gs_model_destroy(fresh); return rc; }
     std::swap(m->planes, fresh->planes);
     m->Pa = fresh->Pa; m->count = fresh->count;
     gs_model_destroy(fresh);

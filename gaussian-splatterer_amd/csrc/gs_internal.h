@@ -154,9 +154,11 @@ int launch_image_int_to_loss(const uint32_t* truth, const float* rast, float* lo
 int launch_ranges(const Dims& d, const Scratch& s, uint32_t* ranges, hipStream_t st);
 int launch_debug_reduce9(const float* in, float* out, hipStream_t st);
 
-// host-side densify (the reference does this on the CPU too, src/Trainer.cu:433-542)
-int densify_host(float* loc, float* sh, float* scale, float* opac, float* rot, int count, int capacity, int M,
-                 const float* var, const float* grad_loc, const gs_hyper& h);
+// densify / prune on the device (k_densify.hip; the reference does it on the CPU, src/Trainer.cu:433-542)
+int launch_densify_classify(int count, int Pa, int M, const float* params, const float* grad, const gs_hyper& h, uint32_t* flags,
+                            uint32_t* ranks, int fs, uint32_t* partials, hipStream_t st);
+int launch_densify_emit(int count, int Pa, int M, const float* params, const float* grad, const gs_hyper& h, const uint32_t* flags,
+                        const uint32_t* ranks, int fs, int splits_done, int clones_done, int kept, int outPa, float* out, hipStream_t st);
 
 }  // namespace gs
 

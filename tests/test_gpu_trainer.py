@@ -113,9 +113,20 @@ def test_training_reduces_loss(orc):
     tr.close()
 
 
-def test_densify_matches_oracle(orc):
+@pytest.mark.parametrize("room", [None, 1000, 25, 0])
+def test_densify_matches_oracle(orc, room):
+    """Densify / prune runs on the device (k_densify.hip) and must equal the oracle's restatement of
+    src/Trainer.cu:433-542 bit for bit — also when the capacity stops the splits or the clones part-way (`room` free
+    slots: the s-th split happens iff count + s < capacity, then the clones)."""
     P, M, n_cams, W, H = 1200, 4, 2, 96, 96
     s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 123)
+    cap = 1000000 if room is None else P + room
+    if room is not None:
+        host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+        host.shDegree = s["D"]
+        host.capacity = cap
+        tr.model = gs.ModelSplatsDevice(host)
+        assert tr.model.capacity == cap
     # thresholds chosen so that all three actions fire on the synthetic scene
     proj = gs.Project(paramDensifyVariance=0.05, paramCullOpacity=0.15, paramSplitSize=0.06)
     h = proj.hyper()
@@ -126,7 +137,6 @@ def test_densify_matches_oracle(orc):
     st = capi.gs_step_stats()
     capi.check(L.gs_trainer_apply(tr.handle, C.byref(h), 1, C.byref(st)))
     got = _download(tr)
-    cap = 1000000
     want = {k: np.zeros(cap * n, np.float32) for k, n in [("loc", 3), ("sh", 3 * M), ("scale", 3), ("opac", 1), ("rot", 4)]}
     pre = {k: s[k].copy() for k in ["loc", "sh", "scale", "opac", "rot"]}
     orc.apply_sgd(pre["loc"], pre["sh"], pre["scale"], pre["opac"], pre["rot"], g,
@@ -138,7 +148,7 @@ def test_densify_matches_oracle(orc):
               clone_distance=proj.paramCloneDistance)
     n2 = orc.densify(want["loc"], want["sh"], want["scale"], want["opac"], want["rot"], P, cap, M, g["var"], g["loc"], hp, 1)
     assert st.count_before == P and st.count_after == n2 == got["count"]
-    assert n2 != P
+    assert n2 != P and n2 <= cap
     for k, n in [("loc", 3), ("sh", 3 * M), ("scale", 3), ("opac", 1), ("rot", 4)]:
         assert np.array_equal(got[k].view(np.uint32), want[k][:n * n2].view(np.uint32)), k
     # the trainer keeps stepping on the re-indexed model
