@@ -446,10 +446,11 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
                     dchannel_dcolor = alpha * T;
                     // upstream blends (last_alpha, last_color) into accum_rec BEFORE using it; doing the same blend with
                     // this entry's (alpha, colour) AFTER use is the identical recurrence one step early
+                    // (alpha*c + (1-alpha)*ar written as ar + alpha*(c - ar): one fma on the difference that is needed anyway)
                     const float c0 = Bc.z - ar0, c1 = Bc.w - ar1, c2 = cbc - ar2;
-                    ar0 = alpha * Bc.z + keep * ar0;
-                    ar1 = alpha * Bc.w + keep * ar1;
-                    ar2 = alpha * cbc + keep * ar2;
+                    ar0 = fmaf(alpha, c0, ar0);
+                    ar1 = fmaf(alpha, c1, ar1);
+                    ar2 = fmaf(alpha, c2, ar2);
                     const float GT = G * T, Gi = G * inv1ma;
 #pragma unroll
                     for (int p = 0; p < K; p++) {
