@@ -212,10 +212,23 @@ __device__ inline void splat_backward_core(const gs_view& vp, int W, int H, cons
 __device__ inline void gather_rows(const float* __restrict__ Gv, uint32_t first, uint32_t tiles, float sum[9]) {
 #pragma unroll
     for (int q = 0; q < 9; q++) sum[q] = 0.0f;
-    for (uint32_t k = 0; k < tiles; k++) {
-        const float4* row = reinterpret_cast<const float4*>(Gv + (size_t)(first + k) * G_STRIDE);
+    const float4* row = reinterpret_cast<const float4*>(Gv + (size_t)first * G_STRIDE);
+    uint32_t k = 0;
+    // four rows in flight per trip (the loop is latency-bound: a splat touches ~7 tiles); the adds keep slot order
+    for (; k + 4 <= tiles; k += 4, row += 12) {
+        float4 a[4], b[4];
+        float c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { a[j] = row[3 * j]; b[j] = row[3 * j + 1]; c[j] = reinterpret_cast<const float*>(row + 3 * j + 2)[0]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            sum[0] += a[j].x; sum[1] += a[j].y; sum[2] += a[j].z; sum[3] += a[j].w;
+            sum[4] += b[j].x; sum[5] += b[j].y; sum[6] += b[j].z; sum[7] += b[j].w; sum[8] += c[j];
+        }
+    }
+    for (; k < tiles; k++, row += 3) {
         const float4 a = row[0], b = row[1];
-        const float c = reinterpret_cast<const float*>(row)[8];
+        const float c = reinterpret_cast<const float*>(row + 2)[0];
         sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w;
         sum[4] += b.x; sum[5] += b.y; sum[6] += b.z; sum[7] += b.w; sum[8] += c;
     }
