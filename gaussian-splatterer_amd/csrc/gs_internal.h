@@ -106,6 +106,7 @@ struct Scratch {
     uint32_t* slot_list;       // [V][Rcap]  sorted slots
     float* G;                  // [V][Rcap][G_STRIDE]
     float* splat_grads;        // [V][Pa][16]  per-(view,splat) backward records (trainer only)
+    float* sh_jac;             // [G][Pa][12]  d colour / d view direction (9 used), written by the projection (trainer only, else null)
     float* out_color;          // [V][3][N]
     float* final_T;            // [V][N]
     uint32_t* n_contrib;       // [V][N]

@@ -6,6 +6,7 @@
 // individually rounded IEEE operation in the same order as oracle/gs_oracle.cpp::preprocess, so
 // depth, radius and tile rectangle (and therefore the sorted tile lists) are bit-identical.
 #include "gs_internal.h"
+#include "sh_jac.h"
 
 namespace gs {
 
@@ -114,7 +115,7 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict
     float dx = px_ - vp.campos[0], dy = py_ - vp.campos[1], dz = pz_ - vp.campos[2];
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     dx = dx / len; dy = dy / len; dz = dz / len;
-    float res[3];
+    float res[3], jac[9];
     uint32_t flags = 0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -142,6 +143,13 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict
         val += 0.5f;
         if (val < 0.0f) flags |= (1u << c);
         res[c] = fmaxf(val, 0.0f);
+        if (s.sh_jac) sh_direction_jacobian<D>(dx, dy, dz, [&](int k) { return params[pl.sh(k, c) * st + i]; }, jac[3 * c], jac[3 * c + 1], jac[3 * c + 2]);
+    }
+    if (s.sh_jac) {  // for the per-splat backward of every pass of this camera (sh_jac.h)
+        float4* jrec = reinterpret_cast<float4*>(s.sh_jac + ((size_t)v * st + i) * 12);
+        jrec[0] = make_float4(jac[0], jac[1], jac[2], jac[3]);
+        jrec[1] = make_float4(jac[4], jac[5], jac[6], jac[7]);
+        jrec[2] = make_float4(jac[8], 0.0f, 0.0f, 0.0f);
     }
 
     // Cull threshold: a pixel contributes only if alpha = min(0.99, opacity*exp(-q)) >= 1/255, i.e. only where the

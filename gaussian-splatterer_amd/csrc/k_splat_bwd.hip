@@ -7,6 +7,7 @@
 // sums that splat's (splat,tile) gradient rows (contiguous slots, fixed order), and writes every
 // averaged-gradient plane exactly once per step — no per-view read-modify-write, no atomics.
 #include "gs_internal.h"
+#include "sh_jac.h"
 
 namespace gs {
 
@@ -26,11 +27,12 @@ template <int D> struct SplatOut {
     float sh[NC][3];
 };
 
-// in: mean, s = mod*scale, quaternion (r,x,y,z), sh[NC][3], view, clamp flags, the pixel-stage sums
-// (colour 3, mean2D 2, conic x/y/w 3).  Mirrors oracle/gs_oracle.cpp::preprocess_backward.
-template <int D, bool WANT_SH, class ShAt>
+// in: mean, s = mod*scale, quaternion (r,x,y,z), view, clamp flags, the pixel-stage sums (colour 3, mean2D 2, conic
+// x/y/w 3) and `jac(ch, X, Y, Z, dx, dy, dz)` = d colour[ch] / d direction (sh_jac.h: evaluated from the SH
+// coefficients, or read back from the projection's record).  Mirrors oracle/gs_oracle.cpp::preprocess_backward.
+template <int D, bool WANT_SH, class JacAt>
 __device__ inline void splat_backward_core(const gs_view& vp, int W, int H, const float mean[3], const float s[3],
-                                           const float q[4], ShAt sh, uint32_t clamp_flags,
+                                           const float q[4], JacAt jac, uint32_t clamp_flags,
                                            const float dcolor[3], float g2x, float g2y, float gcx, float gcy, float gcz,
                                            SplatOut<D>& o, float dRGB_out[3]) {
     const float* view = vp.view;
@@ -140,41 +142,23 @@ __device__ inline void splat_backward_core(const gs_view& vp, int W, int H, cons
             float dx_ = 0, dy_ = 0, dz_ = 0;
             dRGB_out[ch] = dl;
             if constexpr (WANT_SH) o.sh[0][ch] = C0 * dl;
-            if constexpr (D > 0) {
-                if constexpr (WANT_SH) { o.sh[1][ch] = (-C1 * Y) * dl; o.sh[2][ch] = (C1 * Z) * dl; o.sh[3][ch] = (-C1 * X) * dl; }
-                dx_ = -C1 * sh(3, ch); dy_ = -C1 * sh(1, ch); dz_ = C1 * sh(2, ch);
-            }
-            if constexpr (D > 1) {
+            if constexpr (WANT_SH && D > 0) { o.sh[1][ch] = (-C1 * Y) * dl; o.sh[2][ch] = (C1 * Z) * dl; o.sh[3][ch] = (-C1 * X) * dl; }
+            if constexpr (WANT_SH && D > 1) {
                 const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
-                if constexpr (WANT_SH) {
-                    o.sh[4][ch] = (C2_0 * xy) * dl; o.sh[5][ch] = (C2_1 * yz) * dl;
-                    o.sh[6][ch] = (C2_2 * (2.0f * zz - xx - yy)) * dl; o.sh[7][ch] = (C2_3 * xz) * dl;
-                    o.sh[8][ch] = (C2_4 * (xx - yy)) * dl;
-                }
-                dx_ += C2_0 * Y * sh(4, ch) + C2_2 * 2.0f * -X * sh(6, ch) + C2_3 * Z * sh(7, ch) + C2_4 * 2.0f * X * sh(8, ch);
-                dy_ += C2_0 * X * sh(4, ch) + C2_1 * Z * sh(5, ch) + C2_2 * 2.0f * -Y * sh(6, ch) + C2_4 * 2.0f * -Y * sh(8, ch);
-                dz_ += C2_1 * Y * sh(5, ch) + C2_2 * 2.0f * 2.0f * Z * sh(6, ch) + C2_3 * X * sh(7, ch);
+                o.sh[4][ch] = (C2_0 * xy) * dl; o.sh[5][ch] = (C2_1 * yz) * dl;
+                o.sh[6][ch] = (C2_2 * (2.0f * zz - xx - yy)) * dl; o.sh[7][ch] = (C2_3 * xz) * dl;
+                o.sh[8][ch] = (C2_4 * (xx - yy)) * dl;
                 if constexpr (D > 2) {
-                    if constexpr (WANT_SH) {
-                        o.sh[9][ch] = (C3_0 * Y * (3.0f * xx - yy)) * dl;
-                        o.sh[10][ch] = (C3_1 * xy * Z) * dl;
-                        o.sh[11][ch] = (C3_2 * Y * (4.0f * zz - xx - yy)) * dl;
-                        o.sh[12][ch] = (C3_3 * Z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * dl;
-                        o.sh[13][ch] = (C3_4 * X * (4.0f * zz - xx - yy)) * dl;
-                        o.sh[14][ch] = (C3_5 * Z * (xx - yy)) * dl;
-                        o.sh[15][ch] = (C3_6 * X * (xx - 3.0f * yy)) * dl;
-                    }
-                    dx_ += C3_0 * sh(9, ch) * 3.0f * 2.0f * xy + C3_1 * sh(10, ch) * yz + C3_2 * sh(11, ch) * -2.0f * xy +
-                           C3_3 * sh(12, ch) * -3.0f * 2.0f * xz + C3_4 * sh(13, ch) * (-3.0f * xx + 4.0f * zz - yy) +
-                           C3_5 * sh(14, ch) * 2.0f * xz + C3_6 * sh(15, ch) * 3.0f * (xx - yy);
-                    dy_ += C3_0 * sh(9, ch) * 3.0f * (xx - yy) + C3_1 * sh(10, ch) * xz +
-                           C3_2 * sh(11, ch) * (-3.0f * yy + 4.0f * zz - xx) + C3_3 * sh(12, ch) * -3.0f * 2.0f * yz +
-                           C3_4 * sh(13, ch) * -2.0f * xy + C3_5 * sh(14, ch) * -2.0f * yz + C3_6 * sh(15, ch) * -3.0f * 2.0f * xy;
-                    dz_ += C3_1 * sh(10, ch) * xy + C3_2 * sh(11, ch) * 4.0f * 2.0f * yz +
-                           C3_3 * sh(12, ch) * 3.0f * (2.0f * zz - xx - yy) + C3_4 * sh(13, ch) * 4.0f * 2.0f * xz +
-                           C3_5 * sh(14, ch) * (xx - yy);
+                    o.sh[9][ch] = (C3_0 * Y * (3.0f * xx - yy)) * dl;
+                    o.sh[10][ch] = (C3_1 * xy * Z) * dl;
+                    o.sh[11][ch] = (C3_2 * Y * (4.0f * zz - xx - yy)) * dl;
+                    o.sh[12][ch] = (C3_3 * Z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * dl;
+                    o.sh[13][ch] = (C3_4 * X * (4.0f * zz - xx - yy)) * dl;
+                    o.sh[14][ch] = (C3_5 * Z * (xx - yy)) * dl;
+                    o.sh[15][ch] = (C3_6 * X * (xx - 3.0f * yy)) * dl;
                 }
             }
+            jac(ch, X, Y, Z, dx_, dy_, dz_);
             ddx += dx_ * dl; ddy += dy_ * dl; ddz += dz_ * dl;
         }
         const float sum2 = ox * ox + oy * oy + oz * oz;
@@ -289,12 +273,13 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
 #endif
     SplatOut<D> o;
     float dRGB[3];
-#ifdef GS_EXP_NO_SH
-    auto sh_at = [&](int k, int c) { return (float)(k + c); };
-#else
-    auto sh_at = [&](int k, int c) { return params[pl.sh(k, c) * st + i]; };  // streamed: no 48-register SH array
-#endif
-    splat_backward_core<D, false>(s.gviews[g], d.W, d.H, mean, sc, q, sh_at, rec->flags, sum, sum[3], sum[4], sum[5], sum[6], sum[7], o, dRGB);
+    // d colour / d direction was evaluated by the projection (same camera for every pass of the group): 9 floats
+    // instead of 3*M SH coefficients per (pass, splat)
+    const float4* jrec = reinterpret_cast<const float4*>(s.sh_jac + ((size_t)g * st + i) * 12);
+    const float4 j0 = jrec[0], j1 = jrec[1], j2 = jrec[2];
+    const float jv[9] = { j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, j2.x };
+    auto jac_at = [&](int ch, float, float, float, float& dx_, float& dy_, float& dz_) { dx_ = jv[3 * ch]; dy_ = jv[3 * ch + 1]; dz_ = jv[3 * ch + 2]; };
+    splat_backward_core<D, false>(s.gviews[g], d.W, d.H, mean, sc, q, jac_at, rec->flags, sum, sum[3], sum[4], sum[5], sum[6], sum[7], o, dRGB);
     out[0] = make_float4(o.mean[0], o.mean[1], o.mean[2], o.scale[0]);
     out[1] = make_float4(o.scale[1], o.scale[2], o.rot[0], o.rot[1]);
     out[2] = make_float4(o.rot[2], o.rot[3], sum[8], dRGB[0]);
@@ -407,8 +392,10 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_seam(Dims d, const float* __re
     g.dL_dopacity[i] += sum[8];
     SplatOut<D> o;
     float dRGB[3];
-    auto sh_at = [&](int k, int c) { return sh[k][c]; };
-    splat_backward_core<D, true>(s.views[0], d.W, d.H, mean, sc, q, sh_at, rec->flags, dcolor, g2x, g2y, gcx, gcy, gcz, o, dRGB);
+    auto jac_at = [&](int ch, float X, float Y, float Z, float& dx_, float& dy_, float& dz_) {
+        sh_direction_jacobian<D>(X, Y, Z, [&](int k) { return sh[k][ch]; }, dx_, dy_, dz_);
+    };
+    splat_backward_core<D, true>(s.views[0], d.W, d.H, mean, sc, q, jac_at, rec->flags, dcolor, g2x, g2y, gcx, gcy, gcz, o, dRGB);
     for (int c = 0; c < 3; c++) { g.dL_dmean3D[3 * (size_t)i + c] = o.mean[c]; g.dL_dscale[3 * (size_t)i + c] = o.scale[c]; }
     for (int c = 0; c < 6; c++) g.dL_dcov3D[6 * (size_t)i + c] = o.cov3D[c];
     for (int c = 0; c < 4; c++) g.dL_drot[4 * (size_t)i + c] = o.rot[c];
