@@ -1,4 +1,4 @@
-// k_binning.hip — scans, coarse (super-tile) scatter, per-tile gather + depth sort.  Together they replace
+// k_binning.hip — scans, coarse (super-tile) binning, per-tile scatter + depth sort.  Together they replace
 // the InclusiveSum -> duplicateWithKeys -> global 64-bit radix sort -> identifyTileRanges chain of
 // CudaRasterizer::Rasterizer::forward (reference call site src/Trainer.cu:334-360; SURVEY.md
 // Appendix A.2-A.5) and produce the identical per-tile ordered lists:
@@ -7,10 +7,11 @@
 //   (slot = point_offsets[i-1] + k, k-th tile of splat i in y-outer/x-inner order) and each tile is sorted
 //   on the unique 64-bit key (depth_bits << 32 | slot).  slot is monotone in splat id, so the result equals
 //   the stable global sort, deterministically, without any global multi-pass sort.
-// MI355X: scattered device-scope atomics are the scarce resource (~20 G/s, they execute at the memory
-// side), so splats are binned with atomics only at 64x64-px super-tile granularity (~1.5 per splat);
-// every 16x16 tile then GATHERS its entries from its super-tile's candidate list, compacts them into LDS
-// and sorts them there (160 KB LDS/CU).  No per-tile global atomics, no unsorted key array in HBM.
+// MI355X: global atomics are the scarce resource (~10-20 G/s scattered, ~70 ns each on one address; they execute at
+// the memory side), so this file uses NONE.  Splats are binned at 64x64-px super-tile granularity through a
+// (256-splat block x super-tile) count matrix (LDS histograms in k_preprocess, column scan here, LDS cursors in
+// the scatter); one workgroup per super-tile then counts and fills the segments of its 16 tiles with LDS
+// atomics, and every tile sorts its own segment in LDS (160 KB LDS/CU).  Tiles are taken longest list first.
 #include "gs_internal.h"
 
 namespace gs {

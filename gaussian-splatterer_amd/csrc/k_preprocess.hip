@@ -1,5 +1,6 @@
 // k_preprocess.hip — per-(view,splat) projection: frustum cull, cov3D, EWA cov2D, conic, radius,
-// tile rect, SH colour; per-super-tile counting.  Replaces the preprocess stage of
+// tile rect, SH colour (+ its direction Jacobian for the trainer's backward); per-super-tile counting in an LDS
+// histogram, the block's row of the binning's count matrix and the block's tile sum.  Replaces the preprocess stage of
 // CudaRasterizer::Rasterizer::forward (reference call site src/Trainer.cu:334-360; algorithm
 // SURVEY.md Appendix A.1).  One thread per splat, blockIdx.y = view; SoA parameter planes give
 // 256-byte coalesced wave loads.  Built with -ffp-contract=off: every fp32 operation here is an

@@ -6,15 +6,17 @@
 // MI355X mapping (not the upstream one):
 //   * workgroup = one 16x16 tile = 4 wave64; each WAVE owns an 8x8 pixel block, lane = pixel.
 //   * the tile's depth-ordered list is staged through LDS (48-byte records gathered from the
-//     64-byte per-splat lines written by preprocess): 256 entries per round forward, 128 backward
-//     (24 KB of LDS per workgroup -> 6 workgroups = 24 waves per CU).
+//     64-byte per-splat lines written by preprocess, conic pre-scaled to base 2): 256 entries per round
+//     forward, 64 (two passes fused) or 128 backward (22-25 KB of LDS per workgroup, 7 / 6 workgroups per CU).
+//   * workgroups take tiles longest list first (tile_order), so a launch ends on light tiles.
 //   * per 64 staged entries every lane tests ONE entry's "alpha >= 1/255" box against the wave's
 //     8x8 block; the ballot is a scalar bit list and only surviving entries are evaluated — the
 //     skipped pairs are exactly ones the reference blend would skip too, so results are unchanged.
 //     The next surviving entry's record is read from LDS while the current one is evaluated.
 //   * backward: the nine per-pair partial derivatives are reduced across the 64 lanes by a DPP
-//     reduce-scatter (27 VALU instructions instead of 54: every stage halves the number of live
-//     values; bank masks give the per-lane value selection for free), each wave parks its sums in
+//     reduce-scatter (24 VALU instructions instead of 54: every stage halves the number of live
+//     values; bank masks give the per-lane value selection for free; the four 16-lane rows are folded
+//     by two ds_bpermute on the LDS pipe), each wave parks its sums in
 //     its own LDS slot, the four slots are added in fixed order and written as ONE 48-byte row per
 //     (splat,tile) entry.  No global atomic anywhere; the result is bitwise reproducible.
 #include "gs_internal.h"
