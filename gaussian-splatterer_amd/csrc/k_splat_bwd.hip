@@ -266,11 +266,7 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     const uint32_t tiles = s.tiles_touched[(size_t)g * st + i];
     const uint32_t first = s.point_offsets[(size_t)g * st + i] - tiles;
     float sum[9];
-#ifdef GS_EXP_NO_GATHER  // timing experiments only (tools/build_variant.sh)
-    gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, first, tiles ? 1u : 0u, sum);
-#else
     gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, first, tiles, sum);
-#endif
     SplatOut<D> o;
     float dRGB[3];
     // d colour / d direction was evaluated by the projection (same camera for every pass of the group): 9 floats
