@@ -135,7 +135,7 @@ struct ScratchSet {
             const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
             NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE);
         }
-        // zero block: flags | loss totals   (cleared by one memset per step)
+        // flags | loss totals (every word is rewritten by the kernels of a step: no memset)
         zero_bytes = v * 16 + v * 4;
         GS_TRY(zero_block.ensure(zero_bytes));
         GS_TRY(wghist.ensure(v * splat_blocks(Pa) * NST * 4));
@@ -595,7 +595,8 @@ static int resolve_stats(gs_trainer* t) {
     for (int v = 0; v < V; v++) st.num_rendered += t->h_flags[t->h_view_group[v] * 4 + 2];  // R of every pass, as the reference counts
     const float* hl = reinterpret_cast<const float*>(t->h_flags + (size_t)V * 4);
     double L = 0;
-    for (int v = 0; v < V; v++) L += hl[v];
+    if (t->model && t->model->count > 0)
+        for (int v = 0; v < V; v++) L += hl[v];
     st.loss = (float)L;
     t->stats_stale = false;
     return GS_OK;
@@ -638,7 +639,6 @@ static int accumulate_async(gs_trainer* t) {
             GS_HIP(hipMemcpyAsync((void*)s.views, t->h_view_block.data(), t->h_view_block.size(), hipMemcpyHostToDevice, t->stream));
             t->views_on_device = (const void*)s.views;
         }
-        GS_HIP(hipMemsetAsync(t->train.zero_block.p, 0, t->train.zero_bytes, t->stream));
         prof_stage_begin(t, 0, -1);
         GS_TRY(launch_preprocess(d, m->planes, s, t->stream));
         prof_stage_end(t, 0);
@@ -851,7 +851,6 @@ extern "C" int gs_trainer_render(gs_trainer* t, uint32_t* fb, int fb_on_device, 
         build_view_block(view, 1, false, vb);
         GS_HIP(hipMemcpyAsync((void*)s.views, vb.data(), vb.size(), hipMemcpyHostToDevice, t->stream));
         GS_HIP(hipStreamSynchronize(t->stream));  // vb is a stack-lifetime staging buffer
-        GS_HIP(hipMemsetAsync(t->preview.zero_block.p, 0, t->preview.zero_bytes, t->stream));
         GS_TRY(stage_project(d, m->planes, s, t->stream));  // an empty model gives empty lists and the background image
         GS_TRY(stage_bin_render(d, s, t->stream));
         uint32_t flags[4];
@@ -1042,7 +1041,6 @@ extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_u
             GS_HIP(hipMemcpyAsync(vb + offsetof(gs_view, bg), background, 12, hipMemcpyDeviceToDevice, st));
         }
     }
-    GS_HIP(hipMemsetAsync(geom + gl.flags, 0, 32, st));
     float* planes = reinterpret_cast<float*>(geom + gl.planes);
     GS_TRY(launch_aos_to_soa(P, gl.Pa, M, means3D, shs, scales, opacities, rotations, planes, st));
     Dims d = make_dims(P, gl.Pa, D, M, width, height, 1, 0xFFFFFFFFu, scale_modifier);  // no arena yet: nothing can overflow

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(WG) void k_project_scans(Dims d, Scratch s) {
         }
         if (threadIdx.x == 0) {
             s.flags[v * 4 + 2] = carry;  // num_rendered of this group
-            if (carry > d.Rcap) s.flags[v * 4 + 0] = 1u;  // arena too small: the later stages skip the group, the host grows and replays
+            s.flags[v * 4 + 0] = carry > d.Rcap ? 1u : 0u;  // arena too small: the later stages skip the group, the host grows and replays
+            s.flags[v * 4 + 3] = 0u;  // (every flag word is rewritten each step: nothing to clear beforehand)
         }
     } else {
         scan_single(s.coarse_count + (size_t)v * d.NST, s.coarse_end + (size_t)v * d.NST, d.NST);
