@@ -48,6 +48,16 @@ def test_no_gpu_means_loud_failure_not_fallback():
         capi.DeviceBuffer(16)
 
 
+def test_resolution_limits_are_argument_errors_not_crashes():
+    """The binning keeps one LDS counter per 64x64-px super-tile (8192 of them): larger images are refused up front,
+    with or without a GPU (the check precedes the device check)."""
+    for w, h in [(0, 64), (64, -1), (16384, 16384), (8192, 4160)]:
+        with pytest.raises(capi.GsError) as e:
+            gs.Trainer(w, h)
+        assert e.value.status == -1, (w, h, str(e.value))   # GS_ERR_INVALID_ARGUMENT
+    assert "super-tiles" in str(e.value)
+
+
 def test_model_host_constructor_validation():
     P, M = 5, 4
     s = gs.synth.random_splats(P, M, 1)
