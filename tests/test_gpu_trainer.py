@@ -63,7 +63,8 @@ def _download(tr):
 @pytest.mark.parametrize("P,M,n_cams,W,H", [(1000, 4, 1, 256, 256),   # BASELINE cfg1 (+ its black-background twin)
                                               (1500, 1, 3, 128, 96),
                                               (700, 16, 2, 112, 112),
-                                              (10000, 1, 4, 512, 512)])   # BASELINE cfg2 at full size
+                                              (10000, 1, 4, 512, 512),    # BASELINE cfg2 at full size
+                                              (100000, 16, 8, 1024, 1024)])  # BASELINE cfg3 at full size (the oracle needs ~20 s)
 def test_step_sgd_matches_oracle(orc, P, M, n_cams, W, H):
     s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 0x5EED0001)
     proj = gs.Project()
