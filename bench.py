@@ -182,10 +182,19 @@ def main():
         t_d = time.perf_counter()
         st_d = tr.train(proj, densify=True, stats=True)
         densify_ms = (time.perf_counter() - t_d) * 1e3
+    replicas_identical = None
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
+        # every rank applied the same update to the same reduced gradients: the replicas must agree bit for bit
+        import hashlib
+        hm = gs.ModelSplatsHost.fromDevice(tr.model)
+        digest = hashlib.sha256(b"".join(np.ascontiguousarray(a[:k * hm.count]).tobytes() for a, k in
+                                         ((hm.locations, 3), (hm.shs, 3 * hm.shCoeffs), (hm.scales, 3), (hm.opacities, 1), (hm.rotations, 4)))).hexdigest()
+        digests = [None] * world
+        dist.all_gather_object(digests, digest)
+        replicas_identical = all(x == digests[0] for x in digests)
 
     if rank == 0 and args.no_stage_events:
         print(json.dumps({"diagnostic": "no stage events", "value": args.steps / elapsed, "unit": "steps/s", "ms_per_step": elapsed / args.steps * 1e3,
@@ -235,6 +244,7 @@ def main():
                        "views_per_gpu": V_local, "width": W, "height": H, "update": args.update,
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "collective": (args.collective + " all-reduce of %d fp32" % ((12 + 3 * M) * P)) if use_dist else "none",
+                       "replicas_identical_after_run": replicas_identical,
                        "mean_num_rendered_per_view": R_mean, "max_tile_list": st.max_tile_list,
                        "camera_pass_sharing": "on (default): the white/black passes of a camera share projection, tile lists and "
                                               "the forward blend and run one fused backward; bit-identical to per-pass recomputation"},

@@ -1,0 +1,91 @@
+"""Two ranks on the GPU.  The 1-GPU box cannot run RCCL between two devices, but it can run the PRODUCT's data-parallel
+path with two processes sharing the one GPU and torch.distributed's gloo backend carrying the collective on the
+device tensor (gloo stages CUDA tensors through the host, stream-ordered): each rank owns the passes v % 2 == rank,
+gs_trainer_step runs accumulate -> all-reduce hook (dist.TorchAllReduce, the same hook bench.py installs with the nccl
+backend) -> apply, three steps of the reference's update rule.  Checked: both ranks end with bit-identical replicas, and the replicas equal a
+single-process run of all passes up to the re-association of the pass sum (1e-4 relative on the parameters' change)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P, M, N_CAMS, W, H, STEPS = 3000, 4, 4, 160, 96, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene():
+    import gsplat_amd as gs
+    s = gs.synth.random_splats(P, M, 2024)
+    cams = gs.camera.get_cameras(N_CAMS)
+    rng = np.random.default_rng(9)
+    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(N_CAMS)]   # truth content is irrelevant here
+    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(N_CAMS)]
+    return s, cams, fw, fb
+
+
+def _train(rank, world, hook_factory):
+    import gsplat_amd as gs
+    from gsplat_amd import capi
+    s, cams, fw, fb = _scene()
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = s["D"]
+    tr = gs.Trainer(W, H)
+    tr.model = gs.ModelSplatsDevice(host)
+    tr.captureTruths(cams, fw, fb)
+    tr.shard(rank, world)
+    hook = hook_factory(tr) if hook_factory else None
+    proj = gs.Project()     # the reference's clamped ascent: linear in the gradient, so re-association of the pass sum stays tiny
+    for _ in range(STEPS):
+        tr.train(proj)          # no stats: the steps run ahead of the device, as in bench.py
+    h = gs.ModelSplatsHost.fromDevice(tr.model)
+    n = h.count
+    out = np.concatenate([h.locations[:3 * n], h.shs[:3 * M * n], h.scales[:3 * n], h.opacities[:n], h.rotations[:4 * n]])
+    tr.close()
+    del hook
+    return out, np.concatenate([s["loc"].reshape(-1), s["sh"].reshape(-1), s["scale"].reshape(-1), s["opac"].reshape(-1), s["rot"].reshape(-1)])
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gsplat_amd import dist as gsdist
+    out, _ = _train(rank, world, lambda tr: gsdist.TorchAllReduce(tr))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_single_process_run():
+    import multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single, start = _train(0, 1, None)
+    a, b = res[0][1], res[1][1]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))            # replicas stay bit-identical
+    moved = np.abs(single - start).max()
+    assert moved > 1e-7                                                     # the steps did something
+    assert np.abs(a - single).max() <= 1e-4 * moved, (np.abs(a - single).max(), moved)
