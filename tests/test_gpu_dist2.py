@@ -89,3 +89,42 @@ def test_two_ranks_on_one_gpu_match_the_single_process_run():
     moved = np.abs(single - start).max()
     assert moved > 1e-7                                                     # the steps did something
     assert np.abs(a - single).max() <= 1e-4 * moved, (np.abs(a - single).max(), moved)
+
+
+def test_eight_way_view_sharding_sums_to_the_single_shard_gradients():
+    """shard the 16 passes of a step over 8 ranks (2 passes = one camera each, as bench.py --gpus 8
+    does), run every shard's accumulate on the one GPU in turn, sum the eight averaged-gradient buffers on the host
+    as the all-reduce would, and compare with the unsharded accumulate."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    import gsplat_amd as gs
+    from gsplat_amd import capi
+    P8, M8, cams8, W8, H8 = 4000, 9, 8, 176, 128
+    s = gs.synth.random_splats(P8, M8, 808)
+    cams = gs.camera.get_cameras(cams8)
+    rng = np.random.default_rng(3)
+    fw = [rng.integers(0, 2 ** 32, W8 * H8, dtype=np.uint32) for _ in range(cams8)]
+    fb = [rng.integers(0, 2 ** 32, W8 * H8, dtype=np.uint32) for _ in range(cams8)]
+
+    def grads(rank, world):
+        host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+        host.shDegree = s["D"]
+        tr = gs.Trainer(W8, H8)
+        tr.model = gs.ModelSplatsDevice(host)
+        tr.captureTruths(cams, fw, fb)
+        tr.shard(rank, world)
+        st = tr.accumulate(stats=True)
+        assert st.views == 2 * cams8 // world
+        ptr, n = tr.grad_buffer()
+        buf = np.empty(n, np.float32)
+        capi.check(capi.lib().gs_memcpy_d2h(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n * 4))
+        tr.close()
+        planes = 12 + 3 * M8   # the padding lanes (plane stride is P rounded up to 64) are never read by anyone
+        return buf.reshape(planes, n // planes)[:, :P8].astype(np.float64), st.num_rendered
+
+    whole, R = grads(0, 1)
+    parts = [grads(r, 8) for r in range(8)]
+    assert sum(p[1] for p in parts) == R
+    summed = np.sum([p[0] for p in parts], axis=0)
+    scale = np.abs(whole).max()
+    assert scale > 0 and np.abs(summed - whole).max() <= 2e-6 * scale
