@@ -26,6 +26,7 @@ int option_cull() { return g_opt_cull; }
 static int g_opt_share = 1;
 int option_share_passes() { return g_opt_share; }
 static int g_opt_arena = 0;  // initial binning-arena entries per camera (0 = default max(2^20, 16 P))
+static int g_opt_debug_sync = 0;  // wait and check for errors after every stage, like the reference's debug=true rasterizer calls
 
 // grow-only device buffer
 struct DevBuf {
@@ -278,6 +279,7 @@ extern "C" int gs_set_option(const char* name, int value) {
     if (strcmp(name, "cull") == 0) { g_opt_cull = value != 0; return GS_OK; }
     if (strcmp(name, "share_camera_passes") == 0) { g_opt_share = value != 0; return GS_OK; }
     if (strcmp(name, "arena_entries") == 0) { g_opt_arena = value > 0 ? value : 0; return GS_OK; }
+    if (strcmp(name, "debug_sync") == 0) { g_opt_debug_sync = value != 0; return GS_OK; }
     if (strcmp(name, "scan_single_max") == 0) { gs::g_scan_single_max = value > 0 ? value : (1 << 16); return GS_OK; }
     set_error("gs_set_option: unknown option '%s'", name);
     return GS_ERR_INVALID_ARGUMENT;
@@ -477,6 +479,15 @@ void prof_stage_end(gs_trainer* t, int stage) {
     t->prev_mark = e; t->prev_mark_stage = stage;
     t->stage_start = nullptr;
 }
+// "debug_sync": the reference passes debug=true to every rasterizer call (src/Trainer.cu:201,360,412), which makes it
+// synchronise and check for errors after each internal kernel; this names the stage a fault belongs to.
+int debug_check(gs_trainer* t, int stage) {
+    if (!g_opt_debug_sync) return GS_OK;
+    hipError_t e = hipStreamSynchronize(t->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { set_error("stage '%s' failed: %s", kStageNames[stage], hipGetErrorString(e)); return GS_ERR_HIP; }
+    return GS_OK;
+}
 void prof_resolve(gs_trainer* t) {  // caller has synchronised the stream
     for (auto& p : t->pending) {
         float ms = 0.0f;
@@ -642,30 +653,37 @@ static int accumulate_async(gs_trainer* t) {
         prof_stage_begin(t, 0, -1);
         GS_TRY(launch_preprocess(d, m->planes, s, t->stream));
         prof_stage_end(t, 0);
+        GS_TRY(debug_check(t, 0));
         prof_stage_begin(t, 1, 0);
         GS_TRY(launch_coarse_colscan(d, s, t->stream));
         GS_TRY(launch_project_scans(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), t->stream));
         GS_HIP(hipMemcpyAsync(t->h_flags, s.flags, (size_t)t->VG * 16, hipMemcpyDeviceToHost, t->stream));
         GS_HIP(hipEventRecord(t->ev_flags, t->stream));
         prof_stage_end(t, 1);  // the scans and the publication of their overflow verdict
+        GS_TRY(debug_check(t, 1));
         prof_stage_begin(t, 2, 1);
         GS_TRY(stage_bin(d, s, t->stream));
         prof_stage_end(t, 2);
+        GS_TRY(debug_check(t, 2));
         prof_stage_begin(t, 3, 2);
         GS_TRY(launch_tile_build_sort(d, s, t->stream));
         prof_stage_end(t, 3);
+        GS_TRY(debug_check(t, 3));
         prof_stage_begin(t, 4, 3);
         GS_TRY(launch_render_forward(d, s, t->stream));
         prof_stage_end(t, 4);
+        GS_TRY(debug_check(t, 4));
         if (P > 0) {  // an empty model has no gradients: its image is the background, its loss the residual against it
             const int* items = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.views) + view_block_items_offset(V));
             prof_stage_begin(t, 5, 4);
             GS_TRY(launch_render_backward(d, s, items, t->bwd_pairs, t->bwd_singles, t->stream));
             prof_stage_end(t, 5);
+            GS_TRY(debug_check(t, 5));
             prof_stage_begin(t, 6, 5);
             GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), items, t->bwd_pairs,
                                              t->bwd_singles, t->stream));
             prof_stage_end(t, 6);
+            GS_TRY(debug_check(t, 6));
         }
         GS_HIP(hipEventSynchronize(t->ev_flags));
         bool overflow = false;
@@ -767,6 +785,7 @@ extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, g
     GS_TRY(launch_update(pl, m->count, m->Pa, m->planes, t->grad.as<float>(), t->adam_m.as<float>(), t->adam_v.as<float>(),
                          t->adam_t, *h, t->stream));
     prof_stage_end(t, 7);
+    GS_TRY(debug_check(t, 7));
     t->accumulated = false;
     if (densify) {
         GS_TRY(resolve_stats(t));
@@ -786,6 +805,7 @@ extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs
         prof_stage_begin(t, 8, 6);
         rc = t->allreduce(buf, n, (void*)t->stream, t->allreduce_user);
         prof_stage_end(t, 8);
+        GS_TRY(debug_check(t, 8));
         if (rc != 0) { set_error("all-reduce hook failed with %d", rc); return GS_ERR_INTERNAL; }
     }
     return gs_trainer_apply(t, h, densify, stats);

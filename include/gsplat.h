@@ -64,6 +64,8 @@ int gs_device_count(void);
  * forward blend; 0 recomputes them per pass like the reference.  Results are bit-identical either way.
  * "arena_entries" (default 0 = max(2^20, 16*P)): initial capacity, in (splat, tile) entries per camera, of the binning
  * arena of trainers created afterwards; when a step needs more the arena grows and the step is replayed.
+ * "debug_sync" (default 0): wait and check for device errors after every stage of a step, as the reference's
+ * debug=true rasterizer calls do (src/Trainer.cu:201,360,412); a failing step then names its stage.
  * "scan_single_max" (default 65536): the per-view scans of super-tile counters and tile counts run as one workgroup
  * per view up to this many items and as a three-phase scan beyond; results are identical either way. */
 int gs_set_option(const char* name, int value);

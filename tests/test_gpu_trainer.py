@@ -289,3 +289,23 @@ def test_steps_without_stats_run_ahead_and_agree(orc):
     assert res[0][:3] == res[1][:3]
     for k in ("loc", "sh", "scale", "opac", "rot"):
         assert np.array_equal(res[0][3][k].view(np.uint32), res[1][3][k].view(np.uint32)), k
+
+
+def test_debug_sync_changes_nothing_but_the_waiting(orc):
+    """gs_set_option("debug_sync", 1) makes every stage wait and check for device errors (the reference's debug=true
+    rasterizer calls): same results, bit for bit."""
+    P, M, n_cams, W, H = 1500, 4, 2, 128, 96
+    res = []
+    for dbg in (0, 1):
+        capi.check(capi.lib().gs_set_option(b"debug_sync", dbg))
+        try:
+            s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 4242)
+            tr.train(gs.Project())
+            st = tr.train(gs.Project(), stats=True)
+            res.append((st.num_rendered, st.loss, _read_grads(tr, P, M)))
+            tr.close()
+        finally:
+            capi.check(capi.lib().gs_set_option(b"debug_sync", 0))
+    assert res[0][:2] == res[1][:2]
+    for k in res[0][2]:
+        assert np.array_equal(res[0][2][k].view(np.uint32), res[1][2][k].view(np.uint32)), k
