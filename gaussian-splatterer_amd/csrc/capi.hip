@@ -126,7 +126,7 @@ struct ScratchSet {
         Pa = std::max(64, round_up(P, 64));
         V = V_; N = W * H;
         T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-        Rcap = std::max<uint32_t>(Rcap_, 1024);
+        Rcap = (std::max<uint32_t>(Rcap_, 1024) + 63u) & ~63u;  // multiple of 64: every view's slice of G (36-byte rows) stays 8-byte aligned for the sort keys
         const size_t v = (size_t)std::max(V, 1);
         GS_TRY(views.ensure(view_block_bytes((int)v)));
         GS_TRY(geom.ensure(v * Pa * sizeof(GeomRec)));

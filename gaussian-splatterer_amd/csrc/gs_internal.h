@@ -34,7 +34,9 @@ int option_share_passes();
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE = 16;           // 16x16-pixel tiles (upstream BLOCK_X/BLOCK_Y)
 constexpr int WG = 256;            // workgroup = 4 wave64
-constexpr int G_STRIDE = 12;       // floats per (splat,tile) gradient slot (9 used, 48-byte rows)
+constexpr int G_STRIDE = 9;        // floats per (splat, tile, pass) gradient row: 36 bytes, three 12-byte groups (no padding:
+                                   // the rows are the step's largest HBM stream, written once and read once)
+struct alignas(4) Row3 { float a, b, c; };  // one 12-byte group of a gradient row
 constexpr int SORT_LDS_CAP = 2048; // entries a tile sorts in LDS; longer lists take the global path
 constexpr int STILE = 4;           // a super-tile is STILE x STILE tiles (64x64 px): the coarse binning unit
 constexpr int MAX_SUPER_TILES = 8192;  // the binning keeps one LDS counter per super-tile (32 KB): images up to e.g. 8192 x 4096

@@ -383,8 +383,8 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
         const uint32_t slot = slist[e];
 #pragma unroll
         for (int p = 0; p < K; p++) {
-            float4* row = reinterpret_cast<float4*>(s.G + ((size_t)vp[p] * d.Rcap + slot) * G_STRIDE);
-            row[0] = make_float4(0, 0, 0, 0); row[1] = make_float4(0, 0, 0, 0); row[2] = make_float4(0, 0, 0, 0);
+            Row3* row = reinterpret_cast<Row3*>(s.G + ((size_t)vp[p] * d.Rcap + slot) * G_STRIDE);
+            row[0] = Row3{ 0, 0, 0 }; row[1] = Row3{ 0, 0, 0 }; row[2] = Row3{ 0, 0, 0 };
         }
     }
 
@@ -506,10 +506,10 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
                 }
                 const float gmx = -ddelx_dx * op * (conA * sum[3] + conB * sum[4]);
                 const float gmy = -ddely_dy * op * (conC * sum[4] + conB * sum[3]);
-                float4* row = reinterpret_cast<float4*>(s.G + ((size_t)vp[p] * d.Rcap + slot) * G_STRIDE);
-                row[0] = make_float4(sum[0], sum[1], sum[2], gmx);
-                row[1] = make_float4(gmy, hop * sum[5], hop * sum[6], hop * sum[7]);
-                row[2] = make_float4(sum[8], 0.0f, 0.0f, 0.0f);
+                Row3* row = reinterpret_cast<Row3*>(s.G + ((size_t)vp[p] * d.Rcap + slot) * G_STRIDE);
+                row[0] = Row3{ sum[0], sum[1], sum[2] };
+                row[1] = Row3{ gmx, gmy, hop * sum[5] };
+                row[2] = Row3{ hop * sum[6], hop * sum[7], sum[8] };
             }
         }
     }

@@ -196,25 +196,24 @@ __device__ inline void splat_backward_core(const gs_view& vp, int W, int H, cons
 __device__ inline void gather_rows(const float* __restrict__ Gv, uint32_t first, uint32_t tiles, float sum[9]) {
 #pragma unroll
     for (int q = 0; q < 9; q++) sum[q] = 0.0f;
-    const float4* row = reinterpret_cast<const float4*>(Gv + (size_t)first * G_STRIDE);
+    const Row3* row = reinterpret_cast<const Row3*>(Gv + (size_t)first * G_STRIDE);
     uint32_t k = 0;
     // four rows in flight per trip (the loop is latency-bound: a splat touches ~7 tiles); the adds keep slot order
     for (; k + 4 <= tiles; k += 4, row += 12) {
-        float4 a[4], b[4];
-        float c[4];
+        Row3 r[12];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { a[j] = row[3 * j]; b[j] = row[3 * j + 1]; c[j] = reinterpret_cast<const float*>(row + 3 * j + 2)[0]; }
+        for (int j = 0; j < 12; j++) r[j] = row[j];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            sum[0] += a[j].x; sum[1] += a[j].y; sum[2] += a[j].z; sum[3] += a[j].w;
-            sum[4] += b[j].x; sum[5] += b[j].y; sum[6] += b[j].z; sum[7] += b[j].w; sum[8] += c[j];
+            sum[0] += r[3 * j].a; sum[1] += r[3 * j].b; sum[2] += r[3 * j].c;
+            sum[3] += r[3 * j + 1].a; sum[4] += r[3 * j + 1].b; sum[5] += r[3 * j + 1].c;
+            sum[6] += r[3 * j + 2].a; sum[7] += r[3 * j + 2].b; sum[8] += r[3 * j + 2].c;
         }
     }
     for (; k < tiles; k++, row += 3) {
-        const float4 a = row[0], b = row[1];
-        const float c = reinterpret_cast<const float*>(row + 2)[0];
-        sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w;
-        sum[4] += b.x; sum[5] += b.y; sum[6] += b.z; sum[7] += b.w; sum[8] += c;
+        const Row3 r0 = row[0], r1 = row[1], r2 = row[2];
+        sum[0] += r0.a; sum[1] += r0.b; sum[2] += r0.c; sum[3] += r1.a; sum[4] += r1.b; sum[5] += r1.c;
+        sum[6] += r2.a; sum[7] += r2.b; sum[8] += r2.c;
     }
 }
 
