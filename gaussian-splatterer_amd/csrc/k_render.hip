@@ -17,7 +17,7 @@
 //     reduce-scatter (24 VALU instructions instead of 54: every stage halves the number of live
 //     values; bank masks give the per-lane value selection for free; the four 16-lane rows are folded
 //     by two ds_bpermute on the LDS pipe), each wave parks its sums in
-//     its own LDS slot, the four slots are added in fixed order and written as ONE 48-byte row per
+//     its own LDS slot, the four slots are added in fixed order and written as ONE 36-byte row per
 //     (splat,tile) entry.  No global atomic anywhere; the result is bitwise reproducible.
 #include "gs_internal.h"
 
