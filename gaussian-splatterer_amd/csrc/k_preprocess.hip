@@ -150,7 +150,7 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict
         float4* jrec = reinterpret_cast<float4*>(s.sh_jac + ((size_t)v * st + i) * 12);
         jrec[0] = make_float4(jac[0], jac[1], jac[2], jac[3]);
         jrec[1] = make_float4(jac[4], jac[5], jac[6], jac[7]);
-        jrec[2] = make_float4(jac[8], 0.0f, 0.0f, 0.0f);
+        jrec[2] = make_float4(jac[8], __uint_as_float(flags), 0.0f, 0.0f);  // + the clamp bits: the backward needs nothing else of this record
     }
 
     // Cull threshold: a pixel contributes only if alpha = min(0.99, opacity*exp(-q)) >= 1/255, i.e. only where the

@@ -251,8 +251,10 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
     float4* out = rec_out + ((size_t)v * st + i) * 4;
-    const GeomRec* rec = s.geom + (size_t)g * st + i;
-    if ((s.flags[g * 4 + 0] & 1u) || !(rec->radius > 0)) {  // culled: the reference's nine buffers stay zero
+    // culled splats touch no tile (k_preprocess); everything this kernel needs of the projection is in tiles_touched,
+    // point_offsets and the 48-byte sh_jac record — the 64-byte GeomRec is not read here
+    const uint32_t tiles = s.tiles_touched[(size_t)g * st + i];
+    if ((s.flags[g * 4 + 0] & 1u) || tiles == 0) {  // culled: the reference's nine buffers stay zero
         const float4 z = make_float4(0, 0, 0, 0);
         out[0] = z; out[1] = z; out[2] = z; out[3] = z;
         return;
@@ -262,7 +264,6 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     for (int c = 0; c < 3; c++) { mean[c] = params[pl.loc(c) * st + i]; sc[c] = d.mod * params[pl.scale(c) * st + i]; }
 #pragma unroll
     for (int c = 0; c < 4; c++) q[c] = params[pl.rot(c) * st + i];
-    const uint32_t tiles = s.tiles_touched[(size_t)g * st + i];
     const uint32_t first = s.point_offsets[(size_t)g * st + i] - tiles;
     float sum[9];
     gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, first, tiles, sum);
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     const float4 j0 = jrec[0], j1 = jrec[1], j2 = jrec[2];
     const float jv[9] = { j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, j2.x };
     auto jac_at = [&](int ch, float, float, float, float& dx_, float& dy_, float& dz_) { dx_ = jv[3 * ch]; dy_ = jv[3 * ch + 1]; dz_ = jv[3 * ch + 2]; };
-    splat_backward_core<D, false>(s.gviews[g], d.W, d.H, mean, sc, q, jac_at, rec->flags, sum, sum[3], sum[4], sum[5], sum[6], sum[7], o, dRGB);
+    splat_backward_core<D, false>(s.gviews[g], d.W, d.H, mean, sc, q, jac_at, __float_as_uint(j2.y), sum, sum[3], sum[4], sum[5], sum[6], sum[7], o, dRGB);
     out[0] = make_float4(o.mean[0], o.mean[1], o.mean[2], o.scale[0]);
     out[1] = make_float4(o.scale[1], o.scale[2], o.rot[0], o.rot[1]);
     out[2] = make_float4(o.rot[2], o.rot[3], sum[8], dRGB[0]);
