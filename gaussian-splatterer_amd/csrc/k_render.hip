@@ -395,6 +395,7 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
     const bool writer = lane < 16 && (((lane & 1) == 0) || lane == 1);
     const int wslot = (lane & 1) ? 8 : (lane >> 1);
     const int fold16 = (lane ^ 16) << 2, fold32 = (lane ^ 32) << 2;  // ds_bpermute byte addresses of the row partners
+    float* const acc_lane = &sAcc[wave * ROUND * ACC_STRIDE + wslot];  // this lane's column of the wave's slots
 
     for (int r = rounds - 1; r >= 0; r--) {
         const int base = r * ROUND;
@@ -471,7 +472,7 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
                                                               dchannel_dcolor * dpx[p][2], ux, uy, ux * dx, ux * dy, uy * dy, u[p]);
                         red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold16, __builtin_bit_cast(int, red)));
                         red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold32, __builtin_bit_cast(int, red)));
-                        if (writer) sAcc[((p * 4 + wave) * ROUND + jj) * ACC_STRIDE + wslot] = red;
+                        if (writer) acc_lane[jj * ACC_STRIDE + p * (4 * ROUND * ACC_STRIDE)] = red;  // lane-constant base + scalar offset
                     }
                     touched[sb] |= 1ull << kk;
                 }
