@@ -1,5 +1,6 @@
-"""BASELINE.json's FULL sizes (cfg2: 10k splats, 8 passes @512^2; cfg3: 100k splats, 16 passes @1024^2, SH degree 3)
-on the GPU, checked through properties that do not need the oracle to run at that size:
+"""BASELINE.json's FULL sizes (cfg2: 10k splats, 8 passes @512^2; cfg3: 100k splats, 16 passes @1024^2, SH degree 3;
+for the tile lists also cfg5: 1M splats @2048^2) on the GPU, checked through properties that do not need the oracle
+to run at that size:
 
 * the sorted tile lists ARE a stable sort of (tile, depth) over the emitted (splat, tile) pairs (sortedness, stability,
   multiset equality with tiles_touched, ranges partition [0, R));
@@ -66,7 +67,7 @@ def _grads(tr):
     return buf
 
 
-@pytest.mark.parametrize("idx", [2, 3])
+@pytest.mark.parametrize("idx", [2, 3, 5])   # 5: 1M splats @2048^2 — ~1100 entries per tile, lists beyond the LDS sort (spill path)
 def test_lists_are_the_stable_sort_and_blend_identity(idx):
     P, M, D, V, W, H, s, cams = _cfg(idx)
     views = gs.camera.train_views(cams, W, H)
