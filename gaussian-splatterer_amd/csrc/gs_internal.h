@@ -37,7 +37,8 @@ constexpr int WG = 256;            // workgroup = 4 wave64
 constexpr int G_STRIDE = 9;        // floats per (splat, tile, pass) gradient row: 36 bytes, three 12-byte groups (no padding:
                                    // the rows are the step's largest HBM stream, written once and read once)
 struct alignas(4) Row3 { float a, b, c; };  // one 12-byte group of a gradient row
-constexpr int SORT_LDS_CAP = 2048; // entries a tile sorts in LDS; longer lists take the global path
+constexpr int SORT_SMALL_CAP = 2048;  // lists shorter than this: one 256-thread workgroup per tile, 24 KB LDS
+constexpr int SORT_LDS_CAP = 8192;    // longest list sorted in LDS (long-list kernel, 96 KB); beyond: global scratch
 constexpr int STILE = 4;           // a super-tile is STILE x STILE tiles (64x64 px): the coarse binning unit
 constexpr int MAX_SUPER_TILES = 8192;  // the binning keeps one LDS counter per super-tile (32 KB): images up to e.g. 8192 x 4096
 

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(WG) void k_tile_scatter(Dims d, Scratch s) {
         const int tx = tx0 + (threadIdx.x % STILE), ty = ty0 + (threadIdx.x / STILE);
         uint32_t n = 0, e = 0;
         if (tx < d.gx && ty < d.gy) { n = s.tile_count[(size_t)v * d.T + ty * d.gx + tx]; e = s.tile_end[(size_t)v * d.T + ty * d.gx + tx]; }
-        cur[threadIdx.x] = 0; first[threadIdx.x] = e - n; big[threadIdx.x] = n > (uint32_t)SORT_LDS_CAP;
+        cur[threadIdx.x] = 0; first[threadIdx.x] = e - n; big[threadIdx.x] = n > (uint32_t)SORT_LDS_CAP;  // only these take the global-scratch sort, which needs ids by slot
     }
     __syncthreads();
     const size_t c0 = (size_t)v * d.NST + st;
@@ -332,6 +332,10 @@ int launch_tile_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
 // row-major order leaves the CUs that drew a heavy tile last running alone).  Counting sort on min(count, 1023) / 4.
 // ---------------------------------------------------------------------------------------------
 constexpr int ORDER_BINS = 256;
+// bin of a list length: 8-wide bins below 1024 entries, 64-wide bins from there to 9216 (bin boundaries fall on
+// SORT_SMALL_CAP = 2048: "long" tiles, sorted by k_tile_sort_long, are exactly the bins >= ORDER_LONG_BIN)
+__device__ inline int order_bin(uint32_t c) { return c < 1024u ? (int)(c >> 3) : min(ORDER_BINS - 1, 128 + (int)((c - 1024u) >> 6)); }
+constexpr int ORDER_LONG_BIN = 128 + (SORT_SMALL_CAP - 1024) / 64;
 template <bool SCAN>
 __global__ __launch_bounds__(WG) void k_tile_scan_order(Dims d, Scratch s) {
     __shared__ uint32_t hist[ORDER_BINS], start[ORDER_BINS];
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(WG) void k_tile_scan_order(Dims d, Scratch s) {
     for (int t = threadIdx.x; t < d.T; t += WG) {
         const uint32_t c = cnt[t];
         longest = max(longest, c);
-        atomicAdd(&hist[ORDER_BINS - 1 - min(c, 1023u) / 4], 1u);  // bin 0 = longest
+        atomicAdd(&hist[ORDER_BINS - 1 - order_bin(c)], 1u);  // bin 0 = longest
     }
     // statistic: the longest tile list of the group (a global atomicMax per TILE cost 210 us: same-address atomics serialise)
 #pragma unroll
@@ -358,8 +362,10 @@ __global__ __launch_bounds__(WG) void k_tile_scan_order(Dims d, Scratch s) {
     const uint32_t h = hist[threadIdx.x];
     const uint32_t ex = block_excl_scan(h, nullptr);
     start[threadIdx.x] = ex;
+    // the long tiles are the first entries of the order: publish how many there are for k_tile_sort_long
+    if (threadIdx.x == ORDER_BINS - ORDER_LONG_BIN) s.flags[v * 4 + 3] = ex;
     __syncthreads();
-    for (int t = threadIdx.x; t < d.T; t += WG) order[atomicAdd(&start[ORDER_BINS - 1 - min(cnt[t], 1023u) / 4], 1u)] = (uint32_t)t;
+    for (int t = threadIdx.x; t < d.T; t += WG) order[atomicAdd(&start[ORDER_BINS - 1 - order_bin(cnt[t])], 1u)] = (uint32_t)t;
 }
 // tile_end = inclusive scan of tile_count, tile_order = tiles by descending count; one launch unless the scan is too long
 int launch_tile_scan_order(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st) {
@@ -377,13 +383,15 @@ int launch_tile_scan_order(const Dims& d, const Scratch& s, uint32_t* partials, 
 
 // ---------------------------------------------------------------------------------------------
 // per-tile sort on the unique 64-bit key: the tile's workgroup loads its entries (k_tile_scatter) into LDS and sorts:
-// counting-rank sort for n <= 128, depth-bucketed rank sort up to SORT_LDS_CAP (2048), bitonic in global scratch (the
-// not yet used gradient-row buffer G) beyond — the "tile-list spill path".
+// counting-rank sort for n <= 128, depth-bucketed rank sort up to the LDS capacity (2048 entries in the one-tile-per-
+// workgroup kernel, 8192 in the long-list kernel), bitonic in global scratch (the not yet used gradient-row buffer G)
+// beyond — the "tile-list spill path".
 // ---------------------------------------------------------------------------------------------
+template <int NT>
 __device__ inline void bitonic_sort(uint64_t* a, uint32_t n2) {
     for (uint32_t k = 2; k <= n2; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (n2 >> 1); t += WG) {
+            for (uint32_t t = threadIdx.x; t < (n2 >> 1); t += NT) {
                 const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const uint32_t l = i | j;
                 const bool up = ((i & k) == 0);
@@ -397,39 +405,28 @@ __device__ inline void bitonic_sort(uint64_t* a, uint32_t n2) {
 #ifndef GS_RANK_DIRECT_MAX
 #define GS_RANK_DIRECT_MAX 128  // tuning hook (tools/build_variant.sh)
 #endif
-constexpr uint32_t RANK_MAX = SORT_LDS_CAP;  // every list that fits LDS is rank-sorted (measured faster than LDS bitonic up to 2048)
 
-__global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    uint64_t* sk = reinterpret_cast<uint64_t*>(smem_raw);
-    __shared__ uint32_t sid[RANK_MAX];
-    const int v = blockIdx.y;
-    const int tile = (int)s.tile_order[(size_t)v * d.T + blockIdx.x];
-    if (s.flags[v * 4 + 0] & 1u) return;  // overflowed view: nothing was scattered
-    const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
-    if (n == 0) return;
+// Sort one tile's segment with NT threads and room for CAP entries in LDS (sk: CAP keys, sid: CAP ids).
+// Every thread of the workgroup must call it (it synchronises); n > 0.
+template <int NT, int CAP>
+__device__ inline void sort_tile(const Dims& d, const Scratch& s, int v, int tile, uint32_t n, uint64_t* sk, uint32_t* sid) {
     const uint32_t start = s.tile_end[(size_t)v * d.T + tile] - n;
     uint32_t* ids = s.id_of_slot + (size_t)v * d.Rcap;
     uint32_t* pl = s.point_list + (size_t)v * d.Rcap + start;
     uint32_t* sl = s.slot_list + (size_t)v * d.Rcap + start;
-    const bool by_rank = n <= RANK_MAX;
-    uint32_t n2 = 2;
-    while (n2 < n) n2 <<= 1;
-    // the tile's unsorted keys (k_tile_scatter); long lists are sorted in place there (n2 < 2n slots reserved)
+    // the tile's unsorted keys (k_tile_scatter); lists beyond CAP are sorted in place there (n2 < 2n slots reserved)
     uint64_t* a = reinterpret_cast<uint64_t*>(s.G + (size_t)v * d.Rcap * G_STRIDE) + 2 * (size_t)start;
-    if (by_rank) {
-        for (uint32_t t = threadIdx.x; t < n; t += WG) { sk[t] = a[t]; sid[t] = pl[t]; }
-    }
-    if (by_rank) {
+    if (n <= (uint32_t)CAP) {
+        for (uint32_t t = threadIdx.x; t < n; t += NT) { sk[t] = a[t]; sid[t] = pl[t]; }
         __syncthreads();
-        constexpr uint32_t NB = 64, KPT = SORT_LDS_CAP / WG;  // depth buckets; keys per thread
+        constexpr uint32_t NB = 64, KPT = CAP / NT;  // depth buckets; keys per thread
         if (n <= GS_RANK_DIRECT_MAX) {
             // counting-rank sort: rank = #keys smaller is the final position (keys are unique); every thread ranks its
             // key against the whole list with broadcast 16-byte LDS reads
             const uint32_t ne = (n + 1) & ~1u;
             if (threadIdx.x == 0 && ne != n) sk[n] = ~0ull;
             __syncthreads();
-            for (uint32_t t = threadIdx.x; t < n; t += WG) {
+            for (uint32_t t = threadIdx.x; t < n; t += NT) {
                 const uint64_t mine = sk[t];
                 uint32_t rank = 0;
                 const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(sk);
@@ -453,7 +450,7 @@ __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
         if (threadIdx.x < NB) bcount[threadIdx.x] = 0;
 #pragma unroll
         for (uint32_t k = 0; k < KPT; k++) {
-            const uint32_t t = threadIdx.x + k * WG;
+            const uint32_t t = threadIdx.x + k * NT;
             key[k] = t < n ? sk[t] : 0ull;
             id[k] = t < n ? sid[t] : 0u;
             if (t < n) { const uint32_t dz = (uint32_t)(key[k] >> 32); lo = min(lo, dz); hi = max(hi, dz); }
@@ -467,7 +464,7 @@ __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
         const float scale = (float)NB / ((float)(dmax - base) + 1.0f);
 #pragma unroll
         for (uint32_t k = 0; k < KPT; k++) {
-            const uint32_t t = threadIdx.x + k * WG;
+            const uint32_t t = threadIdx.x + k * NT;
             if (t < n) {
                 bk[k] = min(NB - 1, (uint32_t)((float)((uint32_t)(key[k] >> 32) - base) * scale));
                 bp[k] = atomicAdd(&bcount[bk[k]], 1u);
@@ -483,13 +480,13 @@ __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
         __syncthreads();
 #pragma unroll
         for (uint32_t k = 0; k < KPT; k++) {
-            const uint32_t t = threadIdx.x + k * WG;
+            const uint32_t t = threadIdx.x + k * NT;
             if (t < n) sk[bstart[bk[k]] + bp[k]] = key[k];
         }
         __syncthreads();
 #pragma unroll
         for (uint32_t k = 0; k < KPT; k++) {
-            const uint32_t t = threadIdx.x + k * WG;
+            const uint32_t t = threadIdx.x + k * NT;
             if (t < n) {
                 const uint32_t b0 = bstart[bk[k]], b1 = bstart[bk[k] + 1];
                 uint32_t rank = b0;
@@ -500,20 +497,54 @@ __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
         }
         return;
     }
-    for (uint32_t t = n + threadIdx.x; t < n2; t += WG) a[t] = ~0ull;
+    // the spill path: bitonic network in global scratch
+    uint32_t n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    for (uint32_t t = n + threadIdx.x; t < n2; t += NT) a[t] = ~0ull;
     __syncthreads();
-    bitonic_sort(a, n2);
-    for (uint32_t t = threadIdx.x; t < n; t += WG) {
+    bitonic_sort<NT>(a, n2);
+    for (uint32_t t = threadIdx.x; t < n; t += NT) {
         const uint32_t slot = (uint32_t)a[t];
         sl[t] = slot;
         pl[t] = ids[slot];
     }
 }
 
+// Lists below SORT_SMALL_CAP entries: one 256-thread workgroup per tile, 24 KB of LDS (6 workgroups per CU).
+__global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
+    __shared__ __align__(16) uint64_t sk[SORT_SMALL_CAP];
+    __shared__ uint32_t sid[SORT_SMALL_CAP];
+    const int v = blockIdx.y;
+    const int tile = (int)s.tile_order[(size_t)v * d.T + blockIdx.x];
+    if (s.flags[v * 4 + 0] & 1u) return;  // overflowed view: nothing was scattered
+    const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
+    if (n == 0 || n >= (uint32_t)SORT_SMALL_CAP) return;  // long lists: k_tile_sort_long
+    sort_tile<WG, SORT_SMALL_CAP>(d, s, v, tile, n, sk, sid);
+}
+
+// Lists of SORT_SMALL_CAP entries and more: the tile order starts with them (flags[3] = how many).  A few persistent
+// 1024-thread workgroups per camera walk that prefix with SORT_LDS_CAP (8192) entries of LDS each — 96 KB, one
+// workgroup per CU, which is why short lists do not go through here; only lists beyond that spill to global scratch.
+constexpr int LONG_NT = 1024;
+__global__ __launch_bounds__(LONG_NT) void k_tile_sort_long(Dims d, Scratch s) {
+    __shared__ __align__(16) uint64_t sk[SORT_LDS_CAP];
+    __shared__ uint32_t sid[SORT_LDS_CAP];
+    const int v = blockIdx.y;
+    if (s.flags[v * 4 + 0] & 1u) return;
+    const uint32_t n_long = s.flags[v * 4 + 3];
+    for (uint32_t idx = blockIdx.x; idx < n_long; idx += gridDim.x) {
+        const int tile = (int)s.tile_order[(size_t)v * d.T + idx];
+        const uint32_t n = s.tile_count[(size_t)v * d.T + tile];  // >= SORT_SMALL_CAP by construction of the order
+        sort_tile<LONG_NT, SORT_LDS_CAP>(d, s, v, tile, n, sk, sid);
+        __syncthreads();  // LDS is reused by the next tile
+    }
+}
+
 int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.T == 0 || d.VG == 0) return GS_OK;
     GS_TRY(launch_tile_scatter(d, s, st));
-    hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T, d.VG), dim3(WG), SORT_LDS_CAP * sizeof(uint64_t), st, d, s);
+    hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T, d.VG), dim3(WG), 0, st, d, s);
+    hipLaunchKernelGGL(k_tile_sort_long, dim3(std::min(d.T, 64), d.VG), dim3(LONG_NT), 0, st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -164,9 +164,11 @@ def test_empty_and_all_culled(orc):
     assert R == 0 and np.all(out == 1.0)
 
 
-def test_long_tile_lists_take_the_spill_path(orc):
-    """> 2048 entries in one tile: the sort leaves LDS for the global scratch path; lists stay bit-exact."""
-    P, M, D, W, H = 6000, 1, 0, 32, 32
+@pytest.mark.parametrize("P,longer_than", [(6000, 4096), (12000, 8192)])
+def test_long_tile_lists_take_the_spill_path(orc, P, longer_than):
+    """Lists of 2048 entries and more go to the long-list kernel (up to 8192 entries in 96 KB of LDS), longer ones
+    are sorted in global scratch (the spill path); the lists stay bit-exact either way."""
+    M, D, W, H = 1, 0, 32, 32
     s = util.gs.synth.random_splats(P, M, 99)
     s["loc"] = (s["loc"] * 0.05).astype(np.float32)  # everything projects into the same few tiles
     s["opac"] = (s["opac"] * 0.02).astype(np.float32)
@@ -174,11 +176,13 @@ def test_long_tile_lists_take_the_spill_path(orc):
     vp = view_parts(util.gs.camera.train_views(cams, W, H)[0])
     sr, r, out, oout = _check_forward(orc, s, D, M, vp, W, H, min_solid=0.9)
     ranges = r.get("ranges").reshape(-1, 2)
-    assert (ranges[:, 1] - ranges[:, 0]).max() > 4096
+    assert (ranges[:, 1] - ranges[:, 0]).max() > longer_than
     dpix = np.ones((3, H, W), np.float32)
     g = sr.backward(dpix)
     og = r.backward(dpix)
-    assert_close_rel("dL_dopacity", g["dL_dopacity"], og["dL_dopacity"], rtol=1e-4, max_bad_frac=0.002)
+    # thousands of pairs per pixel: most splats share a pixel with SOME pair on a blend threshold, so the firm-splat
+    # mask of test_backward_parity would leave nothing; a small outlier allowance instead
+    assert_close_rel("dL_dopacity", g["dL_dopacity"], og["dL_dopacity"], rtol=1e-4, max_bad_frac=0.005)
 
 
 def test_elongated_splats_cull_box_is_conservative(orc):

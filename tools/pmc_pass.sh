@@ -26,7 +26,7 @@ for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True
         grid[(k, r["Dispatch_Id"])] = int(r.get("Grid_Size", 0) or 0)
     best = {}
     for (k, d), g in grid.items():
-        if k not in best or g > grid[(k, best[k])]:
+        if k not in best or g >= grid[(k, best[k])]:   # ties: the LAST such dispatch (an arena-overflow replay exits early)
             best[k] = d
     for k, d in best.items():
         res[k].update(per[(k, d)])
