@@ -544,7 +544,9 @@ int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.T == 0 || d.VG == 0) return GS_OK;
     GS_TRY(launch_tile_scatter(d, s, st));
     hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T, d.VG), dim3(WG), 0, st, d, s);
-    hipLaunchKernelGGL(k_tile_sort_long, dim3(std::min(d.T, 64), d.VG), dim3(LONG_NT), 0, st, d, s);
+    // one long-list workgroup fills a CU (96 KB LDS): about one per CU over all cameras
+    const int per_cam = std::min(d.T, std::max(16, std::min(256, 256 / std::max(d.VG, 1))));
+    hipLaunchKernelGGL(k_tile_sort_long, dim3(per_cam, d.VG), dim3(LONG_NT), 0, st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
