@@ -309,3 +309,38 @@ def test_debug_sync_changes_nothing_but_the_waiting(orc):
     assert res[0][:2] == res[1][:2]
     for k in res[0][2]:
         assert np.array_equal(res[0][2][k].view(np.uint32), res[1][2][k].view(np.uint32)), k
+
+
+def test_non_finite_and_extreme_parameters_do_not_break_the_step(orc):
+    """NaN / Inf / zero / huge values in a few splats (a diverged model, a corrupt file): every index the kernels form
+    is clamped, so the step completes with GS_OK, the splat count and list statistics stay sane, and the clean splats
+    keep finite parameters after the reference's update rule.  (The oracle is not compared: float->int conversion of
+    NaN and Inf is undefined in C++ and saturating on the GPU.)"""
+    P, M, n_cams, W, H = 600, 4, 2, 64, 64
+    s = gs.synth.random_splats(P, M, 31337)
+    rng = np.random.default_rng(1)
+    loc, scale, opac, rot, sh = (s[k].reshape(P, -1).copy() for k in ("loc", "scale", "opac", "rot", "sh"))
+    bad = rng.choice(P, 60, replace=False)
+    loc[bad[0:6]] = np.nan; loc[bad[6:12]] = np.inf; loc[bad[12:18], 2] = -np.inf
+    scale[bad[18:24]] = 0.0; scale[bad[24:30]] = 1e30; scale[bad[30:34]] = np.nan
+    opac[bad[34:38]] = np.nan; opac[bad[38:42]] = 1e9; opac[bad[42:46]] = -5.0
+    rot[bad[46:50]] = 0.0; rot[bad[50:54]] = np.inf
+    sh[bad[54:60]] = np.nan
+    cams = gs.camera.get_cameras(n_cams)
+    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(n_cams)]
+    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(n_cams)]
+    host = gs.ModelSplatsHost.fromVectors(loc, sh, scale, opac, rot)
+    host.shDegree = s["D"]
+    capi.check(capi.lib().gs_set_option(b"debug_sync", 1))
+    try:
+        tr = gs.Trainer(W, H)
+        tr.model = gs.ModelSplatsDevice(host)
+        tr.captureTruths(cams, fw, fb)
+        for _ in range(3):
+            st = tr.train(gs.Project(), stats=True)
+            assert st.count_after == P and 0 <= st.max_tile_list <= st.num_rendered
+        st = tr.train(gs.Project(), densify=True, stats=True)     # NaN comparisons in the classification are all false
+        assert 0 < st.count_after <= 2 * P
+        tr.close()
+    finally:
+        capi.check(capi.lib().gs_set_option(b"debug_sync", 0))
