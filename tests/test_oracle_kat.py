@@ -201,3 +201,43 @@ def test_densify_respects_capacity_and_variance_gate(orc):
     assert n2 == 3                                        # only one split fits (count < capacity guard)
     n2, *_ = _densify(orc, loc, scale, [0.5, 0.5], [[1, 0, 0, 0]] * 2, [2.5, 2.5], [[0, 0, 1]] * 2, HP)
     assert n2 == 2                                        # var - |grad| = 1.5 <= 2.0: nothing happens
+
+
+def _quat_mul(a, b):   # (w, x, y, z)
+    w1, x1, y1, z1 = a
+    w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def test_rigid_motion_of_scene_and_camera_leaves_the_image_unchanged(orc):
+    """Source-independent pin of the whole projection chain (view transform, EWA Jacobian, quaternion -> covariance):
+    moving splats AND camera by the same rigid transform must not change the picture.  SH degree 0 (higher degrees
+    are defined in the world frame and do not rotate with the scene).  fp64 oracle: agreement to 1e-9."""
+    P, M, W, H = 300, 1, 96, 64
+    s = gs.synth.random_splats(P, M, 5150)
+    cam = gs.camera.get_cameras(3)[1]
+    vb = gs.camera.view_block(cam, W, H, white=True).astype(np.float64)
+    q = np.array([0.3, -0.5, 0.7, 0.4]); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                   [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    t = np.array([0.7, -1.3, 2.1])
+    Tinv = np.eye(4); Tinv[:3, :3] = Rm.T; Tinv[:3, 3] = -Rm.T @ t
+    col = lambda m: m.T.reshape(-1)                      # 4x4 -> glm column-major 16 floats
+    mat = lambda v: np.asarray(v).reshape(4, 4).T
+    view2, proj2 = col(mat(vb[0:16]) @ Tinv), col(mat(vb[16:32]) @ Tinv)
+    campos2 = Rm @ vb[32:35] + t
+    loc = s["loc"].reshape(P, 3).astype(np.float64)
+    rot = s["rot"].reshape(P, 4).astype(np.float64)
+    rot /= np.linalg.norm(rot, axis=1, keepdims=True)   # the rasterizer does not normalise: R(q r) = R(q) R(r) needs |r| = 1 exactly
+    loc2 = loc @ Rm.T + t
+    rot2 = np.stack([_quat_mul(q, r) for r in rot])
+    imgs = []
+    for L, Rq, V, Pm, C in ((loc, rot, vb[0:16], vb[16:32], vb[32:35]), (loc2, rot2, view2, proj2, campos2)):
+        r = orc.Rasterizer(np.float64)
+        out, _ = r.forward(0, M, vb[37:40], W, H, L, s["sh"], s["opac"], s["scale"], 1.0, Rq, V, Pm, C, float(vb[35]), float(vb[36]))
+        imgs.append(out)
+    assert imgs[0].std() > 0.01                          # a non-trivial picture
+    assert np.abs(imgs[0] - imgs[1]).max() < 1e-9
