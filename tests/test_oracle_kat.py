@@ -241,3 +241,27 @@ def test_rigid_motion_of_scene_and_camera_leaves_the_image_unchanged(orc):
         imgs.append(out)
     assert imgs[0].std() > 0.01                          # a non-trivial picture
     assert np.abs(imgs[0] - imgs[1]).max() < 1e-9
+
+
+def test_uniform_scaling_of_scene_and_camera_leaves_the_image_unchanged(orc):
+    """Second source-independent pin: scaling positions, splat sizes and the camera distance by one factor k keeps
+    every projected mean and every 2D covariance (J ~ 1/k, cov3D ~ k^2), hence the picture; depths scale by k, the
+    sort order does not change.  Any degree of SH (directions are unchanged)."""
+    P, M, W, H, k = 300, 9, 96, 64, 2.5
+    s = gs.synth.random_splats(P, M, 777)
+    cam = gs.camera.get_cameras(4)[2]
+    vb = gs.camera.view_block(cam, W, H, white=False).astype(np.float64)
+    mat = lambda v: np.asarray(v).reshape(4, 4).T
+    col = lambda m: m.T.reshape(-1)
+    V = mat(vb[0:16]); PV = mat(vb[16:32])
+    Pm = PV @ np.linalg.inv(V)
+    V2 = V.copy(); V2[:3, 3] *= k
+    imgs, depths = [], []
+    for L, S, Vm, C in ((s["loc"].astype(np.float64), s["scale"].astype(np.float64), V, vb[32:35]),
+                        (s["loc"].astype(np.float64) * k, s["scale"].astype(np.float64) * k, V2, vb[32:35] * k)):
+        r = orc.Rasterizer(np.float64)
+        out, _ = r.forward(2, M, vb[37:40], W, H, L, s["sh"], s["opac"], S, 1.0, s["rot"], col(Vm), col(Pm @ Vm), C, float(vb[35]), float(vb[36]))
+        imgs.append(out)
+    assert imgs[0].std() > 0.01
+    # not 1e-9: upstream divides by (w + 1e-7), and that epsilon does not scale with the scene (1e-8 relative at w = 10)
+    assert np.abs(imgs[0] - imgs[1]).max() < 2e-6
