@@ -1,7 +1,7 @@
 // capi.hip — the C-ABI of include/gsplat.h: model, trainer, rasterizer seam, RCCL communicator.
-// Host orchestration only; every arithmetic step is a HIP kernel in k_*.hip (densify excepted,
-// which the reference also runs on the CPU).  There is no CPU fallback: without a HIP device the
-// entry points fail with GS_ERR_NO_DEVICE / GS_ERR_HIP.
+// Host orchestration only; every arithmetic step is a HIP kernel in k_*.hip (densify / prune
+// included: k_densify.hip — the reference does that one on the CPU).  There is no CPU fallback:
+// without a HIP device the entry points fail with GS_ERR_NO_DEVICE / GS_ERR_HIP.
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <string.h>
@@ -618,12 +618,23 @@ static int resolve_stats(gs_trainer* t) {
 // projection (a few tens of microseconds into the step, while the rest of the step is already queued behind it): on
 // return the stream is still busy.  An overflowing arena is grown and the iteration replayed.
 static int accumulate_async(gs_trainer* t) {
-    if (t->V == 0) { set_error("Can't run training iteration, no truth data available!"); return GS_ERR_NO_TRUTH; }
+    if (t->V == 0 && t->total_samples <= 0) { set_error("Can't run training iteration, no truth data available!"); return GS_ERR_NO_TRUTH; }
     if (!t->model) return GS_ERR_NO_MODEL;
     GS_HIP(hipSetDevice(t->device));
     gs_model* m = t->model;
     const int P = m->count, M = m->sh_coeffs, V = t->V;
     const Planes pl{ M };
+    if (V == 0) {
+        // A data-parallel rank that owns no pass of this iteration (more ranks than passes): its contribution to the
+        // averaged gradients is zero, and it still joins the collective and applies the common update.
+        GS_TRY(t->grad.ensure((size_t)(pl.count() + 1) * m->Pa * 4));
+        t->grad_Pa = m->Pa; t->grad_M = M;
+        GS_HIP(hipMemsetAsync(t->grad.p, 0, (size_t)(pl.count() + 1) * m->Pa * 4, t->stream));
+        gs_step_stats st0{};
+        st0.count_before = st0.count_after = P;
+        t->last = st0; t->stats_stale = false; t->accumulated = true;
+        return GS_OK;
+    }
     if (t->pending.size() > 4096) { GS_HIP(hipStreamSynchronize(t->stream)); prof_resolve(t); }
     gs_step_stats st{};
     st.count_before = st.count_after = P; st.views = V;
@@ -751,13 +762,26 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
     if (rc == GS_OK && hipDeviceSynchronize() != hipSuccess) rc = GS_ERR_HIP;  // model_alloc clears the planes on the null stream; ours does not wait for it
     if (rc == GS_OK) rc = launch_densify_emit(count, m->Pa, M, m->planes, t->grad.as<float>(), *h, flags, ranks, fs, splits_done, clones_done, kept,
                                               fresh->Pa, fresh->planes, t->stream);
+    // Adam moments follow their splats (twins inherit the parent's); the step counter keeps running
+    DevBuf new_m, new_v;
+    if (rc == GS_OK && t->adam_valid) {
+        const size_t bytes = (size_t)(11 + 3 * M) * fresh->Pa * 4;
+        rc = new_m.ensure(bytes);
+        if (rc == GS_OK) rc = new_v.ensure(bytes);
+        if (rc == GS_OK && (hipMemsetAsync(new_m.p, 0, bytes, t->stream) != hipSuccess || hipMemsetAsync(new_v.p, 0, bytes, t->stream) != hipSuccess)) rc = GS_ERR_HIP;
+        if (rc == GS_OK) rc = launch_densify_carry(count, m->Pa, M, *h, flags, ranks, fs, splits_done, clones_done, kept, fresh->Pa,
+                                                   t->adam_m.as<float>(), new_m.as<float>(), t->adam_v.as<float>(), new_v.as<float>(), t->stream);
+    }
     if (rc == GS_OK && hipStreamSynchronize(t->stream) != hipSuccess) { rc = GS_ERR_HIP; set_error("densify failed: %s", hipGetErrorString(hipGetLastError())); }
     work.release();
-    if (rc != GS_OK) { if (fresh) gs_model_destroy(fresh); return rc; }
+    if (rc != GS_OK) { if (fresh) gs_model_destroy(fresh); new_m.release(); new_v.release(); return rc; }
     std::swap(m->planes, fresh->planes);
     m->Pa = fresh->Pa; m->count = fresh->count;
     gs_model_destroy(fresh);
-    t->adam_valid = false; t->adam_t = 0;  // optimizer state does not survive re-indexing
+    if (t->adam_valid) {
+        t->adam_m.release(); t->adam_v.release();
+        t->adam_m = new_m; t->adam_v = new_v;  // DevBuf is a plain (pointer, capacity) pair: ownership moves
+    }
     st->count_after = n2;
     return GS_OK;
 }
@@ -809,6 +833,17 @@ extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs
         if (rc != 0) { set_error("all-reduce hook failed with %d", rc); return GS_ERR_INTERNAL; }
     }
     return gs_trainer_apply(t, h, densify, stats);
+}
+
+extern "C" int gs_trainer_adam_state(gs_trainer* t, float** m, float** v, size_t* n_floats, int* steps) {
+    if (!t || !t->model) return GS_ERR_INVALID_ARGUMENT;
+    GS_HIP(hipStreamSynchronize(t->stream));
+    const bool ok = t->adam_valid;
+    if (m) *m = ok ? t->adam_m.as<float>() : nullptr;
+    if (v) *v = ok ? t->adam_v.as<float>() : nullptr;
+    if (n_floats) *n_floats = ok ? (size_t)(11 + 3 * t->model->sh_coeffs) * t->model->Pa : 0;
+    if (steps) *steps = ok ? t->adam_t : 0;
+    return GS_OK;
 }
 
 extern "C" int gs_trainer_set_allreduce(gs_trainer* t, gs_allreduce_fn fn, void* user) {

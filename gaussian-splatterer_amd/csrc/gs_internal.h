@@ -164,6 +164,11 @@ int launch_densify_classify(int count, int Pa, int M, const float* params, const
 int launch_densify_emit(int count, int Pa, int M, const float* params, const float* grad, const gs_hyper& h, const uint32_t* flags,
                         const uint32_t* ranks, int fs, int splits_done, int clones_done, int kept, int outPa, float* out, hipStream_t st);
 
+// Adam moments (two [11+3M][Pa] buffers) re-indexed like the parameters of the same densify (k_densify.hip)
+int launch_densify_carry(int count, int Pa, int M, const gs_hyper& h, const uint32_t* flags, const uint32_t* ranks, int fs, int splits_done,
+                         int clones_done, int kept, int outPa, const float* src_m, float* dst_m, const float* src_v, float* dst_v,
+                         hipStream_t st);
+
 }  // namespace gs
 
 struct gs_model {

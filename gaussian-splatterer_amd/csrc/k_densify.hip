@@ -3,8 +3,8 @@
 // The reference does this on the CPU every 200th iteration (src/Trainer.cu:433-542: download the model, walk
 // std::unordered_sets, upload); at 100k splats that round trip costs 60 ms, i.e. 0.3 ms per iteration amortised —
 // 12 % of a 2.4 ms step.  The same decisions are order-independent once the candidates are visited in ascending
-// index (the reference's set order is implementation-defined; oracle/ and csrc/densify.cpp use ascending index too),
-// so they become three prefix sums and one emit pass, bit-identical to csrc/densify.cpp:
+// index (the reference's set order is implementation-defined; the oracle's restatement uses ascending index too),
+// so they become three prefix sums and one emit pass, bit-identical to that restatement (oracle/gs_oracle.cpp, orc_densify):
 //   cull   : opacity <= cullOpacity  or  |scale| < cullSize                                              (:451)
 //   densify: var - |avgGradLoc| > densifyVariance; split if |scale| > splitSize else clone               (:453-454)
 //   capacity: the s-th split (ascending index) happens iff original + s < capacity, then the c-th clone iff
@@ -14,7 +14,7 @@
 //   clone  : the copy is offset by (R*scale) (.) normalize(avgGradLoc) * cloneDistance                    (:499-521)
 //   prune  : stable compaction: kept originals in index order, then the split twins, then the clone twins (:524-534)
 // Built with -ffp-contract=off like the rest of the library: every float operation is the individually rounded
-// IEEE operation densify.cpp performs, in the same order.
+// IEEE operation the restatement performs, in the same order.
 #include "gs_internal.h"
 
 namespace gs {
@@ -24,7 +24,7 @@ enum : uint32_t { KEEP = 0, SPLIT = 1, CLONE = 2, REMOVE = 3 };
 
 __device__ inline float norm3(float a, float b, float c) { return sqrtf(a * a + b * b + c * c); }
 
-// (mat4)q * vec4(v, 1) followed by the reference's divide by w, as densify.cpp::rotate
+// (mat4)q * vec4(v, 1) followed by the reference's divide by w, as the reference's glm expression does (src/Trainer.cu:466-470)
 __device__ inline void rotate(float w_, float x, float y, float z, const float v[3], float out[3]) {
     float R[3][3];  // R[col][row]
     R[0][0] = 1.0f - 2.0f * (y * y + z * z); R[0][1] = 2.0f * (x * y + w_ * z); R[0][2] = 2.0f * (x * z - w_ * y);
@@ -121,6 +121,46 @@ __global__ __launch_bounds__(WG) void k_densify_emit(int count, int Pa, int M, c
         out[(size_t)(3 + k) * so + dest] = v;
         if (twin >= 0) out[(size_t)(3 + k) * so + twin] = v;
     }
+}
+
+// Optimizer state through densify (build-side extension; the reference has no optimizer state): the Adam moments of
+// a kept splat move to its new index, both halves of a split and a clone's twin inherit the parent's moments, and the
+// rotation rows follow the quaternion's member permutation of a split (k_densify_emit).  Same index bookkeeping as the
+// emit pass; blockIdx.y selects the first or the second moment buffer.
+__global__ __launch_bounds__(WG) void k_densify_carry(int count, int Pa, int M, gs_hyper h, const uint32_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ ranks, int fs, int splits_done, int clones_done, int kept,
+                                                      int outPa, const float* __restrict__ src_m, float* __restrict__ dst_m,
+                                                      const float* __restrict__ src_v, float* __restrict__ dst_v) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= count) return;
+    if (!flags[2 * (size_t)fs + i]) return;
+    const float* __restrict__ src = blockIdx.y ? src_v : src_m;
+    float* __restrict__ dst = blockIdx.y ? dst_v : dst_m;
+    const Planes pl{ M };
+    const size_t st = (size_t)Pa, so = (size_t)outPa;
+    const int dest = (int)ranks[2 * (size_t)fs + i] - 1;
+    const bool do_split = flags[i] != 0u && (int)ranks[i] - 1 < splits_done;
+    const bool do_clone = flags[(size_t)fs + i] != 0u && (int)ranks[(size_t)fs + i] - 1 < clones_done;
+    const int twin = do_split ? kept + (int)ranks[i] - 1 : (do_clone ? kept + splits_done + (int)ranks[(size_t)fs + i] - 1 : -1);
+    const bool permute = do_split && h.quat_layout == GS_QUAT_XYZW;
+    const int nplanes = pl.count();
+    for (int p = 0; p < nplanes; p++) {
+        int ps = p;
+        if (permute && p >= pl.rot(0)) ps = pl.rot(((p - pl.rot(0)) + 1) & 3);  // stored (q1, q2, q3, q0): row c takes old row c + 1
+        const float v = src[(size_t)ps * st + i];
+        dst[(size_t)p * so + dest] = v;
+        if (twin >= 0) dst[(size_t)p * so + twin] = v;
+    }
+}
+
+int launch_densify_carry(int count, int Pa, int M, const gs_hyper& h, const uint32_t* flags, const uint32_t* ranks, int fs, int splits_done,
+                         int clones_done, int kept, int outPa, const float* src_m, float* dst_m, const float* src_v, float* dst_v,
+                         hipStream_t st) {
+    if (count == 0) return GS_OK;
+    hipLaunchKernelGGL(k_densify_carry, dim3((count + WG - 1) / WG, 2), dim3(WG), 0, st, count, Pa, M, h, flags, ranks, fs, splits_done,
+                       clones_done, kept, outPa, src_m, dst_m, src_v, dst_v);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
 }
 
 // Launch helpers.  `flags` and `ranks` are 3 x fs u32 each; `partials` as launch_scan_u32 needs for (count, batch 3).

@@ -468,10 +468,17 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
 #pragma unroll
                     for (int p = 0; p < K; p++) {
                         const float ux = u[p] * dx, uy = u[p] * dy;
+#if defined(GS_EXP_NO_REDUCE)     // experiment (WRONG results): what the kernel costs without the cross-lane reduction
+                        float red = ((dchannel_dcolor * dpx[p][0] + dchannel_dcolor * dpx[p][1]) + (dchannel_dcolor * dpx[p][2] + ux)) +
+                                    ((uy + ux * dx) + (ux * dy + uy * dy)) + u[p];
+#elif defined(GS_EXP_NO_MOMENTS)  // experiment (WRONG results): neither moments nor reduction, only the two LDS-side values
+                        float red = dchannel_dcolor + u[p];
+#else
                         float red = wave_reduce_scatter9_rows(dchannel_dcolor * dpx[p][0], dchannel_dcolor * dpx[p][1],
                                                               dchannel_dcolor * dpx[p][2], ux, uy, ux * dx, ux * dy, uy * dy, u[p]);
                         red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold16, __builtin_bit_cast(int, red)));
                         red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold32, __builtin_bit_cast(int, red)));
+#endif
                         if (writer) acc_lane[jj * ACC_STRIDE + p * (4 * ROUND * ACC_STRIDE)] = red;  // lane-constant base + scalar offset
                     }
                     touched[sb] |= 1ull << kk;

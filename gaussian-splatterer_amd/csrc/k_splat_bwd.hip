@@ -308,15 +308,20 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __
         aOpac += r2.z / samples;
 #pragma unroll
         for (int c = 0; c < 4; c++) aRot[c] += gr[c] / samples;
-        const float* cp = s.views[v].campos;
-        const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
-        const float len = sqrtf(ox * ox + oy * oy + oz * oz);
-        float basis[NC];
-        sh_basis<D>(ox / len, oy / len, oz / len, basis);
+        // A pass in which the splat is culled (or its colour gradient is exactly zero) adds +0 to every SH sum: skip it,
+        // as upstream's radii > 0 guard does — the basis of a splat AT the camera position (len = 0) or with a
+        // non-finite mean is NaN, and NaN * 0 would poison the SH planes for good.
+        if (dRGB[0] != 0.0f || dRGB[1] != 0.0f || dRGB[2] != 0.0f) {
+            const float* cp = s.views[v].campos;
+            const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
+            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+            float basis[NC];
+            sh_basis<D>(ox / len, oy / len, oz / len, basis);
 #pragma unroll
-        for (int k = 0; k < NC; k++)
+            for (int k = 0; k < NC; k++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) aSh[k][c] += (basis[k] * dRGB[c]) / samples;
+                for (int c = 0; c < 3; c++) aSh[k][c] += (basis[k] * dRGB[c]) / samples;
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) { grad[pl.loc(c) * st + i] = aLoc[c]; grad[pl.scale(c) * st + i] = aScale[c]; }

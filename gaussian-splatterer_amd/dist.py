@@ -1,8 +1,9 @@
 """Data-parallel plumbing over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo"
 on CPU for tests).  One process per GPU; splat parameters are replicated, the passes of an
-iteration are sharded round-robin (pass v -> rank v % world), and ONE sum all-reduce of the
-averaged-gradient buffer [(12+3M) planes x plane stride fp32] runs between accumulate and apply
-(SURVEY §8e).  S (the divisor of accumulateGradients, src/Trainer.cu:419) stays the GLOBAL pass
+iteration are sharded by CAMERA (camera c -> rank c % world, both its white and its black pass, so the
+rank keeps the shared projection / tile lists / fused two-pass backward of the camera), and ONE sum
+all-reduce of the averaged-gradient buffer [(12+3M) planes x plane stride fp32] runs between accumulate
+and apply.  S (the divisor of accumulateGradients, src/Trainer.cu:419) stays the GLOBAL pass
 count, so local sums are already correctly scaled and the reduction is a plain sum.
 
 The reference has no multi-GPU path; this module is the build-side addition north_star asks for.
@@ -18,7 +19,14 @@ def env_world():
 
 
 def shard_views(total_views, rank, world):
-    """Passes owned by `rank`: v % world == rank (white/black twins of a camera may land on different ranks)."""
+    """Passes owned by `rank`.  The iteration has C = total_views / 2 cameras, pass c = camera c on white, pass C + c =
+    camera c on black (src/Trainer.cu:311-314).  Camera c goes to rank c % world WITH BOTH PASSES, so every rank keeps
+    the per-camera sharing (projection, lists, forward blend once; fused two-pass backward).  Only when there are
+    fewer cameras than ranks are the passes dealt one by one (v % world) — twins then split, and ranks beyond the pass
+    count own nothing: they still join the collective with a zero gradient (gs_trainer_set_views with n_views = 0)."""
+    C = total_views // 2
+    if total_views % 2 == 0 and C >= world:
+        return [v for v in range(total_views) if (v % C) % world == rank]
     return [v for v in range(total_views) if v % world == rank]
 
 

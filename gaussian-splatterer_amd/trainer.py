@@ -121,7 +121,7 @@ class Trainer:
         self._views_dirty = True
 
     def shard(self, rank, world):
-        """Data-parallel view sharding: pass v of the iteration goes to rank v % world."""
+        """Data-parallel view sharding: camera c of the iteration goes to rank c % world with both passes (dist.shard_views)."""
         self._rank, self._world = int(rank), int(world)
         self._views_dirty = True
 
@@ -129,7 +129,8 @@ class Trainer:
         Cn = len(self.truthCameras)
         blocks = cam.train_views(self.truthCameras, self.width, self.height) if Cn else np.zeros((0, 40), np.float32)
         total = 2 * Cn
-        mine = [v for v in range(total) if v % self._world == self._rank]
+        from .dist import shard_views
+        mine = shard_views(total, self._rank, self._world)
         views = (capi.gs_view * max(len(mine), 1))()
         ptrs = (C.c_void_p * max(len(mine), 1))()
         for k, v in enumerate(mine):

@@ -169,7 +169,11 @@ gs_model* gs_trainer_get_model(gs_trainer* trainer);
  * byte, width*height each; src/rtx/RtxDevice.cu:100).  `truth[i]` is a host pointer, or a device
  * pointer when truth_on_device != 0; images are copied.  `total_samples` is S, the number of
  * passes of the whole iteration over ALL processes (2 * #cameras, src/Trainer.cu:419): equal to
- * n_views on one GPU, larger when views are sharded. */
+ * n_views on one GPU, larger when views are sharded.  n_views == 0 with total_samples > 0 is a
+ * data-parallel rank that owns no pass (more ranks than passes): its steps contribute a zero
+ * gradient, still run the collective hook and apply the common update.  n_views == 0 with
+ * total_samples == 0 is the reference's "no truth data" state (gs_trainer_step fails with
+ * GS_ERR_NO_TRUTH, src/Trainer.cu:253). */
 int gs_trainer_set_views(gs_trainer* trainer, int n_views, const gs_view* views, const uint32_t* const* truth,
                          int truth_on_device, int total_samples);
 /* Trainer::train(Project&, bool densify), src/Trainer.cu:252-543: all local passes (forward, loss,
@@ -187,6 +191,13 @@ int gs_trainer_step(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs_
 int gs_trainer_accumulate(gs_trainer* trainer, gs_step_stats* stats);
 int gs_trainer_grad_buffer(gs_trainer* trainer, float** device_ptr, size_t* n_floats);
 int gs_trainer_apply(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs_step_stats* stats);
+
+/* Optimizer state of GS_UPDATE_ADAM (build-side extension; the reference has none): device pointers to the first and
+ * second moment, each [11+3M planes][plane stride] fp32 like the parameters, and the number of Adam steps taken.
+ * NULL / 0 before the first Adam step.  The moments follow their splats through densify/prune (the two halves of a
+ * split and a clone's twin start from the parent's moments) and the step counter keeps running; replacing the model
+ * (gs_trainer_set_model) resets both.  Synchronises the trainer's stream. */
+int gs_trainer_adam_state(gs_trainer* trainer, float** moment1, float** moment2, size_t* n_floats, int* steps);
 
 /* Collective hook called by gs_trainer_step between accumulate and apply: must sum `n_floats`
  * fp32 values at `device_buf` in place over all ranks, enqueued on `hip_stream`.  Return 0 on success. */

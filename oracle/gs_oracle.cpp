@@ -319,12 +319,103 @@ template <class R> struct Grads {
 // arbitrary order; here each (tile,entry) partial is summed in double in pixel order and the
 // partials are then added per splat in sorted-list order, i.e. the correctly rounded sum of the
 // same fp32 terms.  `abs9` (optional) receives sum|term| per splat for tolerance floors.
+//
+// Decision flips.  The blend has two discrete decisions per (pixel, entry) pair: "alpha < 1/255 -> skip" and
+// "T(1-alpha) < 1e-4 -> stop, entry not applied".  An implementation whose exp() differs from libm's in the last
+// bit may take the other branch for a pair that sits on a threshold, which moves the terms of EVERY splat blended
+// at that pixel.  PixelFlip forces one such decision the other way; with `flip9` (optional) render_backward re-runs
+// each pixel once per pair that lies within `flip_margin` (relative) of a threshold with that decision inverted and
+// accumulates |term_flipped - term| per splat and sum: the admissible deviation of an implementation that flips
+// those pairs.  The parity tests use  tol = 1e-4 * sum|term| + flip9(margin)  and report how the count of
+// out-of-tolerance splats depends on the margin (tests/test_gpu_raster.py).
+struct PixelFlip { long k = -1; int kind = 0; };  // kind 1: alpha test of list entry k inverted, 2: T test inverted
+
+// Forward blend of one pixel over list entries [beg, end) -> (final T, last contributor), as render_forward does,
+// with an optional forced decision.  Collects the fragile pairs when `frag` is given.
 template <class R>
-void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const Grads<R>& o, double* abs9) {
+inline void pixel_forward(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx, R pixfy, PixelFlip flip, R& T_out,
+                          uint32_t& last_out, std::vector<PixelFlip>* frag, float frag_margin) {
+    R Tt = R(1.0);
+    uint32_t contributor = 0, last = 0;
+    for (uint32_t k = beg; k < end; k++) {
+        contributor++;
+        const uint32_t id = g.point_list[k];
+        const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+        const R* co = &g.conic_opacity[4 * (size_t)id];
+        const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        if (power > R(0.0)) continue;
+        const R alpha = std::min(R(0.99), co[3] * std::exp(power));
+        bool skip = alpha < R(1.0) / R(255.0);
+        if (frag && (float)(std::fabs(alpha - R(1.0 / 255.0)) * R(255.0)) < frag_margin) frag->push_back({ (long)k, 1 });
+        if (flip.kind == 1 && flip.k == (long)k) skip = !skip;
+        if (skip) continue;
+        const R test_T = Tt * (R(1.0) - alpha);
+        bool stop = test_T < R(0.0001);
+        if (frag && (float)(std::fabs(test_T - R(0.0001)) * R(10000.0)) < frag_margin) frag->push_back({ (long)k, 2 });
+        if (flip.kind == 2 && flip.k == (long)k) stop = !stop;
+        if (stop) break;
+        Tt = test_T;
+        last = contributor;
+    }
+    T_out = Tt; last_out = last;
+}
+
+// Reverse traversal of one pixel (upstream renderCUDA backward); emit(k, q, term) receives the nine terms of every
+// blended entry.  The alpha test honours the same forced decision as pixel_forward.
+template <class R, class Emit>
+inline void pixel_backward(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx, R pixfy, R T_final, uint32_t last_contributor,
+                           const R* bg, const R dpx[3], R ddelx_dx, R ddely_dy, PixelFlip flip, Emit emit) {
+    R Tt = T_final;
+    R accum_rec[3] = { 0, 0, 0 }, last_color[3] = { 0, 0, 0 }, last_alpha = 0;
+    uint32_t contributor = end - beg;
+    for (uint32_t k = end; k-- > beg;) {
+        contributor--;
+        if (contributor >= last_contributor) continue;
+        const uint32_t id = g.point_list[k];
+        const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+        const R* co = &g.conic_opacity[4 * (size_t)id];
+        const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        if (power > R(0.0)) continue;
+        const R G = std::exp(power);
+        const R alpha = std::min(R(0.99), co[3] * G);
+        bool skip = alpha < R(1.0) / R(255.0);
+        if (flip.kind == 1 && flip.k == (long)k) skip = !skip;
+        if (skip) continue;
+        Tt = Tt / (R(1.0) - alpha);
+        const R dchannel_dcolor = alpha * Tt;
+        R dL_dalpha = 0;
+        for (int c = 0; c < 3; c++) {
+            const R col = g.rgb[3 * (size_t)id + c];
+            accum_rec[c] = last_alpha * last_color[c] + (R(1.0) - last_alpha) * accum_rec[c];
+            last_color[c] = col;
+            dL_dalpha += (col - accum_rec[c]) * dpx[c];
+            emit(k, c, dchannel_dcolor * dpx[c]);
+        }
+        dL_dalpha *= Tt;
+        last_alpha = alpha;
+        R bg_dot = 0;
+        for (int c = 0; c < 3; c++) bg_dot += bg[c] * dpx[c];
+        dL_dalpha += (-T_final / (R(1.0) - alpha)) * bg_dot;
+        const R dL_dG = co[3] * dL_dalpha;
+        const R gdx = G * dx, gdy = G * dy;
+        const R dG_ddelx = -gdx * co[0] - gdy * co[1];
+        const R dG_ddely = -gdy * co[2] - gdx * co[1];
+        emit(k, 3, dL_dG * dG_ddelx * ddelx_dx);
+        emit(k, 4, dL_dG * dG_ddely * ddely_dy);
+        emit(k, 5, R(-0.5) * gdx * dx * dL_dG);
+        emit(k, 6, R(-0.5) * gdx * dy * dL_dG);
+        emit(k, 7, R(-0.5) * gdy * dy * dL_dG);
+        emit(k, 8, G * dL_dalpha);
+    }
+}
+
+template <class R>
+void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const Grads<R>& o, double* abs9, double* flip9 = nullptr,
+                     float flip_margin = 0.0f) {
     const int W = g.W, H = g.H, P = g.P;
     const size_t N = (size_t)W * H;
     const size_t Rn = g.point_list.size();
-    std::vector<double> part(Rn * 9, 0.0), partabs(abs9 ? Rn * 9 : 0, 0.0);
+    std::vector<double> part(Rn * 9, 0.0), partabs(abs9 ? Rn * 9 : 0, 0.0), partflip(flip9 ? Rn * 9 : 0, 0.0);
     const int T = g.gx * g.gy;
     const R ddelx_dx = R(0.5) * R(W), ddely_dy = R(0.5) * R(H);
 #pragma omp parallel for schedule(dynamic, 4)
@@ -332,63 +423,46 @@ void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const
         const int tx = tile % g.gx, ty = tile / g.gx;
         const uint32_t beg = g.ranges[2 * (size_t)tile], end = g.ranges[2 * (size_t)tile + 1];
         if (end <= beg) continue;
+        std::vector<PixelFlip> frag;
+        std::vector<double> t0, t1;
         for (int py = ty * TILE; py < std::min(H, (ty + 1) * TILE); py++)
             for (int px = tx * TILE; px < std::min(W, (tx + 1) * TILE); px++) {
                 const size_t pix = (size_t)py * W + px;
                 const R pixfx = (R)px, pixfy = (R)py;
-                const R T_final = g.final_T[pix];
-                R Tt = T_final;
-                const uint32_t last_contributor = g.n_contrib[pix];
-                R accum_rec[3] = { 0, 0, 0 }, last_color[3] = { 0, 0, 0 }, last_alpha = 0;
                 const R dpx[3] = { dL_dpix[pix], dL_dpix[N + pix], dL_dpix[2 * N + pix] };
-                uint32_t contributor = end - beg;
-                for (uint32_t k = end; k-- > beg;) {
-                    contributor--;
-                    if (contributor >= last_contributor) continue;
-                    const uint32_t id = g.point_list[k];
-                    const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
-                    const R* co = &g.conic_opacity[4 * (size_t)id];
-                    const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > R(0.0)) continue;
-                    const R G = std::exp(power);
-                    const R alpha = std::min(R(0.99), co[3] * G);
-                    if (alpha < R(1.0) / R(255.0)) continue;
-                    Tt = Tt / (R(1.0) - alpha);
-                    const R dchannel_dcolor = alpha * Tt;
-                    R dL_dalpha = 0;
-                    double* pp = &part[(size_t)k * 9];
-                    double* pa = abs9 ? &partabs[(size_t)k * 9] : nullptr;
-                    for (int c = 0; c < 3; c++) {
-                        const R col = g.rgb[3 * (size_t)id + c];
-                        accum_rec[c] = last_alpha * last_color[c] + (R(1.0) - last_alpha) * accum_rec[c];
-                        last_color[c] = col;
-                        dL_dalpha += (col - accum_rec[c]) * dpx[c];
-                        const R term = dchannel_dcolor * dpx[c];
-                        pp[c] += (double)term; if (pa) pa[c] += std::fabs((double)term);
-                    }
-                    dL_dalpha *= Tt;
-                    last_alpha = alpha;
-                    R bg_dot = 0;
-                    for (int c = 0; c < 3; c++) bg_dot += bg[c] * dpx[c];
-                    dL_dalpha += (-T_final / (R(1.0) - alpha)) * bg_dot;
-                    const R dL_dG = co[3] * dL_dalpha;
-                    const R gdx = G * dx, gdy = G * dy;
-                    const R dG_ddelx = -gdx * co[0] - gdy * co[1];
-                    const R dG_ddely = -gdy * co[2] - gdx * co[1];
-                    const R t3 = dL_dG * dG_ddelx * ddelx_dx, t4 = dL_dG * dG_ddely * ddely_dy;
-                    const R t5 = R(-0.5) * gdx * dx * dL_dG, t6 = R(-0.5) * gdx * dy * dL_dG, t7 = R(-0.5) * gdy * dy * dL_dG;
-                    const R t8 = G * dL_dalpha;
-                    const R tt[6] = { t3, t4, t5, t6, t7, t8 };
-                    for (int q = 0; q < 6; q++) { pp[3 + q] += (double)tt[q]; if (pa) pa[3 + q] += std::fabs((double)tt[q]); }
+                pixel_backward<R>(g, beg, end, pixfx, pixfy, g.final_T[pix], g.n_contrib[pix], bg, dpx, ddelx_dx, ddely_dy, PixelFlip{},
+                                  [&](uint32_t k, int q, R term) {
+                                      part[(size_t)k * 9 + q] += (double)term;
+                                      if (abs9) partabs[(size_t)k * 9 + q] += std::fabs((double)term);
+                                  });
+                if (!flip9 || !(g.margin[pix] < flip_margin)) continue;
+                // this pixel holds at least one pair within flip_margin of a threshold: one re-run per such pair
+                frag.clear();
+                R Tq; uint32_t lastq;
+                pixel_forward<R>(g, beg, end, pixfx, pixfy, PixelFlip{}, Tq, lastq, &frag, flip_margin);
+                if (frag.empty()) continue;
+                const size_t n = (size_t)(end - beg) * 9;
+                t0.assign(n, 0.0);
+                pixel_backward<R>(g, beg, end, pixfx, pixfy, Tq, lastq, bg, dpx, ddelx_dx, ddely_dy, PixelFlip{},
+                                  [&](uint32_t k, int q, R term) { t0[(size_t)(k - beg) * 9 + q] = (double)term; });
+                for (const PixelFlip& f : frag) {
+                    R Tf; uint32_t lastf;
+                    pixel_forward<R>(g, beg, end, pixfx, pixfy, f, Tf, lastf, nullptr, 0.0f);
+                    t1.assign(n, 0.0);
+                    pixel_backward<R>(g, beg, end, pixfx, pixfy, Tf, lastf, bg, dpx, ddelx_dx, ddely_dy, f,
+                                      [&](uint32_t k, int q, R term) { t1[(size_t)(k - beg) * 9 + q] = (double)term; });
+                    for (size_t j = 0; j < n; j++) partflip[(size_t)beg * 9 + j] += std::fabs(t1[j] - t0[j]);
                 }
             }
     }
     std::vector<double> acc((size_t)P * 9, 0.0);
     if (abs9) std::fill(abs9, abs9 + (size_t)P * 9, 0.0);
+    if (flip9) std::fill(flip9, flip9 + (size_t)P * 9, 0.0);
     for (size_t k = 0; k < Rn; k++) {
         const uint32_t id = g.point_list[k];
         for (int q = 0; q < 9; q++) acc[(size_t)id * 9 + q] += part[k * 9 + q];
         if (abs9) for (int q = 0; q < 9; q++) abs9[(size_t)id * 9 + q] += partabs[k * 9 + q];
+        if (flip9) for (int q = 0; q < 9; q++) flip9[(size_t)id * 9 + q] += partflip[k * 9 + q];
     }
     for (int i = 0; i < P; i++) {
         const double* a = &acc[(size_t)i * 9];
@@ -591,8 +665,8 @@ int forward_impl(State<R>* st, int P, int D, int M, const R* bg, int W, int H, c
 template <class R>
 void backward_impl(State<R>* st, int D, int M, const R* bg, const R* means, const R* shs, const R* scales, R mod,
                    const R* rots, const R* view, const R* proj, const R* campos, R tanx, R tany, const R* dL_dpix,
-                   const Grads<R>& o, double* abs9) {
-    render_backward<R>(st->v, bg, dL_dpix, o, abs9);
+                   const Grads<R>& o, double* abs9, double* flip9 = nullptr, float flip_margin = 0.0f) {
+    render_backward<R>(st->v, bg, dL_dpix, o, abs9, flip9, flip_margin);
     preprocess_backward<R>(st->v, D, M, means, scales, mod, rots, shs, view, proj, campos, tanx, tany, o);
 }
 
@@ -657,6 +731,36 @@ void orc_backward_f32(orc_state* s, int D, int M, const float* bg, const float* 
                       float* dL_dsh, float* dL_dscale, float* dL_drot, double* abs9) {
     Grads<float> o{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
     backward_impl<float>(&s->f, D, M, bg, means, shs, scales, mod, rots, view, proj, campos, tanx, tany, dL_dpix, o, abs9);
+}
+// The same, plus the decision-flip allowance (see render_backward): flip9[P][9] receives, per splat and sum, the
+// total |term change| over single-decision flips of every pair within `flip_margin` (relative) of a blend threshold.
+void orc_backward_f32_flip(orc_state* s, int D, int M, const float* bg, const float* means, const float* shs,
+                           const float* scales, float mod, const float* rots, const float* view, const float* proj,
+                           const float* campos, float tanx, float tany, const float* dL_dpix, float* dL_dmean2D,
+                           float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                           float* dL_dsh, float* dL_dscale, float* dL_drot, double* abs9, double* flip9, float flip_margin) {
+    Grads<float> o{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
+    backward_impl<float>(&s->f, D, M, bg, means, shs, scales, mod, rots, view, proj, campos, tanx, tany, dL_dpix, o, abs9, flip9, flip_margin);
+}
+// The per-splat half of the backward alone (upstream's computeCov2DCUDA + preprocessCUDA backward)
+// on caller-supplied pixel-stage sums: sums9[P][9] = dL_dcolor(3), dL_dmean2D(2), dL_dconic x/y/w(3), dL_dopacity(1).
+// The chain is LINEAR in those sums for a fixed scene, so the parity tests can carry a per-splat tolerance on the
+// sums (e.g. the decision-flip allowance) through to dL_dmean3D / dL_dcov3D / dL_dsh / dL_dscale / dL_drot by
+// evaluating it on unit inputs.  Uses the state of the last orc_forward_f32.
+void orc_chain_f32(orc_state* s, int D, int M, const float* means, const float* shs, const float* scales, float mod,
+                   const float* rots, const float* view, const float* proj, const float* campos, float tanx, float tany,
+                   const float* sums9, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot) {
+    const int P = s->f.v.P;
+    std::vector<float> m2((size_t)P * 3, 0.0f), con((size_t)P * 4, 0.0f), op(P, 0.0f), col((size_t)P * 3, 0.0f);
+    for (int i = 0; i < P; i++) {
+        const float* q = sums9 + (size_t)i * 9;
+        col[3 * (size_t)i] = q[0]; col[3 * (size_t)i + 1] = q[1]; col[3 * (size_t)i + 2] = q[2];
+        m2[3 * (size_t)i] = q[3]; m2[3 * (size_t)i + 1] = q[4];
+        con[4 * (size_t)i] = q[5]; con[4 * (size_t)i + 1] = q[6]; con[4 * (size_t)i + 3] = q[7];
+        op[i] = q[8];
+    }
+    Grads<float> o{ m2.data(), con.data(), op.data(), col.data(), dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
+    preprocess_backward<float>(s->f.v, D, M, means, scales, mod, rots, shs, view, proj, campos, tanx, tany, o);
 }
 void orc_backward_f64(orc_state* s, int D, int M, const double* bg, const double* means, const double* shs,
                       const double* scales, double mod, const double* rots, const double* view, const double* proj,
@@ -805,10 +909,30 @@ void orc_train_views(int P, int D, int M, int W, int H, int V, const float* loc,
 // (src/Trainer.cu:463,493-494); quat_xyzw == 0 models GLM_FORCE_QUAT_DATA_WXYZ (no permutation).
 // Arrays are ModelSplatsHost buffers sized to `capacity`; returns the new count.
 // ---------------------------------------------------------------------------------------------
-int orc_densify(float* loc, float* sh, float* scale, float* opac, float* rot, int count, int capacity, int M,
-                const float* var, const float* gradLoc, float cullOpacity, float cullSize, float densifyVariance,
-                float splitSize, float splitDistance, float splitScale, float cloneDistance, int quat_xyzw) {
+// adam_m / adam_v (optional, build-side extension: the reference has no optimizer state): Adam moments in the same
+// capacity-sized five-array layout [loc 3C | sh 3MC | scale 3C | opac C | rot 4C]; they follow their splat through
+// every copy (both halves of a split and a clone's twin inherit the parent's moments) and the rotation rows follow
+// the quaternion's member permutation.
+static int densify_impl(float* loc, float* sh, float* scale, float* opac, float* rot, int count, int capacity, int M,
+                        const float* var, const float* gradLoc, float cullOpacity, float cullSize, float densifyVariance,
+                        float splitSize, float splitDistance, float splitScale, float cloneDistance, int quat_xyzw,
+                        float* adam_m, float* adam_v) {
     std::set<int> toSplit, toClone, toRemove;
+    const size_t C = (size_t)capacity;
+    auto state_copy = [&](float* a, int to, int from) {
+        if (!a) return;
+        float *aLoc = a, *aSh = a + 3 * C, *aScale = aSh + 3 * (size_t)M * C, *aOpac = aScale + 3 * C, *aRot = aOpac + C;
+        std::memcpy(&aLoc[to * 3], &aLoc[from * 3], 12);
+        for (int k = 0; k < M * 3; k++) aSh[(size_t)to * 3 * M + k] = aSh[(size_t)from * 3 * M + k];
+        std::memcpy(&aScale[to * 3], &aScale[from * 3], 12);
+        aOpac[to] = aOpac[from];
+        std::memcpy(&aRot[to * 4], &aRot[from * 4], 16);
+    };
+    auto state_permute_rot = [&](float* a, int i) {
+        if (!a || !quat_xyzw) return;
+        float* r = a + 3 * C + 3 * (size_t)M * C + 3 * C + C + (size_t)i * 4;
+        const float w = r[0]; r[0] = r[1]; r[1] = r[2]; r[2] = r[3]; r[3] = w;
+    };
     auto len3 = [](float a, float b, float c) { return std::sqrt(a * a + b * b + c * c); };
     for (int i = 0; i < count; i++) {
         const float sizeMag = len3(scale[i * 3], scale[i * 3 + 1], scale[i * 3 + 2]);
@@ -823,6 +947,7 @@ int orc_densify(float* loc, float* sh, float* scale, float* opac, float* rot, in
         std::memcpy(&scale[to * 3], &scale[from * 3], 12);
         opac[to] = opac[from];
         std::memcpy(&rot[to * 4], &rot[from * 4], 16);
+        state_copy(adam_m, to, from); state_copy(adam_v, to, from);
     };
     for (int i : toSplit) {
         if (count >= capacity) continue;
@@ -853,6 +978,7 @@ int orc_densify(float* loc, float* sh, float* scale, float* opac, float* rot, in
         const float qmem_xyzw[4] = { qx, qy, qz, qw }, qmem_wxyz[4] = { qw, qx, qy, qz };
         const float* qm = quat_xyzw ? qmem_xyzw : qmem_wxyz;
         std::memcpy(&rot[i * 4], qm, 16); std::memcpy(&rot[i2 * 4], qm, 16);
+        state_permute_rot(adam_m, i); state_permute_rot(adam_m, i2); state_permute_rot(adam_v, i); state_permute_rot(adam_v, i2);
     }
     for (int i : toClone) {
         if (count >= capacity) continue;
@@ -879,6 +1005,19 @@ int orc_densify(float* loc, float* sh, float* scale, float* opac, float* rot, in
         count -= (int)toRemove.size();
     }
     return count;
+}
+int orc_densify(float* loc, float* sh, float* scale, float* opac, float* rot, int count, int capacity, int M,
+                const float* var, const float* gradLoc, float cullOpacity, float cullSize, float densifyVariance,
+                float splitSize, float splitDistance, float splitScale, float cloneDistance, int quat_xyzw) {
+    return densify_impl(loc, sh, scale, opac, rot, count, capacity, M, var, gradLoc, cullOpacity, cullSize, densifyVariance, splitSize,
+                        splitDistance, splitScale, cloneDistance, quat_xyzw, nullptr, nullptr);
+}
+int orc_densify_adam(float* loc, float* sh, float* scale, float* opac, float* rot, int count, int capacity, int M,
+                     const float* var, const float* gradLoc, float cullOpacity, float cullSize, float densifyVariance,
+                     float splitSize, float splitDistance, float splitScale, float cloneDistance, int quat_xyzw,
+                     float* adam_m, float* adam_v) {
+    return densify_impl(loc, sh, scale, opac, rot, count, capacity, M, var, gradLoc, cullOpacity, cullSize, densifyVariance, splitSize,
+                        splitDistance, splitScale, cloneDistance, quat_xyzw, adam_m, adam_v);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -111,7 +111,10 @@ class Rasterizer:
             raise KeyError(name)
         return buf[:n].view(dt).copy()
 
-    def backward(self, dL_dpix, want_abs=False):
+    def backward(self, dL_dpix, want_abs=False, flip_margin=None):
+        """flip_margin (fp32 only): also return g["flip9"][P, 9], the admissible deviation of an implementation that
+        takes the other branch at every blend decision within that relative margin of its threshold (gs_oracle.cpp,
+        render_backward)."""
         a = self.args
         dt = self.dt
         P, M = self.P, a["M"]
@@ -120,17 +123,22 @@ class Rasterizer:
                  dL_dsh=np.zeros(3 * M * P, dt), dL_dscale=np.zeros(3 * P, dt), dL_drot=np.zeros(4 * P, dt))
         dpix = _c(dL_dpix, dt).reshape(-1)
         if dt == np.float32:
-            abs9 = np.zeros(9 * P, np.float64) if want_abs else None
-            lib().orc_backward_f32(self.h, C.c_int(a["D"]), C.c_int(M), _p(a["bg"], f32p), _p(a["means"], f32p),
+            abs9 = np.zeros(9 * P, np.float64) if (want_abs or flip_margin is not None) else None
+            flip9 = np.zeros(9 * P, np.float64) if flip_margin is not None else None
+            fn = lib().orc_backward_f32 if flip_margin is None else lib().orc_backward_f32_flip
+            extra = () if flip_margin is None else (_p(flip9, f64p), C.c_float(flip_margin))
+            fn(self.h, C.c_int(a["D"]), C.c_int(M), _p(a["bg"], f32p), _p(a["means"], f32p),
                                    _p(a["shs"], f32p), _p(a["scales"], f32p), C.c_float(a["mod"]),
                                    _p(a["rots"], f32p), _p(a["view"], f32p), _p(a["proj"], f32p),
                                    _p(a["campos"], f32p), C.c_float(a["tanx"]), C.c_float(a["tany"]),
                                    _p(dpix, f32p), _p(g["dL_dmean2D"], f32p), _p(g["dL_dconic"], f32p),
                                    _p(g["dL_dopacity"], f32p), _p(g["dL_dcolor"], f32p), _p(g["dL_dmean3D"], f32p),
                                    _p(g["dL_dcov3D"], f32p), _p(g["dL_dsh"], f32p), _p(g["dL_dscale"], f32p),
-                                   _p(g["dL_drot"], f32p), _p(abs9, f64p))
-            if want_abs:
+                                   _p(g["dL_drot"], f32p), _p(abs9, f64p), *extra)
+            if abs9 is not None:
                 g["abs9"] = abs9.reshape(P, 9)
+            if flip9 is not None:
+                g["flip9"] = flip9.reshape(P, 9)
         else:
             lib().orc_backward_f64(self.h, C.c_int(a["D"]), C.c_int(M), _p(a["bg"], f64p), _p(a["means"], f64p),
                                    _p(a["shs"], f64p), _p(a["scales"], f64p), C.c_double(a["mod"]),
@@ -141,6 +149,22 @@ class Rasterizer:
                                    _p(g["dL_dcov3D"], f64p), _p(g["dL_dsh"], f64p), _p(g["dL_dscale"], f64p),
                                    _p(g["dL_drot"], f64p))
         return g
+
+
+def chain(r, sums9):
+    """The per-splat half of the backward (linear in the nine pixel-stage sums) of Rasterizer `r`'s last forward on
+    caller-supplied sums9[P, 9]; returns dL_dmean3D / dL_dcov3D / dL_dsh / dL_dscale / dL_drot (fp32)."""
+    a = r.args
+    P, M = r.P, a["M"]
+    assert r.dt == np.float32
+    sums9 = _c(sums9, np.float32).reshape(P, 9)
+    g = dict(dL_dmean3D=np.zeros(3 * P, np.float32), dL_dcov3D=np.zeros(6 * P, np.float32), dL_dsh=np.zeros(3 * M * P, np.float32),
+             dL_dscale=np.zeros(3 * P, np.float32), dL_drot=np.zeros(4 * P, np.float32))
+    lib().orc_chain_f32(r.h, C.c_int(a["D"]), C.c_int(M), _p(a["means"], f32p), _p(a["shs"], f32p), _p(a["scales"], f32p),
+                        C.c_float(a["mod"]), _p(a["rots"], f32p), _p(a["view"], f32p), _p(a["proj"], f32p), _p(a["campos"], f32p),
+                        C.c_float(a["tanx"]), C.c_float(a["tany"]), _p(sums9, f32p), _p(g["dL_dmean3D"], f32p),
+                        _p(g["dL_dcov3D"], f32p), _p(g["dL_dsh"], f32p), _p(g["dL_dscale"], f32p), _p(g["dL_drot"], f32p))
+    return g
 
 
 def image_float_to_int(src, w, h):
@@ -195,8 +219,18 @@ def apply_adam(loc, sh, scale, opac, rot, g, m, v, t, lrs, max_scale, b1, b2, ep
                          C.c_float(max_scale), C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_int(M), C.c_int(P))
 
 
-def densify(loc, sh, scale, opac, rot, count, capacity, M, var, grad_loc, hp, quat_xyzw=1):
-    """Trainer::train densify block (src/Trainer.cu:437-542); arrays sized to capacity, in place."""
+def densify(loc, sh, scale, opac, rot, count, capacity, M, var, grad_loc, hp, quat_xyzw=1, adam_m=None, adam_v=None):
+    """Trainer::train densify block (src/Trainer.cu:437-542); arrays sized to capacity, in place.  adam_m / adam_v
+    (optional, capacity-sized five-array layout) are carried along with their splats."""
+    if adam_m is not None:
+        lib().orc_densify_adam.restype = C.c_int
+        return lib().orc_densify_adam(_p(loc, f32p), _p(sh, f32p), _p(scale, f32p), _p(opac, f32p), _p(rot, f32p),
+                                      C.c_int(count), C.c_int(capacity), C.c_int(M), _p(_c(var, np.float32), f32p),
+                                      _p(_c(grad_loc, np.float32), f32p), C.c_float(hp["cull_opacity"]),
+                                      C.c_float(hp["cull_size"]), C.c_float(hp["densify_variance"]),
+                                      C.c_float(hp["split_size"]), C.c_float(hp["split_distance"]),
+                                      C.c_float(hp["split_scale"]), C.c_float(hp["clone_distance"]), C.c_int(quat_xyzw),
+                                      _p(adam_m, f32p), _p(adam_v, f32p))
     return lib().orc_densify(_p(loc, f32p), _p(sh, f32p), _p(scale, f32p), _p(opac, f32p), _p(rot, f32p),
                              C.c_int(count), C.c_int(capacity), C.c_int(M), _p(_c(var, np.float32), f32p),
                              _p(_c(grad_loc, np.float32), f32p), C.c_float(hp["cull_opacity"]),

@@ -1,5 +1,6 @@
-"""Multi-process data-parallel path on CPU (gloo, world_size 2): the passes of one iteration are sharded
-round-robin, every rank accumulates its own passes with the GLOBAL divisor S, one sum all-reduce of the
+"""Multi-process data-parallel path on CPU (gloo, world_size 2 and 3): the passes of one iteration are sharded by
+camera (both passes of a camera on one rank; pass by pass only when there are fewer cameras than ranks, and a rank
+may then own nothing), every rank accumulates its own passes with the GLOBAL divisor S, one sum all-reduce of the
 gradient buffer follows, and every rank applies the identical update.  The compute
 on each rank is the oracle (this box has no GPU); what is under test is the sharding + collective logic
 of gaussian-splatterer_amd/dist.py that bench.py uses with the nccl (RCCL) backend."""
@@ -21,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_cams=3):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
     import torch.distributed as dist
@@ -29,12 +30,13 @@ def _worker(rank, world, port, q):
     import gsplat_amd as gs
     from oracle import pyoracle as orc
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    P, M, W, H, n_cams = 300, 4, 64, 48, 3
+    P, M, W, H = 300, 4, 64, 48
     s = gs.synth.random_splats(P, M, 11)
     views = gs.camera.train_views(gs.camera.get_cameras(n_cams), W, H)
     V = views.shape[0]
     truths = np.random.default_rng(5).integers(0, 2 ** 32, (V, W * H), dtype=np.uint32)
     mine = gs.dist.shard_views(V, rank, world)
+    # a rank that owns no pass contributes a zero gradient and still joins the collective and the update
     o = orc.train_views(P, 1, M, W, H, s["loc"], s["sh"], s["scale"], s["opac"], s["rot"], views[mine], truths[mine], float(V))
     buf = np.concatenate([o[k] for k in ("loc", "sh", "scale", "opac", "rot", "var")])  # the library's plane order
     gs.dist.allreduce_sum_numpy(buf)
@@ -79,12 +81,61 @@ def test_two_rank_view_sharding_matches_single_process():
     assert np.abs(buf0 - single).max() <= 1e-6 * scale
 
 
+def _single(n_cams):
+    sys.path.insert(0, ROOT)
+    import gsplat_amd as gs
+    from oracle import pyoracle as orc
+    P, M, W, H = 300, 4, 64, 48
+    s = gs.synth.random_splats(P, M, 11)
+    views = gs.camera.train_views(gs.camera.get_cameras(n_cams), W, H)
+    V = 2 * n_cams
+    truths = np.random.default_rng(5).integers(0, 2 ** 32, (V, W * H), dtype=np.uint32)
+    o = orc.train_views(P, 1, M, W, H, s["loc"], s["sh"], s["scale"], s["opac"], s["rot"], views, truths, float(V))
+    return np.concatenate([o[k] for k in ("loc", "sh", "scale", "opac", "rot", "var")])
+
+
+@pytest.mark.parametrize("world,n_cams", [(2, 3),   # cameras % world != 0: rank 0 owns two cameras, rank 1 one
+                                           (3, 1)])  # more ranks than passes: rank 2 owns nothing
+def test_uneven_and_empty_shards(world, n_cams):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_cams)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    owned = [r[1] for r in res]
+    assert sorted(v for m in owned for v in m) == list(range(2 * n_cams))
+    if n_cams >= world:   # twins stay together
+        for m in owned:
+            assert sorted(v % n_cams for v in m) == sorted(2 * [c for c in set(v % n_cams for v in m)])
+    else:
+        assert any(len(m) == 0 for m in owned)
+    for r in res[1:]:
+        assert np.array_equal(r[2].view(np.uint32), res[0][2].view(np.uint32))   # identical reduced gradients everywhere
+        assert np.array_equal(r[3].view(np.uint32), res[0][3].view(np.uint32))   # identical replicas after the update
+    single = _single(n_cams)
+    assert np.abs(res[0][2] - single).max() <= 1e-6 * np.abs(single).max()
+
+
 def test_shard_views_partition():
     sys.path.insert(0, ROOT)
     import gsplat_amd as gs
-    for total in (1, 2, 16, 32, 33):
-        for world in (1, 2, 4, 8):
-            got = sorted(v for r in range(world) for v in gs.dist.shard_views(total, r, world))
-            assert got == list(range(total))
-            sizes = [len(gs.dist.shard_views(total, r, world)) for r in range(world)]
-            assert max(sizes) - min(sizes) <= 1
+    for total in (1, 2, 6, 16, 32, 33, 34):
+        for world in (1, 2, 3, 4, 8):
+            shards = [gs.dist.shard_views(total, r, world) for r in range(world)]
+            assert sorted(v for m in shards for v in m) == list(range(total))
+            C = total // 2
+            if total % 2 == 0 and C >= world:
+                for m in shards:   # both passes of every owned camera, cameras dealt evenly
+                    cams = sorted(set(v % C for v in m))
+                    assert sorted(m) == sorted(cams + [c + C for c in cams])
+                sizes = [len(m) // 2 for m in shards]
+                assert max(sizes) - min(sizes) <= 1
+            else:
+                sizes = [len(m) for m in shards]
+                assert max(sizes) - min(sizes) <= 1

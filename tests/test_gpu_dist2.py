@@ -128,3 +128,41 @@ def test_eight_way_view_sharding_sums_to_the_single_shard_gradients():
     summed = np.sum([p[0] for p in parts], axis=0)
     scale = np.abs(whole).max()
     assert scale > 0 and np.abs(summed - whole).max() <= 2e-6 * scale
+
+
+def test_rank_without_passes_steps_with_zero_gradient():
+    """More ranks than passes (world 3, one camera): rank 2 owns nothing.  Its step must not fail with "no truth data":
+    it contributes a zero gradient buffer, runs the collective hook and applies the update (a no-op on in-range
+    parameters under the reference rule)."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    import gsplat_amd as gs
+    from gsplat_amd import capi
+    s = gs.synth.random_splats(500, 4, 7)
+    cams = gs.camera.get_cameras(1)
+    rng = np.random.default_rng(1)
+    fw = [rng.integers(0, 2 ** 32, 64 * 48, dtype=np.uint32)]
+    fb = [rng.integers(0, 2 ** 32, 64 * 48, dtype=np.uint32)]
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = s["D"]
+    tr = gs.Trainer(64, 48)
+    tr.model = gs.ModelSplatsDevice(host)
+    tr.captureTruths(cams, fw, fb)
+    tr.shard(2, 3)
+    calls = []
+    hook = capi.ALLREDUCE_FN(lambda buf, n, stream, user: calls.append(n) or 0)
+    capi.check(capi.lib().gs_trainer_set_allreduce(tr.handle, C.cast(hook, C.c_void_p), None))
+    st = tr.train(gs.Project(), stats=True)
+    assert tr.local_views == [] and st.views == 0 and st.num_rendered == 0 and len(calls) == 1
+    ptr, n = tr.grad_buffer()
+    buf = np.empty(n, np.float32)
+    capi.check(capi.lib().gs_memcpy_d2h(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n * 4))
+    assert not buf.any()
+    h = gs.ModelSplatsHost.fromDevice(tr.model)
+    assert np.array_equal(h.locations[:1500], s["loc"]) and np.array_equal(h.opacities[:500], s["opac"])
+    tr.close()
+    # and the reference's own error is still there when there is no truth data at all
+    tr2 = gs.Trainer(64, 48)
+    with pytest.raises(RuntimeError, match="no truth data"):
+        tr2.train(gs.Project())
+    tr2.close()

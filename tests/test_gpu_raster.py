@@ -6,7 +6,8 @@ The projection stage is bit-exact by construction (same fp32 operation order, no
 every per-splat geometry field is compared with ==.  The blend differs from the oracle only through
 exp() (hardware v_exp_f32 vs libm): pixels that sit within 1e-3 relative of one of the blend's
 discrete thresholds (alpha = 1/255, T = 1e-4) are reported by the oracle (`margin`) and excluded from
-the per-pixel comparisons; everything else must meet 1e-4."""
+the per-pixel comparisons; everything else must meet 1e-4.  Gradients are compared for EVERY splat: the budget is
+1e-4 of sum|term| plus the oracle's decision-flip allowance (check_pixel_stage)."""
 import numpy as np
 import pytest
 
@@ -81,6 +82,49 @@ def test_forward_parity(orc, P, M, D, W, H, seed):
         _check_forward(orc, s, D, M, view_parts(views[v]), W, H)
 
 
+NINE = {"dL_dcolor": ([0, 1, 2], 3, [0, 1, 2]), "dL_dmean2D": ([3, 4], 3, [0, 1]), "dL_dconic": ([5, 6, 7], 4, [0, 1, 3]),
+        "dL_dopacity": ([8], 1, [0])}
+FLIP_MARGINS = (0.0, 1e-5, 1e-4, 1e-3)
+ASSERT_MARGIN = 1e-4
+
+
+def pixel_stage_outliers(P, g, og, flip9=None):
+    """Splats whose nine pixel-stage sums leave  1e-4 * sum|term| (+ the decision-flip allowance): bool[P]."""
+    bad = np.zeros(P, bool)
+    abs9 = og["abs9"]
+    for name, (qs, stride, cols) in NINE.items():
+        got = g[name].reshape(P, stride)
+        want = og[name].reshape(P, stride)
+        for q, c in zip(qs, cols):
+            tol = 1e-4 * np.maximum(abs9[:, q], 1e-3 * abs9[:, q].max() + 1e-30)
+            if flip9 is not None:
+                tol = tol + flip9[:, q]
+            bad |= np.abs(got[:, c].astype(np.float64) - want[:, c]) > tol
+    return bad
+
+
+def check_pixel_stage(P, g, r, dpix, max_allow_frac):
+    """The nine sums against the oracle with NO splat excluded.  The error budget of a splat is 1e-4 of sum|term| (fp32
+    summation) plus what a flipped blend decision can move: for every (pixel, splat) pair within a relative margin m
+    of one of the two discrete thresholds (alpha = 1/255, T = 1e-4) the oracle re-runs the pixel with that decision
+    inverted and adds |term change| to the allowance of every splat blended there (flip9).  The count of
+    out-of-budget splats is reported for m = 0 (no allowance), 1e-5, 1e-4 and 1e-3 and must be ZERO at 1e-4, where
+    the allowance may touch only a small part of the scene (max_allow_frac)."""
+    counts, allow = {}, {}
+    for m in FLIP_MARGINS:
+        og = r.backward(dpix, want_abs=True, flip_margin=m)
+        bad = pixel_stage_outliers(P, g, og, og["flip9"])
+        counts[m] = int(bad.sum())
+        allow[m] = float((og["flip9"].sum(1) > 0).mean())
+        if m == ASSERT_MARGIN:
+            og_assert, bad_assert = og, bad
+    print(f"pixel-stage outliers of {P} splats by flip margin: " + ", ".join(f"{m:g}: {counts[m]} (allowance on {100 * allow[m]:.2f} %)" for m in FLIP_MARGINS))
+    assert counts[ASSERT_MARGIN] == 0, (counts, np.flatnonzero(bad_assert)[:10])
+    assert allow[ASSERT_MARGIN] <= max_allow_frac, allow
+    assert counts[0.0] <= max(3, 0.02 * P), counts   # without any allowance only a handful of splats may be off at all
+    return og_assert
+
+
 @pytest.mark.parametrize("P,M,D,W,H,seed", CASES)
 def test_backward_parity(orc, P, M, D, W, H, seed):
     s, cams, views = make_scene(P, M, seed, W, H, n_cams=2)
@@ -89,27 +133,23 @@ def test_backward_parity(orc, P, M, D, W, H, seed):
     rng = np.random.default_rng(seed)
     dpix = rng.uniform(-1, 1, (3, H, W)).astype(np.float32)
     g = sr.backward(dpix)
-    og = r.backward(dpix, want_abs=True)
-    abs9 = og["abs9"]  # per splat sum|term| of the nine pixel-stage sums
-    # Splats that take part in a (pixel, splat) pair within 1e-3 relative of one of the blend's discrete thresholds
-    # (alpha = 1/255, T = 1e-4) can gain or lose a whole pixel through a 1-ulp exp difference: the oracle flags them
-    # (`splat_margin`, inherited by every splat blended at such a pixel) and they are excluded; every other splat must
-    # meet the bar with no outliers.
-    firm = r.get("splat_margin") > 1e-3
-    assert firm.mean() > (0.9 if P <= 2000 else 0.3)   # very dense scenes put many more splats under every fragile pixel
-    # pixel-stage sums: error budget is relative to sum|term| (fp32 summation), 1e-4 of it
-    idx = {"dL_dcolor": ([0, 1, 2], 3, [0, 1, 2]), "dL_dmean2D": ([3, 4], 3, [0, 1]), "dL_dconic": ([5, 6, 7], 4, [0, 1, 3]),
-           "dL_dopacity": ([8], 1, [0])}
-    for name, (qs, stride, cols) in idx.items():
-        got = g[name].reshape(P, stride)
-        want = og[name].reshape(P, stride)
-        for q, c in zip(qs, cols):
-            tol = 1e-4 * np.maximum(abs9[:, q], 1e-3 * abs9[:, q].max() + 1e-30)
-            bad = (np.abs(got[:, c].astype(np.float64) - want[:, c]) > tol) & firm
-            assert not bad.any(), (name, c, int(bad.sum()))
-    # per-splat chain outputs: 1e-4 relative to the array scale
-    for name, stride in [("dL_dmean3D", 3), ("dL_dcov3D", 6), ("dL_dsh", 3 * M), ("dL_dscale", 3), ("dL_drot", 4)]:
-        assert_close_rel(name, g[name].reshape(P, stride)[firm], og[name].reshape(P, stride)[firm], rtol=1e-4, floor=None, max_bad_frac=0.002)
+    og = check_pixel_stage(P, g, r, dpix, max_allow_frac=0.05)
+    # per-splat chain outputs over ALL splats: 1e-4 relative to the array scale (<= 0.2 % outliers), plus the flip
+    # allowance of the splat's nine sums carried through the chain — which is linear in them, so the oracle evaluates it
+    # on the nine unit inputs and  |d out_k| <= sum_q |A_kq| * flip9_q
+    names = [("dL_dmean3D", 3), ("dL_dcov3D", 6), ("dL_dsh", 3 * M), ("dL_dscale", 3), ("dL_drot", 4)]
+    extra = {n: np.zeros((P, k)) for n, k in names}
+    if og["flip9"].any():
+        for q in range(9):
+            unit = np.zeros((P, 9), np.float32); unit[:, q] = 1.0
+            col = orc.chain(r, unit)
+            for n, k in names:
+                extra[n] += np.abs(col[n].reshape(P, k).astype(np.float64)) * og["flip9"][:, q:q + 1]
+    for name, stride in names:
+        got, want = g[name].reshape(P, stride).astype(np.float64), og[name].reshape(P, stride).astype(np.float64)
+        tol = 1e-4 * np.maximum(np.abs(want), 1e-3 * np.abs(want).max()) + extra[name] + 1e-30
+        bad = np.abs(got - want) > tol
+        assert bad.mean() <= 0.002, (name, int(bad.sum()), bad.size)
     # culled splats: all nine buffers exactly zero (src/Trainer.cu:366-375 + radii>0 guard)
     culled = r.get("radii") <= 0
     if culled.any():
@@ -179,9 +219,9 @@ def test_long_tile_lists_take_the_spill_path(orc, P, longer_than):
     assert (ranges[:, 1] - ranges[:, 0]).max() > longer_than
     dpix = np.ones((3, H, W), np.float32)
     g = sr.backward(dpix)
-    og = r.backward(dpix)
-    # thousands of pairs per pixel: most splats share a pixel with SOME pair on a blend threshold, so the firm-splat
-    # mask of test_backward_parity would leave nothing; a small outlier allowance instead
+    # thousands of pairs per pixel: most pixels hold SOME pair near a blend threshold, so the flip allowance reaches a
+    # large part of this scene (it is still a bound, not an exclusion: every splat is compared)
+    og = check_pixel_stage(P, g, r, dpix, max_allow_frac=1.0)
     assert_close_rel("dL_dopacity", g["dL_dopacity"], og["dL_dopacity"], rtol=1e-4, max_bad_frac=0.005)
 
 

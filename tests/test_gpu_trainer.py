@@ -64,7 +64,10 @@ def _download(tr):
                                               (1500, 1, 3, 128, 96),
                                               (700, 16, 2, 112, 112),
                                               (10000, 1, 4, 512, 512),    # BASELINE cfg2 at full size
-                                              (100000, 16, 8, 1024, 1024)])  # BASELINE cfg3 at full size (the oracle needs ~20 s)
+                                              (100000, 16, 8, 1024, 1024),   # BASELINE cfg3 at full size (the oracle needs ~20 s)
+                                              (100000, 16, 16, 1024, 1024),  # BASELINE cfg4: 32 passes on one GPU
+                                              (1000000, 16, 1, 2048, 2048)])  # BASELINE cfg5 size, one camera (white + black):
+                                                                              # ~1100 entries per tile, long-list sort kernel
 def test_step_sgd_matches_oracle(orc, P, M, n_cams, W, H):
     s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 0x5EED0001)
     proj = gs.Project()
@@ -155,6 +158,85 @@ def test_densify_matches_oracle(orc, room):
         assert np.array_equal(got[k].view(np.uint32), want[k][:n * n2].view(np.uint32)), k
     # the trainer keeps stepping on the re-indexed model
     tr.train(proj, stats=True)
+    tr.close()
+
+
+def _read_adam(tr, P, M):
+    """Adam moments in the oracle's five-array layout [loc 3P | sh 3MP | scale 3P | opac P | rot 4P], and the step count."""
+    L = capi.lib()
+    pm, pv, n, steps = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_int()
+    capi.check(L.gs_trainer_adam_state(tr.handle, C.byref(pm), C.byref(pv), C.byref(n), C.byref(steps)))
+    planes = 11 + 3 * M
+    Pa = n.value // planes
+    out = []
+    for ptr in (pm, pv):
+        buf = np.empty(n.value, np.float32)
+        capi.check(L.gs_memcpy_d2h(buf.ctypes.data_as(C.c_void_p), ptr, n.value * 4))
+        pl = buf.reshape(planes, Pa)[:, :P]
+        out.append(np.concatenate([np.ascontiguousarray(pl[0:3].T).reshape(-1), np.ascontiguousarray(pl[3:3 + 3 * M].T).reshape(-1),
+                                   np.ascontiguousarray(pl[3 + 3 * M:6 + 3 * M].T).reshape(-1), pl[6 + 3 * M].copy(),
+                                   np.ascontiguousarray(pl[7 + 3 * M:11 + 3 * M].T).reshape(-1)]))
+    return out[0], out[1], steps.value
+
+
+def _five(a, n, M):
+    """split a five-array block of n splats into its sections"""
+    return np.split(a, np.cumsum([3 * n, 3 * M * n, 3 * n, n])[:4])
+
+
+@pytest.mark.parametrize("quat", [capi.GS_QUAT_XYZW, capi.GS_QUAT_WXYZ])
+def test_adam_state_survives_densify(orc, quat):
+    """The Adam moments follow their splats through split / clone / prune (twins inherit the parent's moments, the
+    rotation rows follow the quaternion's member permutation) and the step counter keeps running: parameters AND
+    moments equal the oracle's restatement bit for bit right after the densify step and after one more Adam step."""
+    P, M, n_cams, W, H = 1200, 4, 2, 96, 96
+    s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 123)
+    cap = P + 400
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = s["D"]
+    host.capacity = cap
+    tr.model = gs.ModelSplatsDevice(host)
+    proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=1e-3, lrSh=2e-3, lrScale=5e-4, lrOpacity=1e-3, lrRotation=1e-3,
+                      paramDensifyVariance=0.05, paramCullOpacity=0.15, paramSplitSize=0.06, quatLayout=quat)
+    lrs = (proj.lrLocation, proj.lrSh, proj.lrScale, proj.lrOpacity, proj.lrRotation)
+    keys = ["loc", "sh", "scale", "opac", "rot"]
+    want = {k: s[k].copy() for k in keys}
+    m = np.zeros((11 + 3 * M) * P, np.float32)
+    v = np.zeros_like(m)
+    n = P
+    for t in range(1, 5):
+        densify = t == 3
+        st = tr.train(proj, densify=densify, stats=True)
+        assert st.count_before == n
+        g = _read_grads(tr, n, M)
+        orc.apply_adam(want["loc"], want["sh"], want["scale"], want["opac"], want["rot"], g, m, v, t, lrs, proj.paramScaleMax,
+                       proj.adamBeta1, proj.adamBeta2, proj.adamEps, M)
+        if densify:
+            big = {k: np.zeros(cap * w, np.float32) for k, w in zip(keys, (3, 3 * M, 3, 1, 4))}
+            for k in keys:
+                big[k][:want[k].size] = want[k]
+            bm, bv = np.zeros((11 + 3 * M) * cap, np.float32), np.zeros((11 + 3 * M) * cap, np.float32)
+            for src, dst in ((m, bm), (v, bv)):
+                for a, b in zip(_five(src, n, M), _five(dst, cap, M)):
+                    b[:a.size] = a
+            hp = dict(cull_opacity=proj.paramCullOpacity, cull_size=proj.paramCullSize, densify_variance=proj.paramDensifyVariance,
+                      split_size=proj.paramSplitSize, split_distance=proj.paramSplitDistance, split_scale=proj.paramSplitScale,
+                      clone_distance=proj.paramCloneDistance)
+            n2 = orc.densify(big["loc"], big["sh"], big["scale"], big["opac"], big["rot"], n, cap, M, g["var"], g["loc"], hp,
+                             1 if quat == capi.GS_QUAT_XYZW else 0, bm, bv)
+            assert st.count_after == n2 and n2 != n
+            want = {k: big[k][:w * n2].copy() for k, w in zip(keys, (3, 3 * M, 3, 1, 4))}
+            m = np.concatenate([a[:w * n2] for a, w in zip(_five(bm, cap, M), (3, 3 * M, 3, 1, 4))])
+            v = np.concatenate([a[:w * n2] for a, w in zip(_five(bv, cap, M), (3, 3 * M, 3, 1, 4))])
+            n = n2
+        got = _download(tr)
+        assert got["count"] == n
+        for k in keys:
+            assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (t, k)
+        gm, gv, steps = _read_adam(tr, n, M)
+        assert steps == t
+        assert np.array_equal(gm.view(np.uint32), m.view(np.uint32)), t
+        assert np.array_equal(gv.view(np.uint32), v.view(np.uint32)), t
     tr.close()
 
 
