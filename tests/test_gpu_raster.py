@@ -103,24 +103,25 @@ def pixel_stage_outliers(P, g, og, flip9=None):
     return bad
 
 
-def check_pixel_stage(P, g, r, dpix, max_allow_frac):
+def check_pixel_stage(P, g, r, dpix, max_allow_frac, assert_margin=ASSERT_MARGIN):
     """The nine sums against the oracle with NO splat excluded.  The error budget of a splat is 1e-4 of sum|term| (fp32
     summation) plus what a flipped blend decision can move: for every (pixel, splat) pair within a relative margin m
     of one of the two discrete thresholds (alpha = 1/255, T = 1e-4) the oracle re-runs the pixel with that decision
     inverted and adds |term change| to the allowance of every splat blended there (flip9).  The count of
-    out-of-budget splats is reported for m = 0 (no allowance), 1e-5, 1e-4 and 1e-3 and must be ZERO at 1e-4, where
-    the allowance may touch only a small part of the scene (max_allow_frac)."""
+    out-of-budget splats is reported for m = 0 (no allowance), 1e-5, 1e-4 and 1e-3 and must be ZERO at `assert_margin`
+    (1e-4 unless the caller says otherwise), where the allowance may touch only a small part of the scene
+    (max_allow_frac)."""
     counts, allow = {}, {}
     for m in FLIP_MARGINS:
         og = r.backward(dpix, want_abs=True, flip_margin=m)
         bad = pixel_stage_outliers(P, g, og, og["flip9"])
         counts[m] = int(bad.sum())
         allow[m] = float((og["flip9"].sum(1) > 0).mean())
-        if m == ASSERT_MARGIN:
+        if m == assert_margin:
             og_assert, bad_assert = og, bad
     print(f"pixel-stage outliers of {P} splats by flip margin: " + ", ".join(f"{m:g}: {counts[m]} (allowance on {100 * allow[m]:.2f} %)" for m in FLIP_MARGINS))
-    assert counts[ASSERT_MARGIN] == 0, (counts, np.flatnonzero(bad_assert)[:10])
-    assert allow[ASSERT_MARGIN] <= max_allow_frac, allow
+    assert counts[assert_margin] == 0, (counts, np.flatnonzero(bad_assert)[:10])
+    assert allow[assert_margin] <= max_allow_frac, allow
     assert counts[0.0] <= max(3, 0.02 * P), counts   # without any allowance only a handful of splats may be off at all
     return og_assert
 
@@ -221,7 +222,9 @@ def test_long_tile_lists_take_the_spill_path(orc, P, longer_than):
     g = sr.backward(dpix)
     # thousands of pairs per pixel: most pixels hold SOME pair near a blend threshold, so the flip allowance reaches a
     # large part of this scene (it is still a bound, not an exclusion: every splat is compared)
-    og = check_pixel_stage(P, g, r, dpix, max_allow_frac=1.0)
+    # T is a running product of up to `longer_than` factors here: its fp32 rounding error grows to ~n * 2^-24 (5e-4 at
+    # 8192 entries), so the T = 1e-4 decision can flip anywhere within that distance of the threshold: margin 1e-3
+    og = check_pixel_stage(P, g, r, dpix, max_allow_frac=1.0, assert_margin=1e-3)
     assert_close_rel("dL_dopacity", g["dL_dopacity"], og["dL_dopacity"], rtol=1e-4, max_bad_frac=0.005)
 
 

@@ -206,9 +206,10 @@ def test_adam_state_survives_densify(orc, quat):
     n = P
     for t in range(1, 5):
         densify = t == 3
-        st = tr.train(proj, densify=densify, stats=True)
+        tr.accumulate()                       # split API: the gradient buffer is read between accumulate and apply
+        g = _read_grads(tr, n, M)             # (densify re-indexes the model, the buffer then no longer matches it)
+        st = tr.apply(proj, densify=densify, stats=True)
         assert st.count_before == n
-        g = _read_grads(tr, n, M)
         orc.apply_adam(want["loc"], want["sh"], want["scale"], want["opac"], want["rot"], g, m, v, t, lrs, proj.paramScaleMax,
                        proj.adamBeta1, proj.adamBeta2, proj.adamEps, M)
         if densify:
