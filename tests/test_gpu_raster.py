@@ -135,20 +135,23 @@ def test_backward_parity(orc, P, M, D, W, H, seed):
     dpix = rng.uniform(-1, 1, (3, H, W)).astype(np.float32)
     g = sr.backward(dpix)
     og = check_pixel_stage(P, g, r, dpix, max_allow_frac=0.05)
-    # per-splat chain outputs over ALL splats: 1e-4 relative to the array scale (<= 0.2 % outliers), plus the flip
-    # allowance of the splat's nine sums carried through the chain — which is linear in them, so the oracle evaluates it
-    # on the nine unit inputs and  |d out_k| <= sum_q |A_kq| * flip9_q
+    # per-splat chain outputs over ALL splats.  The chain (conic -> cov2D -> cov3D / mean, mean2D -> mean, colour -> SH,
+    # cov3D -> scale / rotation) is LINEAR in the splat's nine pixel-stage sums and the HIP chain repeats the oracle's
+    # fp32 operations one for one, so the budget of an output is the budget of the sums carried through the chain:
+    #     |d out_k| <= sum_q |A_kq| * (1e-4 * sum|term|_q + flip9_q),   A = the chain evaluated on the nine unit inputs
+    # (plus 1e-4 relative to the array scale, the bar the step-level tests use; <= 0.2 % outliers)
     names = [("dL_dmean3D", 3), ("dL_dcov3D", 6), ("dL_dsh", 3 * M), ("dL_dscale", 3), ("dL_drot", 4)]
-    extra = {n: np.zeros((P, k)) for n, k in names}
-    if og["flip9"].any():
-        for q in range(9):
-            unit = np.zeros((P, 9), np.float32); unit[:, q] = 1.0
-            col = orc.chain(r, unit)
-            for n, k in names:
-                extra[n] += np.abs(col[n].reshape(P, k).astype(np.float64)) * og["flip9"][:, q:q + 1]
+    budget = {n: np.zeros((P, k)) for n, k in names}
+    abs9 = og["abs9"]
+    for q in range(9):
+        unit = np.zeros((P, 9), np.float32); unit[:, q] = 1.0
+        col = orc.chain(r, unit)
+        tol_q = 1e-4 * np.maximum(abs9[:, q], 1e-3 * abs9[:, q].max() + 1e-30) + og["flip9"][:, q]
+        for n, k in names:
+            budget[n] += np.abs(col[n].reshape(P, k).astype(np.float64)) * tol_q[:, None]
     for name, stride in names:
         got, want = g[name].reshape(P, stride).astype(np.float64), og[name].reshape(P, stride).astype(np.float64)
-        tol = 1e-4 * np.maximum(np.abs(want), 1e-3 * np.abs(want).max()) + extra[name] + 1e-30
+        tol = 1e-4 * np.maximum(np.abs(want), 1e-3 * np.abs(want).max()) + budget[name] + 1e-30
         bad = np.abs(got - want) > tol
         assert bad.mean() <= 0.002, (name, int(bad.sum()), bad.size)
     # culled splats: all nine buffers exactly zero (src/Trainer.cu:366-375 + radii>0 guard)
