@@ -26,6 +26,7 @@ int option_cull() { return g_opt_cull; }
 static int g_opt_share = 1;
 int option_share_passes() { return g_opt_share; }
 static int g_opt_arena = 0;  // initial binning-arena entries per camera (0 = default max(2^20, 16 P))
+static int g_opt_fuse = 1;   // gs_trainer_step without densify: one backward per camera pair (the step's `var` has no reader)
 static int g_opt_debug_sync = 0;  // wait and check for errors after every stage, like the reference's debug=true rasterizer calls
 
 // grow-only device buffer
@@ -278,6 +279,7 @@ extern "C" int gs_set_option(const char* name, int value) {
     if (!name) return GS_ERR_INVALID_ARGUMENT;
     if (strcmp(name, "cull") == 0) { g_opt_cull = value != 0; return GS_OK; }
     if (strcmp(name, "share_camera_passes") == 0) { g_opt_share = value != 0; return GS_OK; }
+    if (strcmp(name, "fuse_camera_passes") == 0) { g_opt_fuse = value != 0; return GS_OK; }
     if (strcmp(name, "arena_entries") == 0) { g_opt_arena = value > 0 ? value : 0; return GS_OK; }
     if (strcmp(name, "debug_sync") == 0) { g_opt_debug_sync = value != 0; return GS_OK; }
     if (strcmp(name, "scan_single_max") == 0) { gs::g_scan_single_max = value > 0 ? value : (1 << 16); return GS_OK; }
@@ -617,7 +619,7 @@ static int resolve_stats(gs_trainer* t) {
 // gradients in t->grad.  The only host wait is on the arena-overflow flags, which the device publishes right after the
 // projection (a few tens of microseconds into the step, while the rest of the step is already queued behind it): on
 // return the stream is still busy.  An overflowing arena is grown and the iteration replayed.
-static int accumulate_async(gs_trainer* t) {
+static int accumulate_async(gs_trainer* t, bool need_var) {
     if (t->V == 0 && t->total_samples <= 0) { set_error("Can't run training iteration, no truth data available!"); return GS_ERR_NO_TRUTH; }
     if (!t->model) return GS_ERR_NO_MODEL;
     GS_HIP(hipSetDevice(t->device));
@@ -687,12 +689,13 @@ static int accumulate_async(gs_trainer* t) {
         if (P > 0) {  // an empty model has no gradients: its image is the background, its loss the residual against it
             const int* items = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.views) + view_block_items_offset(V));
             prof_stage_begin(t, 5, 4);
-            GS_TRY(launch_render_backward(d, s, items, t->bwd_pairs, t->bwd_singles, t->stream));
+            const bool fuse = !need_var && g_opt_fuse != 0;
+            GS_TRY(launch_render_backward(d, s, items, t->bwd_pairs, t->bwd_singles, fuse, t->stream));
             prof_stage_end(t, 5);
             GS_TRY(debug_check(t, 5));
             prof_stage_begin(t, 6, 5);
             GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), items, t->bwd_pairs,
-                                             t->bwd_singles, t->stream));
+                                             t->bwd_singles, fuse, t->stream));
             prof_stage_end(t, 6);
             GS_TRY(debug_check(t, 6));
         }
@@ -718,7 +721,7 @@ static int accumulate_async(gs_trainer* t) {
 
 extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
     if (!t) return GS_ERR_INVALID_ARGUMENT;
-    GS_TRY(accumulate_async(t));
+    GS_TRY(accumulate_async(t, true));
     GS_TRY(resolve_stats(t));  // callers of the split API read the gradient buffer next: hand it over complete
     if (stats) *stats = t->last;
     return GS_OK;
@@ -821,7 +824,9 @@ extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, g
 
 extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs_step_stats* stats) {
     if (!t || !h) return GS_ERR_INVALID_ARGUMENT;
-    GS_TRY(accumulate_async(t));
+    // `var` (accumulateGradients, src/Trainer.cu:52) is read by the densify block of the same iteration only (:444,453)
+    // and starts from zero every iteration (:304-309): a step without densify does not need per-pass gradients
+    GS_TRY(accumulate_async(t, densify != 0));
     if (t->allreduce) {
         float* buf = nullptr; size_t n = 0;
         GS_TRY(gs_trainer_grad_buffer(t, &buf, &n));
@@ -1151,7 +1156,7 @@ extern "C" int gs_rasterize_backward(int P, int D_in, int M, int R, const float*
     s.dL_dpix = dL_dpix;
     Dims d = make_dims(P, gl.Pa, D, M, width, height, 1, bl.Rcap, scale_modifier);
     hipStream_t st = 0;
-    GS_TRY(launch_render_backward(d, s, reinterpret_cast<const int*>(geom_buffer + gl.view + view_block_items_offset(1)), 0, 1, st));
+    GS_TRY(launch_render_backward(d, s, reinterpret_cast<const int*>(geom_buffer + gl.view + view_block_items_offset(1)), 0, 1, false, st));
     SeamGrads g{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
     GS_TRY(launch_splat_backward_seam(d, reinterpret_cast<const float*>(geom_buffer + gl.planes), s, g, st));
     GS_HIP(hipStreamSynchronize(st));

@@ -140,10 +140,11 @@ int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t st);
 // loss_total[v] = sum over tiles of loss[v][tile], in a fixed order (the statistic is reproducible bit for bit)
 int launch_loss_sum(const Dims& d, const Scratch& s, hipStream_t st);
-int launch_render_backward(const Dims& d, const Scratch& s, const int* items, int n_pairs, int n_singles, hipStream_t st);
-// Trainer form: loops the views, writes the averaged-gradient planes (incl. var) once.
+int launch_render_backward(const Dims& d, const Scratch& s, const int* items, int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st);
+// Trainer form: loops the views, writes the averaged-gradient planes (incl. var) once.  fuse_pairs: the backward left ONE
+// gradient set per pair item (render_bwd_body<1, 2>): the per-splat chain runs once per item and `var` is written as zero.
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad_planes, const int* items,
-                              int n_pairs, int n_singles, hipStream_t st);
+                              int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st);
 // Seam form: one view, reference-shaped AoS outputs with the reference's += / = discipline.
 struct SeamGrads { float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot; };
 int launch_splat_backward_seam(const Dims& d, const float* params, const Scratch& s, const SeamGrads& g, hipStream_t st);

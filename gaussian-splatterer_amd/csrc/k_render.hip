@@ -291,26 +291,40 @@ int launch_debug_reduce9(const float* in, float* out, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-// One workgroup = one tile of one camera, K passes of that camera at once (K = 2: the reference's white- and
+// One workgroup = one tile of one camera, the passes of that camera at once (the reference's white- and
 // black-background pair).  Everything that does not depend on dL/dpixel — pair geometry, exp, alpha, the
-// transmittance recurrence, the accumulated colour behind — is evaluated once and shared; only the dL/dalpha
-// chain, the nine sums and their reduction run per pass.
-template <int K>
+// transmittance recurrence, the accumulated colour behind — is evaluated once and shared.
+//   <K = 2, F = 1>  two gradient sets: the dL/dalpha chain, the nine sums and their reduction run per pass; one
+//                   gradient row per (entry, pass).  Needed when per-pass gradients are: accumulateGradients'
+//                   `var += |g_loc| / S` (src/Trainer.cu:52) takes the norm of every pass's location gradient.
+//   <K = 1, F = 2>  ONE gradient set for the pair.  Every other output of accumulateGradients is a plain sum over the
+//                   passes, and the whole backward is linear in dL/dpixel for a fixed camera, so the two residual
+//                   images are added per pixel (dL/dpixel = r_white + r_black, and T_final * (bg . r) likewise) and
+//                   the pair costs one single-pass backward: one row per (entry, camera), half the reductions.
+//                   `var` is not produced — the trainer takes this form on steps whose `var` nobody reads
+//                   (gs_trainer_step without densify; the reference recomputes var from zero every iteration and
+//                   reads it only inside the densify block, src/Trainer.cu:304-309,444,453).
+//   <K = 1, F = 1>  a single pass (rasterizer seam, cameras with an odd number of passes).
+template <int K, int F>
 __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s, const int* __restrict__ items) {
 #pragma clang fp contract(fast)
+    static_assert(K * F <= 2, "an item carries two passes");
     constexpr int ROUND = (K == 1) ? BWD_ROUND : GS_BWD_ROUND_K2;  // entries staged per round (LDS: ~24 KB either way)
     __shared__ StagedTile<ROUND> st;
     __shared__ uint32_t sSlot[ROUND];
     __shared__ float sAcc[K * 4 * ROUND * ACC_STRIDE];
     __shared__ unsigned long long sTouched[4][(ROUND + 63) / 64];
     __shared__ uint32_t sMaxLast;
-    __shared__ float sLoss[K][4];
+    __shared__ float sLoss[K * F][4];
     const int* item = items + 3 * blockIdx.y;  // {group, pass 0, pass 1}
     const int g = item[0];                     // geometry group: lists, records, T and n_contrib live there
     const int tile = (int)s.tile_order[(size_t)g * d.T + blockIdx.x];
-    int vp[K];
+    int vin[K * F];  // the passes read: gradient set p sums passes vin[p * F .. p * F + F - 1]
+    int vp[K];       // where gradient set p's rows go: the slice of its first pass
 #pragma unroll
-    for (int p = 0; p < K; p++) vp[p] = item[1 + p];
+    for (int q = 0; q < K * F; q++) vin[q] = item[1 + q];
+#pragma unroll
+    for (int p = 0; p < K; p++) vp[p] = vin[p * F];
     if (s.flags[g * 4 + 0] & 1u) return;
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -329,34 +343,35 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
     // per-pixel state
     float T_final = 0.0f;
     uint32_t last_contributor = 0;
-    float dpx[K][3], res2[K], tfbg[K];
+    float dpx[K][3], res2[K * F], tfbg[K];
 #pragma unroll
-    for (int p = 0; p < K; p++) { dpx[p][0] = dpx[p][1] = dpx[p][2] = 0.0f; res2[p] = 0.0f; }
+    for (int p = 0; p < K; p++) { dpx[p][0] = dpx[p][1] = dpx[p][2] = 0.0f; tfbg[p] = 0.0f; }
+#pragma unroll
+    for (int q = 0; q < K * F; q++) res2[q] = 0.0f;
     if (inside) {
         const size_t pix = (size_t)py * d.W + px;
         T_final = s.final_T[(size_t)g * d.N + pix];
         last_contributor = s.n_contrib[(size_t)g * d.N + pix];
 #pragma unroll
-        for (int p = 0; p < K; p++) {
-            const int v = vp[p];
+        for (int q = 0; q < K * F; q++) {
+            const int v = vin[q], p = q / F;
+            float r0, r1, r2;
             if (s.dL_dpix) {
                 const float* gp = s.dL_dpix + (size_t)v * 3 * d.N;
-                dpx[p][0] = gp[pix]; dpx[p][1] = gp[(size_t)d.N + pix]; dpx[p][2] = gp[2 * (size_t)d.N + pix];
+                r0 = gp[pix]; r1 = gp[(size_t)d.N + pix]; r2 = gp[2 * (size_t)d.N + pix];
             } else {
                 // imageIntToLoss, src/Trainer.cu:33-44: truth/255 - rasterized
                 const uint32_t t = s.truth[(size_t)v * d.N + pix];
                 const float* out = s.out_color + (size_t)v * 3 * d.N;
-                dpx[p][0] = ((float)(t & 0xFF) / 255.0f) - out[pix];
-                dpx[p][1] = ((float)((t >> 8) & 0xFF) / 255.0f) - out[(size_t)d.N + pix];
-                dpx[p][2] = ((float)((t >> 16) & 0xFF) / 255.0f) - out[2 * (size_t)d.N + pix];
-                res2[p] = dpx[p][0] * dpx[p][0] + dpx[p][1] * dpx[p][1] + dpx[p][2] * dpx[p][2];
+                r0 = ((float)(t & 0xFF) / 255.0f) - out[pix];
+                r1 = ((float)((t >> 8) & 0xFF) / 255.0f) - out[(size_t)d.N + pix];
+                r2 = ((float)((t >> 16) & 0xFF) / 255.0f) - out[2 * (size_t)d.N + pix];
+                res2[q] = r0 * r0 + r1 * r1 + r2 * r2;
             }
+            const float* bg = s.views[v].bg;
+            dpx[p][0] += r0; dpx[p][1] += r1; dpx[p][2] += r2;
+            tfbg[p] += -T_final * (bg[0] * r0 + bg[1] * r1 + bg[2] * r2);
         }
-    }
-#pragma unroll
-    for (int p = 0; p < K; p++) {
-        const float* bg = s.views[vp[p]].bg;
-        tfbg[p] = -T_final * (bg[0] * dpx[p][0] + bg[1] * dpx[p][1] + bg[2] * dpx[p][2]);
     }
     if (tid == 0) sMaxLast = 0;
     __syncthreads();
@@ -367,15 +382,15 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
     if (lane == 0) atomicMax(&sMaxLast, wave_max_last);
     if (s.loss && !s.dL_dpix) {
 #pragma unroll
-        for (int p = 0; p < K; p++) {
-            const float l = wave_sum_to_lane63(res2[p]);
-            if (lane == 63) sLoss[p][wave] = l;
+        for (int q = 0; q < K * F; q++) {
+            const float l = wave_sum_to_lane63(res2[q]);
+            if (lane == 63) sLoss[q][wave] = l;
         }
     }
     __syncthreads();
     const int max_last = (int)sMaxLast;
-    if (s.loss && !s.dL_dpix && tid < K)  // fixed summation order: the loss statistic is reproducible too
-        s.loss[(size_t)vp[tid] * d.T + tile] = (sLoss[tid][0] + sLoss[tid][1]) + (sLoss[tid][2] + sLoss[tid][3]);
+    if (s.loss && !s.dL_dpix && tid < K * F)  // fixed summation order: the loss statistic is reproducible too
+        s.loss[(size_t)vin[tid] * d.T + tile] = (sLoss[tid][0] + sLoss[tid][1]) + (sLoss[tid][2] + sLoss[tid][3]);
     if (n == 0) return;
     const int rounds = (max_last + ROUND - 1) / ROUND;
     // entries no pixel reaches still own a gradient row per pass: zero it
@@ -468,17 +483,10 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
 #pragma unroll
                     for (int p = 0; p < K; p++) {
                         const float ux = u[p] * dx, uy = u[p] * dy;
-#if defined(GS_EXP_NO_REDUCE)     // experiment (WRONG results): what the kernel costs without the cross-lane reduction
-                        float red = ((dchannel_dcolor * dpx[p][0] + dchannel_dcolor * dpx[p][1]) + (dchannel_dcolor * dpx[p][2] + ux)) +
-                                    ((uy + ux * dx) + (ux * dy + uy * dy)) + u[p];
-#elif defined(GS_EXP_NO_MOMENTS)  // experiment (WRONG results): neither moments nor reduction, only the two LDS-side values
-                        float red = dchannel_dcolor + u[p];
-#else
                         float red = wave_reduce_scatter9_rows(dchannel_dcolor * dpx[p][0], dchannel_dcolor * dpx[p][1],
                                                               dchannel_dcolor * dpx[p][2], ux, uy, ux * dx, ux * dy, uy * dy, u[p]);
                         red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold16, __builtin_bit_cast(int, red)));
                         red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold32, __builtin_bit_cast(int, red)));
-#endif
                         if (writer) acc_lane[jj * ACC_STRIDE + p * (4 * ROUND * ACC_STRIDE)] = red;  // lane-constant base + scalar offset
                     }
                     touched[sb] |= 1ull << kk;
@@ -548,16 +556,21 @@ int launch_loss_sum(const Dims& d, const Scratch& s, hipStream_t stream) {
 // VGPRs, 21.8 KB LDS; measured 3 % faster than the 6 the compiler picks by itself), the one-pass form is bounded by
 // its 25 KB of LDS at 6.
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_render_bwd2(Dims d, Scratch s, const int* __restrict__ items) {
-    render_bwd_body<2>(d, s, items);
+    render_bwd_body<2, 1>(d, s, items);
 }
 __global__ __launch_bounds__(WG) void k_render_bwd1(Dims d, Scratch s, const int* __restrict__ items) {
-    render_bwd_body<1>(d, s, items);
+    render_bwd_body<1, 1>(d, s, items);
+}
+__global__ __launch_bounds__(WG) void k_render_bwd_pair(Dims d, Scratch s, const int* __restrict__ items) {
+    render_bwd_body<1, 2>(d, s, items);
 }
 
-// items: n2 pairs {group, pass a, pass b} followed by n1 singles {group, pass, -1} (device array of 3*(n2+n1) ints)
-int launch_render_backward(const Dims& d, const Scratch& s, const int* items, int n2, int n1, hipStream_t stream) {
+// items: n2 pairs {group, pass a, pass b} followed by n1 singles {group, pass, -1} (device array of 3*(n2+n1) ints).
+// fuse_pairs: one gradient set per pair (rows in pass a's slice of G) instead of one per pass.
+int launch_render_backward(const Dims& d, const Scratch& s, const int* items, int n2, int n1, bool fuse_pairs, hipStream_t stream) {
     if (d.T == 0) return GS_OK;
-    if (n2 > 0) hipLaunchKernelGGL(k_render_bwd2, dim3(d.T, n2), dim3(WG), 0, stream, d, s, items);
+    if (n2 > 0 && fuse_pairs) hipLaunchKernelGGL(k_render_bwd_pair, dim3(d.T, n2), dim3(WG), 0, stream, d, s, items);
+    if (n2 > 0 && !fuse_pairs) hipLaunchKernelGGL(k_render_bwd2, dim3(d.T, n2), dim3(WG), 0, stream, d, s, items);
     if (n1 > 0) hipLaunchKernelGGL(k_render_bwd1, dim3(d.T, n1), dim3(WG), 0, stream, d, s, items + 3 * n2);
     GS_HIP(hipGetLastError());
     return GS_OK;

@@ -236,16 +236,17 @@ template <int D> __device__ inline void sh_basis(float X, float Y, float Z, floa
 // runs the per-splat chain; the result is ONE 64-byte record per (pass, splat):
 //   mean(3) scale(3) rot(4) opacity(1) dL_dRGB(3, clamp-masked) pad(2).   Culled splats write zeros.
 // (Fusing the two passes of a camera into one thread was measured slower: 175 VGPRs, 2 waves/SIMD.)
-// Work items are the backward's {group, pass a, pass b}.
+// Work items are the backward's {group, pass a, pass b}.  With fused pairs (render_bwd_body<1, 2>) there is one
+// gradient set per item, in pass a's slice: blockIdx.y then enumerates items and the record is pass a's.
 template <int D>
 __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __restrict__ params, Scratch s, float4* __restrict__ rec_out,
-                                                       const int* __restrict__ items, int n_pairs) {
+                                                       const int* __restrict__ items, int n_pairs, int fused) {
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
     // blockIdx.y enumerates passes: the two passes of every pair item first, then the single items
     const int y = blockIdx.y;
-    const int which = y < 2 * n_pairs ? (y & 1) : 0;
-    const int* item = items + 3 * (y < 2 * n_pairs ? (y >> 1) : (y - n_pairs));
+    const int which = (!fused && y < 2 * n_pairs) ? (y & 1) : 0;
+    const int* item = items + 3 * (fused ? y : (y < 2 * n_pairs ? (y >> 1) : (y - n_pairs)));
     const int g = item[0];          // geometry group: records and slots live there
     const int v = item[1 + which];  // pass: gradient rows and the output record
     const Planes pl{ d.M };
@@ -285,9 +286,12 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
 // Trainer stage 2: one thread per splat walks the views in the reference's order and applies
 // accumulateGradients (src/Trainer.cu:51-76: var += |g_loc| / S, avg += g / S); the SH gradient is rebuilt as
 // basis(view direction) x dL_dRGB.  Every gradient plane is written exactly once per step.
+// n_fused_items > 0: the records are one per work item (the pair's summed gradient, at the item's first pass) and
+// `var`, which needs every pass's own location gradient, is written as zero (see render_bwd_body).
 template <int D>
 __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __restrict__ params, Scratch s, float samples,
-                                                         const float4* __restrict__ rec_in, float* __restrict__ grad) {
+                                                         const float4* __restrict__ rec_in, float* __restrict__ grad,
+                                                         const int* __restrict__ items, int n_fused_items) {
     constexpr int NC = (D + 1) * (D + 1);
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
@@ -297,7 +301,9 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __
     float var = 0.0f, aLoc[3] = { 0, 0, 0 }, aScale[3] = { 0, 0, 0 }, aRot[4] = { 0, 0, 0, 0 }, aOpac = 0.0f, aSh[NC][3];
 #pragma unroll
     for (int k = 0; k < NC; k++) aSh[k][0] = aSh[k][1] = aSh[k][2] = 0.0f;
-    for (int v = 0; v < d.V; v++) {
+    const int n_rec = n_fused_items > 0 ? n_fused_items : d.V;
+    for (int k = 0; k < n_rec; k++) {
+        const int v = n_fused_items > 0 ? items[3 * k + 1] : k;
         const float4* r = rec_in + ((size_t)v * st + i) * 4;
         const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
         const float gm[3] = { r0.x, r0.y, r0.z }, gs3[3] = { r0.w, r1.x, r1.y }, gr[4] = { r1.z, r1.w, r2.x, r2.y };
@@ -334,26 +340,29 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __
     grad[pl.opac() * st + i] = aOpac;
 #pragma unroll
     for (int c = 0; c < 4; c++) grad[pl.rot(c) * st + i] = aRot[c];
-    grad[pl.var() * st + i] = var;
+    grad[pl.var() * st + i] = n_fused_items > 0 ? 0.0f : var;
 }
 
 template <int D>
 static void launch_splat_avg_d(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, const int* items, int n2,
-                               int n1, hipStream_t stream) {
+                               int n1, bool fuse, hipStream_t stream) {
     const int bx = (d.P + WG - 1) / WG;
     float4* rec = reinterpret_cast<float4*>(s.splat_grads);
-    if (2 * n2 + n1 > 0) hipLaunchKernelGGL(k_splat_bwd_view<D>, dim3(bx, 2 * n2 + n1), dim3(WG), 0, stream, d, params, s, rec, items, n2);
-    hipLaunchKernelGGL(k_splat_bwd_reduce<D>, dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad);
+    fuse = fuse && n2 > 0;
+    const int ny = fuse ? n2 + n1 : 2 * n2 + n1;
+    if (ny > 0) hipLaunchKernelGGL(k_splat_bwd_view<D>, dim3(bx, ny), dim3(WG), 0, stream, d, params, s, rec, items, n2, fuse ? 1 : 0);
+    hipLaunchKernelGGL(k_splat_bwd_reduce<D>, dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
+                       fuse ? n2 + n1 : 0);
 }
 
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, const int* items,
-                              int n_pairs, int n_singles, hipStream_t stream) {
+                              int n_pairs, int n_singles, bool fuse_pairs, hipStream_t stream) {
     if (d.P == 0) return GS_OK;
     switch (d.D) {
-        case 0: launch_splat_avg_d<0>(d, params, s, samples, grad, items, n_pairs, n_singles, stream); break;
-        case 1: launch_splat_avg_d<1>(d, params, s, samples, grad, items, n_pairs, n_singles, stream); break;
-        case 2: launch_splat_avg_d<2>(d, params, s, samples, grad, items, n_pairs, n_singles, stream); break;
-        default: launch_splat_avg_d<3>(d, params, s, samples, grad, items, n_pairs, n_singles, stream); break;
+        case 0: launch_splat_avg_d<0>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, stream); break;
+        case 1: launch_splat_avg_d<1>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, stream); break;
+        case 2: launch_splat_avg_d<2>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, stream); break;
+        default: launch_splat_avg_d<3>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, stream); break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

@@ -62,6 +62,11 @@ int gs_device_count(void);
  * "share_camera_passes" (default 1; read by gs_trainer_set_views): passes whose camera parameters are bit-identical
  * (the reference's white/black pair per camera, src/Trainer.cu:311-318) share projection, tile lists and the
  * forward blend; 0 recomputes them per pass like the reference.  Results are bit-identical either way.
+ * "fuse_camera_passes" (default 1): gs_trainer_step WITHOUT densify runs ONE backward per camera on the sum of its
+ * passes' residual images instead of one per pass (the backward is linear in dL/dpixel for a fixed camera).  All
+ * averaged gradients are the same sums (re-associated: agreement ~1e-7); only `var`, which needs every pass's own
+ * location gradient (src/Trainer.cu:52) and is read by the densify block alone (:444,453), is then not produced (its
+ * plane of the gradient buffer is zero).  gs_trainer_accumulate and densify steps always take the per-pass form.
  * "arena_entries" (default 0 = max(2^20, 16*P)): initial capacity, in (splat, tile) entries per camera, of the binning
  * arena of trainers created afterwards; when a step needs more the arena grows and the step is replayed.
  * "debug_sync" (default 0): wait and check for device errors after every stage of a step, as the reference's
@@ -180,7 +185,8 @@ int gs_trainer_set_views(gs_trainer* trainer, int n_views, const gs_view* views,
  * backward, gradient averaging), the collective hook if one is installed, the parameter update,
  * and densify/prune when `densify` != 0.  The caller increments its own Project::iterations
  * (src/Trainer.cu:255).  Synchronises with the device once (arena check) and fully when
- * densify != 0 or stats != NULL. */
+ * densify != 0 or stats != NULL.  With densify == 0 the `var` plane of the gradient buffer is not produced
+ * (option "fuse_camera_passes"); the model after the step is what the reference's step leaves. */
 int gs_trainer_step(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs_step_stats* stats);
 
 /* The same step split at the point where data-parallel ranks exchange gradients:

@@ -41,7 +41,7 @@ def test_cfg1_matches_golden(orc):
     tr = gs.Trainer(W, H)
     tr.model = gs.ModelSplatsDevice(host)
     tr.captureTruths(gs.camera.get_cameras(1), truths[:1], truths[1:])
-    tr.train(gs.Project(), stats=True)
+    tr.accumulate()   # the per-pass form: produces `var` too (a step without densify fuses the camera's two passes)
     from test_gpu_trainer import _read_grads
     g = _read_grads(tr, P, M)
     for k in ("var", "loc", "sh", "scale", "opac", "rot"):

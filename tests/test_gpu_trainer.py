@@ -71,15 +71,18 @@ def _download(tr):
 def test_step_sgd_matches_oracle(orc, P, M, n_cams, W, H):
     s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 0x5EED0001)
     proj = gs.Project()
-    st = tr.train(proj, densify=False, stats=True)
-    assert proj.iterations == 1 and st.views == 2 * n_cams and st.count_after == P
     views = gs.camera.train_views(cams, W, H)
     truths = np.concatenate(fw + fb)
     o = orc.train_views(P, s["D"], M, W, H, s["loc"], s["sh"], s["scale"], s["opac"], s["rot"], views, truths, 2.0 * n_cams)
-    assert st.num_rendered == int(o["num_rendered"].sum())
+    # (1) the per-pass form (gs_trainer_accumulate / _apply; also what a densify step runs): every output of
+    #     accumulateGradients, `var` included
+    st = tr.accumulate(stats=True)
+    assert st.views == 2 * n_cams and st.num_rendered == int(o["num_rendered"].sum())
     g = _read_grads(tr, P, M)
     for k in ["loc", "sh", "scale", "opac", "rot", "var"]:
         assert_close_rel("avg_" + k, g[k], o[k], rtol=1e-4, max_bad_frac=0.002)
+    st = tr.apply(proj, stats=True)
+    assert proj.iterations == 1 and st.count_after == P
     # the update itself is bit-exact: applyGradients on the GPU's own averaged gradients
     want = {k: s[k].copy() for k in ["loc", "sh", "scale", "opac", "rot"]}
     orc.apply_sgd(want["loc"], want["sh"], want["scale"], want["opac"], want["rot"], g,
@@ -87,7 +90,49 @@ def test_step_sgd_matches_oracle(orc, P, M, n_cams, W, H):
     got = _download(tr)
     for k in want:
         assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+    # (2) Trainer::train without densify (gs_trainer_step): one backward per camera on the summed residuals of its two
+    #     passes.  Same bar against the oracle for every averaged gradient; `var` has no reader on such a step and is zero.
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = s["D"]
+    tr.model = gs.ModelSplatsDevice(host)
+    st = tr.train(proj, densify=False, stats=True)
+    assert proj.iterations == 2 and st.views == 2 * n_cams and st.num_rendered == int(o["num_rendered"].sum())
+    gf = _read_grads(tr, P, M)
+    for k in ["loc", "sh", "scale", "opac", "rot"]:
+        assert_close_rel("avg_" + k + " (fused pair)", gf[k], o[k], rtol=1e-4, max_bad_frac=0.002)
+        assert_close_rel("fused vs per-pass " + k, gf[k], g[k], rtol=2e-5, max_bad_frac=0.002)   # the same sums, re-associated
+    assert not gf["var"].any()
+    want = {k: s[k].copy() for k in ["loc", "sh", "scale", "opac", "rot"]}
+    orc.apply_sgd(want["loc"], want["sh"], want["scale"], want["opac"], want["rot"], gf,
+                  (proj.lrLocation, proj.lrSh, proj.lrScale, proj.lrOpacity, proj.lrRotation), proj.paramScaleMax, M)
+    got = _download(tr)
+    for k in want:
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
     tr.close()
+
+
+def test_fused_pair_switch(orc):
+    """gs_set_option("fuse_camera_passes", 0) makes gs_trainer_step take the per-pass form on every step: its gradient
+    buffer then equals gs_trainer_accumulate's bit for bit (var included), and the loss statistic is the same either way."""
+    P, M, n_cams, W, H = 1500, 4, 3, 128, 96
+    res = []
+    for fuse in (1, 0):
+        capi.check(capi.lib().gs_set_option(b"fuse_camera_passes", fuse))
+        try:
+            s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 4242)
+            st = tr.train(gs.Project(), stats=True)
+            res.append((st.num_rendered, st.loss, _read_grads(tr, P, M)))
+            tr.close()
+        finally:
+            capi.check(capi.lib().gs_set_option(b"fuse_camera_passes", 1))
+    s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 4242)
+    tr.accumulate()
+    ga = _read_grads(tr, P, M)
+    tr.close()
+    assert res[0][:2] == res[1][:2]
+    for k in ga:
+        assert np.array_equal(res[1][2][k].view(np.uint32), ga[k].view(np.uint32)), k
+    assert res[1][2]["var"].any() and not res[0][2]["var"].any()
 
 
 def test_step_adam_matches_oracle(orc):
@@ -299,7 +344,7 @@ def test_camera_pass_sharing_is_bit_identical(orc):
         capi.check(capi.lib().gs_set_option(b"share_camera_passes", share))
         try:
             s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 4242)
-            st = tr.train(gs.Project(), stats=True)
+            st = tr.accumulate(stats=True)   # the per-pass form (without sharing there are no pairs a step could fuse)
             g = _read_grads(tr, P, M)
             imgs = [tr.read_image(v) for v in range(2 * n_cams)]
             res.append((st.num_rendered, st.loss, g, imgs))
