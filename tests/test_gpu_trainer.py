@@ -100,7 +100,7 @@ def test_step_sgd_matches_oracle(orc, P, M, n_cams, W, H):
     gf = _read_grads(tr, P, M)
     for k in ["loc", "sh", "scale", "opac", "rot"]:
         assert_close_rel("avg_" + k + " (fused pair)", gf[k], o[k], rtol=1e-4, max_bad_frac=0.002)
-        assert_close_rel("fused vs per-pass " + k, gf[k], g[k], rtol=2e-5, max_bad_frac=0.002)   # the same sums, re-associated
+        assert_close_rel("fused vs per-pass " + k, gf[k], g[k], rtol=1e-4, max_bad_frac=0.002)   # the same sums, re-associated
     assert not gf["var"].any()
     want = {k: s[k].copy() for k in ["loc", "sh", "scale", "opac", "rot"]}
     orc.apply_sgd(want["loc"], want["sh"], want["scale"], want["opac"], want["rot"], gf,
