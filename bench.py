@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
+N_SIMD = 256 * 4       # 256 CUs x 4 SIMD-32
+CLOCK_GHZ = 2.4        # max shader clock; a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
 
 WORKLOAD_TEXT = {
     1: "cfg1: 1k random-init splats, 1 camera x (white,black) @256x256, SH degree 1 (M=4)",
@@ -63,7 +65,7 @@ def stage_bytes(stage, P, M, N, R, V):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (default 3 = the metric's config)")
     ap.add_argument("--update", choices=["adam", "sgd"], default="adam")
@@ -218,14 +220,36 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         step_bytes = sum(stage_bytes(k, P, M, N, R_mean, V_local) for k in kern) + (48 + 12 * M) * P
         ms_per_step = elapsed / args.steps * 1e3
-        traffic = None
-        try:  # HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (same command, separate runs)
+        # Counters of the dominant kernel (rocprofv3 --pmc passes of the same command, tools/pmc_pass.sh, committed as
+        # profiles/pmc_latest.json).  They are only reported when they were collected from the kernel sources this run
+        # uses (source stamp) and for the metric's own configuration; otherwise null.
+        traffic = valu = None
+        pmc_note = "profiles/pmc_latest.json missing"
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from source_stamp import source_stamp
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            stamp_ok = pmc.get("_stamp", {}).get("source_sha256") == source_stamp()
             k = pmc.get(dom)
-            if k and args.config == 3 and not args.views and world == 1:
-                traffic = k["fetch_bytes_x2"] + k["write_bytes"]
-        except Exception:
-            traffic = None
+            if not stamp_ok:
+                pmc_note = "profiles/pmc_latest.json was collected from other kernel sources (stamp mismatch): counters not reported"
+            elif not (k and args.config == 3 and not args.views and world == 1):
+                pmc_note = "counters are collected for the metric's configuration on one GPU only"
+            else:
+                pmc_note = "rocprofv3 --pmc, separate passes, same sources (stamp matches), largest dispatch of the kernel"
+                if "fetch_bytes_x2" in k and "write_bytes" in k:
+                    traffic = k["fetch_bytes_x2"] + k["write_bytes"]
+                if "SQ_INSTS_VALU" in k:
+                    # VALU issue roofline: every wave64 VALU instruction holds its SIMD-32 for 2 cycles
+                    insts = k["SQ_INSTS_VALU"]
+                    per_simd_cycle = insts / N_SIMD / (dom_ms * 1e-3 * CLOCK_GHZ * 1e9)
+                    valu = {"wave_instructions": insts, "per_simd_per_cycle": per_simd_cycle, "peak_per_simd_per_cycle": 0.5,
+                            "frac": per_simd_cycle / 0.5, "clock_ghz_assumed": CLOCK_GHZ,
+                            "note": "SQ_INSTS_VALU of the launch / 1024 SIMDs / (measured launch time x max clock) against one instruction per 2 cycles"}
+        except Exception as e:  # noqa: BLE001
+            pmc_note = f"profiles/pmc_latest.json unusable: {e!r}"
+        hbm_frac = achieved / HBM_PEAK_GBS
+        bound = "valu" if (valu and valu["frac"] > hbm_frac) else "hbm"
         out = {
             "metric": "train steps/sec (fwd+bwd+Adam), 100k splats x 16 views @1024^2, 1->8 GPU" if args.config == 3 else
                       f"train steps/sec (fwd+bwd+update), BASELINE config {args.config}",
@@ -247,9 +271,13 @@ def main():
                        "replicas_identical_after_run": replicas_identical,
                        "mean_num_rendered_per_view": R_mean, "max_tile_list": st.max_tile_list,
                        "camera_pass_sharing": "on (default): the white/black passes of a camera share projection, tile lists and "
-                                              "the forward blend and run one fused backward; bit-identical to per-pass recomputation"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                              "the forward blend; a step without densify runs ONE backward per camera on the sum of the "
+                                              "two residual images (the backward is linear in dL/dpixel; only accumulateGradients' `var`, "
+                                              "read by the densify block alone, needs per-pass gradients and is produced on densify steps)"},
+            "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": hbm_frac, "traffic": traffic, "valu": valu, "counters": pmc_note,
+                         "bound_note": "achieved/peak/frac are the HBM roofline of the dominant kernel (algorithmic bytes / measured time); "
+                                       "`valu` is its vector-issue roofline; `bound` names the larger fraction (no dense contraction here: MFMA is not used)",
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms, "measured": dom_src,
                          "step_algorithmic_GB": step_bytes / 1e9,
                          "step_achieved_GBs": step_bytes / (ms_per_step * 1e-3) / 1e9,

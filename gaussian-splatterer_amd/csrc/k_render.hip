@@ -28,6 +28,12 @@ constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_STOP = 0.0001f;
 constexpr int ACC_STRIDE = 9;
 constexpr int BWD_ROUND = 128;  // entries staged per backward round
+#ifndef GS_BWD_ROUND_PAIR
+#define GS_BWD_ROUND_PAIR 64  // fused-pair kernel (tuning hook): 64 entries, 12.6 KB LDS and 64 VGPRs -> 8 waves per SIMD
+#endif                        // measured 0.903 ms per 16-view launch against 0.938 at 128 entries / 6 waves
+#ifndef GS_BWD_PAIR_WAVES
+#define GS_BWD_PAIR_WAVES 8
+#endif
 #ifndef GS_BWD_ROUND_K2
 #define GS_BWD_ROUND_K2 (BWD_ROUND / 2)  // tuning hook (tools/build_variant.sh)
 #endif
@@ -309,7 +315,7 @@ template <int K, int F>
 __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s, const int* __restrict__ items) {
 #pragma clang fp contract(fast)
     static_assert(K * F <= 2, "an item carries two passes");
-    constexpr int ROUND = (K == 1) ? BWD_ROUND : GS_BWD_ROUND_K2;  // entries staged per round (LDS: ~24 KB either way)
+    constexpr int ROUND = (K == 2) ? GS_BWD_ROUND_K2 : (F == 2 ? GS_BWD_ROUND_PAIR : BWD_ROUND);  // entries staged per round
     __shared__ StagedTile<ROUND> st;
     __shared__ uint32_t sSlot[ROUND];
     __shared__ float sAcc[K * 4 * ROUND * ACC_STRIDE];
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 __global__ __launch_bounds__(WG) void k_render_bwd1(Dims d, Scratch s, const int* __restrict__ items) {
     render_bwd_body<1, 1>(d, s, items);
 }
-__global__ __launch_bounds__(WG) void k_render_bwd_pair(Dims d, Scratch s, const int* __restrict__ items) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GS_BWD_PAIR_WAVES, GS_BWD_PAIR_WAVES))) void k_render_bwd_pair(Dims d, Scratch s, const int* __restrict__ items) {
     render_bwd_body<1, 2>(d, s, items);
 }
 

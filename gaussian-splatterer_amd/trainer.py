@@ -111,10 +111,12 @@ class Trainer:
         capi.check(capi.lib().gs_trainer_set_model(self.handle, device_model.handle))
         device_model.release()
 
-    def captureTruths(self, cameras, framesW, framesB):
+    def captureTruths(self, cameras, framesW, framesB, view_blocks=None):
         """Replaces Trainer::captureTruths (src/Trainer.cu:218-250): the caller supplies, per camera, the
-        white- and black-background RGBA8 truth images (width*height uint32 each)."""
+        white- and black-background RGBA8 truth images (width*height uint32 each).  view_blocks (optional,
+        float32[2C, 40]): the pass parameters to use instead of deriving them from the cameras (C white, then C black)."""
         assert len(cameras) == len(framesW) == len(framesB)
+        self._view_blocks = None if view_blocks is None else np.ascontiguousarray(view_blocks, np.float32).reshape(2 * len(cameras), 40)
         self.truthCameras = list(cameras)
         self.truthFrameBuffersW = [np.ascontiguousarray(f, np.uint32).reshape(-1) for f in framesW]
         self.truthFrameBuffersB = [np.ascontiguousarray(f, np.uint32).reshape(-1) for f in framesB]
@@ -128,6 +130,8 @@ class Trainer:
     def _upload_views(self):
         Cn = len(self.truthCameras)
         blocks = cam.train_views(self.truthCameras, self.width, self.height) if Cn else np.zeros((0, 40), np.float32)
+        if Cn and getattr(self, "_view_blocks", None) is not None:
+            blocks = self._view_blocks
         total = 2 * Cn
         from .dist import shard_views
         mine = shard_views(total, self._rank, self._world)

@@ -5,15 +5,24 @@
 //     ModelSplatsDevice  src/ModelSplatsDevice.h:5-30, src/ModelSplatsDevice.cpp:6-48
 //     Trainer            src/Trainer.cuh:10-75,       src/Trainer.cu:103-543
 //
+// plus the two small value types the Trainer's signatures use:
+//     Camera             src/Camera.h:9-26,  getView / getProjection src/Camera.cpp:79-86
+//     Project            src/Project.h:6-75  (run-time hyper-parameters; any type with the same field names works)
+//
 // Same public members, same argument meaning, same error behaviour (std::runtime_error with the
-// reference's messages).  Differences a maintainer has to know (INTEGRATION.md has the diff):
+// reference's messages).  The reference's call sites compile unchanged:
+//     delete trainer->model; trainer->model = new ModelSplatsDevice(host);      (src/ui/UiFrame.cpp:157-158)
+//     trainer->train(project, densify);                                          (src/ui/UiFrame.cpp:288)
+//     trainer->render(fb, w, h, project.previewSplatScale, camera);              (src/ui/UiPanelViewOutput.cpp:52-60)
+//     trainer->truthCameras.size()                                               (src/ui/UiPanelViewInput.cpp:39)
+// Differences a maintainer has to know (INTEGRATION.md has the diff):
 //   * glm types in signatures are replaced by plain float arrays (this header has no dependencies);
 //   * ModelSplatsDevice owns an opaque gs_model* instead of five raw device pointers — device data
 //     is SoA inside the library; host code reaches it through ModelSplatsHost(const ModelSplatsDevice&);
 //   * Trainer::captureTruths takes the truth images as input (the OptiX renderer is out of scope);
-//   * Trainer::train takes the hyper-parameters as a gs_hyper (Project's fields, src/Project.h:26-41)
-//     and returns the statistics; the caller increments Project::iterations (src/Trainer.cu:255).
+//   * truthFrameBuffersW/B hold host copies of the truth images (the reference keeps device pointers).
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -137,14 +146,94 @@ inline ModelSplatsHost::ModelSplatsHost(const ModelSplatsDevice& device) : Model
     check(gs_model_download(device.handle, locations, shs, scales, opacities, rotations));
 }
 
+// src/Camera.h:9-26.  Matrices come out as glm column-major float[16] (m[col * 4 + row]).
+class Camera {
+public:
+    float location[3];
+    float target[3];
+    float fovDegY;
+
+    Camera(const float locationArg[3], const float targetArg[3], float fovDegYArg) : fovDegY(fovDegYArg) {
+        for (int k = 0; k < 3; k++) { location[k] = locationArg[k]; target[k] = targetArg[k]; }
+    }
+    Camera(float lx, float ly, float lz, float tx, float ty, float tz, float fovDegYArg) : location{ lx, ly, lz }, target{ tx, ty, tz }, fovDegY(fovDegYArg) {}
+
+    // -glm::lookAt(location, target, +Y), src/Camera.cpp:79-82 (every entry negated: view-space +z is forward)
+    void getView(float out[16]) const {
+        const float up[3] = { 0.0f, 1.0f, 0.0f };
+        float f[3], s[3], u[3];
+        for (int k = 0; k < 3; k++) f[k] = target[k] - location[k];
+        unit(f);
+        cross(f, up, s);
+        unit(s);
+        cross(s, f, u);
+        const float m[16] = { s[0], u[0], -f[0], 0.0f, s[1], u[1], -f[1], 0.0f, s[2], u[2], -f[2], 0.0f,
+                              -dot(s, location), -dot(u, location), dot(f, location), 1.0f };
+        for (int k = 0; k < 16; k++) out[k] = -m[k];
+    }
+    // glm::perspective(radians(fovDegY), aspect, 0.1, 100), src/Camera.cpp:84-86
+    void getProjection(float aspect, float out[16]) const {
+        const float fovy = fovDegY * 0.01745329251994329576923690768489f, zNear = 0.1f, zFar = 100.0f;
+        const float t = std::tan(fovy / 2.0f);
+        for (int k = 0; k < 16; k++) out[k] = 0.0f;
+        out[0] = 1.0f / (aspect * t);
+        out[5] = 1.0f / t;
+        out[10] = -(zFar + zNear) / (zFar - zNear);
+        out[11] = -1.0f;
+        out[14] = -(2.0f * zFar * zNear) / (zFar - zNear);
+    }
+    // One pass of this camera as the trainer passes it to the rasterizer (src/Trainer.cu:317-326, :355-356): view,
+    // projection * view, camera position, tan(fov / 2) on both axes, background.
+    gs_view pass(int width, int height, float background) const {
+        gs_view v{};
+        float proj[16];
+        getView(v.view);
+        getProjection((float)width / (float)height, proj);
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 4; r++)
+                v.projview[c * 4 + r] = proj[0 * 4 + r] * v.view[c * 4 + 0] + proj[1 * 4 + r] * v.view[c * 4 + 1] +
+                                        proj[2 * 4 + r] * v.view[c * 4 + 2] + proj[3 * 4 + r] * v.view[c * 4 + 3];
+        for (int k = 0; k < 3; k++) { v.campos[k] = location[k]; v.bg[k] = background; }
+        v.tan_fovx = v.tan_fovy = std::tan(fovDegY * 0.01745329251994329576923690768489f * 0.5f);
+        return v;
+    }
+
+private:
+    static float dot(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+    static void cross(const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - b[1] * a[2]; o[1] = a[2] * b[0] - b[2] * a[0]; o[2] = a[0] * b[1] - b[0] * a[1];
+    }
+    static void unit(float v[3]) { const float inv = 1.0f / std::sqrt(dot(v, v)); for (int k = 0; k < 3; k++) v[k] *= inv; }
+};
+
+// The run-time hyper-parameters of src/Project.h:24-45 under the reference's names and defaults (the GUI / JSON
+// fields of the reference's Project are not needed by this path).  Trainer::train is a template over the project
+// type, so the reference's own Project class works unchanged.
+struct Project {
+    float lrLocation = 0.00005f, lrSh = 0.0001f, lrScale = 0.00002f, lrOpacity = 0.0001f, lrRotation = 0.000025f;
+    float paramScaleMax = 0.3f;
+    float paramCullOpacity = 0.005f, paramCullSize = 0.004f, paramDensifyVariance = 2.0f;
+    float paramSplitSize = 0.04f, paramSplitDistance = 1.5f, paramSplitScale = 0.8f, paramCloneDistance = 1.6f;
+    int iterations = 0;
+    int intervalCapture = 50;
+    int intervalDensify = 200;
+    float previewSplatScale = 1.0f;
+};
+
 class Trainer {
 public:
-    // `model` mirrors the reference's public pointer: callers `delete trainer->model; trainer->model = new
-    // ModelSplatsDevice(host);` (src/ui/UiFrame.cpp:157-158).  Call adoptModel() after assigning.
+    // The reference's public pointer.  Callers replace it directly — `delete trainer->model; trainer->model = new
+    // ModelSplatsDevice(host);` (src/ui/UiFrame.cpp:157-158,173-174,261-262,448-449) — and the next train / render /
+    // captureTruths call hands the new device model to the library (syncModel).
     ModelSplatsDevice* model = nullptr;
     std::vector<std::vector<uint32_t>> truthFrameBuffersW;  // host copies (the reference keeps device pointers)
     std::vector<std::vector<uint32_t>> truthFrameBuffersB;
+    std::vector<Camera> truthCameras;                        // src/Trainer.cuh:54
     std::vector<gs_view> truthViewsW, truthViewsB;          // per camera: the pass parameters (white / black)
+    // build-side extensions to the reference's Project: not part of its JSON
+    int updateRule = GS_UPDATE_SGD_CLAMP;
+    float adamBeta1 = 0.9f, adamBeta2 = 0.999f, adamEps = 1e-15f;
+    int quatLayout = GS_QUAT_XYZW;
 
     Trainer(int width = 1024, int height = 1024) : w(width), h(height) {
         check(gs_trainer_create(width, height, &handle));
@@ -157,15 +246,37 @@ public:
         gs_trainer_destroy(handle);
     }
 
-    // After `trainer->model = new ModelSplatsDevice(host)`: hand the device model to the library.
-    void adoptModel() {
-        check(gs_trainer_set_model(handle, model->release()));
-        viewsDirty = true;
+    // The device model the caller assigned to `model` becomes the library's (ownership moves to the trainer, as in
+    // the reference, whose destructor deletes `model`); a no-op while `model` still is the library's own.
+    void syncModel() {
+        if (!model) throw std::runtime_error("trainer has no model");
+        if (model->handle != gs_trainer_get_model(handle)) check(gs_trainer_set_model(handle, model->release()));
+    }
+    void adoptModel() { syncModel(); }  // (kept for callers written against the first version of this header)
+
+    // Trainer::render, src/Trainer.cu:148-216: black background, tan_fovx = tan(radians(sizeX * fovY / sizeY) / 2) (:196).
+    void render(uint32_t* frameBuffer, int sizeX, int sizeY, float splatScale, const Camera& camera, bool frameBufferOnDevice = false) {
+        gs_view view = camera.pass(sizeX, sizeY, 0.0f);
+        view.tan_fovx = std::tan(((float)sizeX * camera.fovDegY / (float)sizeY) * 0.01745329251994329576923690768489f * 0.5f);
+        render(frameBuffer, sizeX, sizeY, splatScale, view, frameBufferOnDevice);
+    }
+    // the same with the pass parameters spelled out (view / projview / campos / tan_fov* / bg)
+    void render(uint32_t* frameBuffer, int sizeX, int sizeY, float splatScale, const gs_view& view, bool frameBufferOnDevice = false) {
+        syncModel();
+        check(gs_trainer_render(handle, frameBuffer, frameBufferOnDevice ? 1 : 0, sizeX, sizeY, splatScale, &view));
     }
 
-    // Trainer::render, src/Trainer.cu:148-216.  `view` carries the camera (view/projview/campos/tan_fov*).
-    void render(uint32_t* frameBuffer, int sizeX, int sizeY, float splatScale, const gs_view& view, bool frameBufferOnDevice = false) {
-        check(gs_trainer_render(handle, frameBuffer, frameBufferOnDevice ? 1 : 0, sizeX, sizeY, splatScale, &view));
+    // Replaces Trainer::captureTruths(const Project&, RtxHost&) (src/Trainer.cu:218-250): the cameras of the scene
+    // (Camera::getCameras(project) in the reference) and, per camera, the white- and the black-background RGBA8
+    // truth image (width * height each) that the reference's ray tracer would have produced.
+    void captureTruths(const std::vector<Camera>& cameras, const std::vector<std::vector<uint32_t>>& framesWhite,
+                       const std::vector<std::vector<uint32_t>>& framesBlack) {
+        if (cameras.size() != framesWhite.size() || cameras.size() != framesBlack.size()) throw std::runtime_error("captureTruths: one white and one black frame per camera");
+        truthCameras = cameras;
+        truthViewsW.clear(); truthViewsB.clear();
+        for (const Camera& c : cameras) { truthViewsW.push_back(c.pass(w, h, 1.0f)); truthViewsB.push_back(c.pass(w, h, 0.0f)); }
+        truthFrameBuffersW = framesWhite; truthFrameBuffersB = framesBlack;
+        viewsDirty = true;
     }
 
     // Replaces Trainer::captureTruths (src/Trainer.cu:218-250): per camera, the white- and black-background
@@ -177,14 +288,38 @@ public:
         viewsDirty = true;
     }
 
-    // Trainer::train(Project&, bool densify), src/Trainer.cu:252-543.
+    // Trainer::train(Project&, bool densify), src/Trainer.cu:252-543: reads the learning rates and densify
+    // parameters from the project on every call and counts the iteration (:255).  Like the reference it returns
+    // with the device still working unless densify is set.
+    template <class ProjectT> void train(ProjectT& project, bool densify) {
+        if (truthFrameBuffersW.empty()) throw std::runtime_error("Can't run training iteration, no truth data available!");
+        project.iterations++;
+        const gs_hyper hyper = hyperOf(project);
+        syncModel();
+        if (viewsDirty) uploadViews();
+        check(gs_trainer_step(handle, &hyper, densify ? 1 : 0, nullptr));
+        if (densify) model->refresh();
+    }
+    // the same with explicit hyper-parameters, returning the step's statistics (this waits for the step to finish)
     gs_step_stats train(const gs_hyper& hyper, bool densify) {
         if (truthFrameBuffersW.empty()) throw std::runtime_error("Can't run training iteration, no truth data available!");
+        syncModel();
         if (viewsDirty) uploadViews();
         gs_step_stats st{};
         check(gs_trainer_step(handle, &hyper, densify ? 1 : 0, &st));
         if (densify) model->refresh();
         return st;
+    }
+    template <class ProjectT> gs_hyper hyperOf(const ProjectT& p) const {
+        gs_hyper hy{};
+        hy.lr_location = p.lrLocation; hy.lr_sh = p.lrSh; hy.lr_scale = p.lrScale; hy.lr_opacity = p.lrOpacity; hy.lr_rotation = p.lrRotation;
+        hy.scale_max = p.paramScaleMax;
+        hy.cull_opacity = p.paramCullOpacity; hy.cull_size = p.paramCullSize; hy.densify_variance = p.paramDensifyVariance;
+        hy.split_size = p.paramSplitSize; hy.split_distance = p.paramSplitDistance; hy.split_scale = p.paramSplitScale;
+        hy.clone_distance = p.paramCloneDistance;
+        hy.update_rule = updateRule; hy.adam_beta1 = adamBeta1; hy.adam_beta2 = adamBeta2; hy.adam_eps = adamEps;
+        hy.quat_layout = quatLayout;
+        return hy;
     }
 
     gs_trainer* native() { return handle; }

@@ -1,4 +1,8 @@
-// extras_cpu.cpp — host-only check of include/gsplat_extras.hpp: grid field, .gobj written by C++ and read back.
+// extras_cpu.cpp — host-only check of include/gsplat_extras.hpp.
+//   extras_cpu <dir>: reads <dir>/py.gobj (written by the Python mirror) and <dir>/mesh.obj, writes
+//     <dir>/cpp_copy.gobj   = load(py.gobj) saved again            (must equal Python's own load -> save, byte for byte)
+//     <dir>/cpp_grid.gobj   = the first 40 splats of initFieldGrid
+//     <dir>/cpp_mesh.gobj   = initFieldModel(mesh.obj)
 #include <cstdio>
 #include <cstring>
 
@@ -8,19 +12,35 @@ using namespace gsplat_shim;
 
 int main(int argc, char** argv) {
     if (argc != 2) return 2;
+    const std::string dir = argv[1];
     auto grid = initFieldGrid();
     if (grid->count != 17 * 17 * 17 || grid->rotations[3] != 1.0f || grid->scales[0] != 0.5f * 0.1f) return 3;
+    if (grid->locations[0] != -4.0f || grid->locations[5] != -3.5f || grid->locations[3 * (17 * 17 * 17 - 1)] != 4.0f) return 3;  // z fastest
+    if (initFieldGrid(false)->rotations[0] != 1.0f) return 3;
     grid->count = 40;  // keep the file small
-    grid->shs[5] = 0.123456789f; grid->opacities[7] = 1e-5f;
-    saveSplats(argv[1], *grid);
-    auto back = loadSplats(argv[1]);
-    if (back->count != 40 || back->shCoeffs != 4 || back->shDegree != 1 || back->capacity != 1000000) return 4;
-    if (std::fabs(back->shs[5] - 0.123457f) > 1e-7f || std::fabs(back->opacities[7] - 1e-5f) > 1e-11f) return 5;
-    if (initFieldMono()->count != 1) return 6;
-    bool threw = false;
+    saveSplats(dir + "/cpp_grid.gobj", *grid);
+    if (initFieldMono()->count != 1 || initFieldMono()->scales[1] != 0.3f) return 6;
+
+    auto copy = loadSplats(dir + "/py.gobj");
+    if (copy->shCoeffs != 4 || copy->shDegree != 1 || copy->capacity != 1000000) return 4;
+    saveSplats(dir + "/cpp_copy.gobj", *copy);
+
+    auto mesh = initFieldModel(dir + "/mesh.obj");
+    saveSplats(dir + "/cpp_mesh.gobj", *mesh);
+
+    int threw = 0;
     try { ModelSplatsHost bad(std::vector<float>{ 0, 0, 0 }, std::vector<float>{ 1, 2, 3 }, std::vector<float>{ 1, 1 }, { 1 }, { 1, 0, 0, 0 }); }
-    catch (const std::runtime_error&) { threw = true; }
-    if (!threw) return 7;
+    catch (const std::runtime_error&) { threw++; }
+    try {
+        std::istringstream two("v 0 0 0\nsh 1 2 3\ns 1 1 1\na 1\nr 1 0 0 0\nv 0 0 0\nsh 1 2 3 4 5 6\ns 1 1 1\na 1\nr 1 0 0 0\n");
+        readSplats(two);
+    } catch (const std::runtime_error& e) { if (std::string(e.what()) == "Inconsistent SH degree!") threw++; }
+    try {
+        std::istringstream five("v 0 0 0\nf 1 1 1 1 1\n");
+        parseObj(five);
+    } catch (const std::runtime_error& e) { if (std::string(e.what()).rfind("Unexpected vertex count in face list!", 0) == 0) threw++; }
+    try { loadSplats(dir + "/does_not_exist.gobj"); } catch (const std::runtime_error&) { threw++; }
+    if (threw != 4) return 7;
     printf("extras ok\n");
     return 0;
 }

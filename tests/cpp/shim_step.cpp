@@ -25,31 +25,34 @@ int main(int argc, char** argv) {
     const int P = hdr[0], M = hdr[1], W = hdr[2], H = hdr[3], C = hdr[4], steps = hdr[5];
     auto loc = rd<float>(f, 3 * (size_t)P), sh = rd<float>(f, 3 * (size_t)M * P), scale = rd<float>(f, 3 * (size_t)P),
          opac = rd<float>(f, P), rot = rd<float>(f, 4 * (size_t)P);
-    auto views = rd<gs_view>(f, 2 * (size_t)C);
+    auto camf = rd<float>(f, 7 * (size_t)C);  // per camera: location, target, fovDegY
     std::vector<std::vector<uint32_t>> fw, fb;
     for (int c = 0; c < C; c++) fw.push_back(rd<uint32_t>(f, (size_t)W * H));
     for (int c = 0; c < C; c++) fb.push_back(rd<uint32_t>(f, (size_t)W * H));
     fclose(f);
     try {
         Trainer trainer(W, H);
+        Trainer* tp = &trainer;
+        Project project;
         bool threw = false;
-        gs_hyper hyper;
-        check(gs_hyper_defaults(&hyper));
-        try { trainer.train(hyper, false); } catch (const std::runtime_error&) { threw = true; }  // src/Trainer.cu:253
-        if (!threw) return 4;
+        try { tp->train(project, false); } catch (const std::runtime_error&) { threw = true; }  // src/Trainer.cu:253
+        if (!threw || project.iterations != 0) return 4;  // the reference throws before it counts the iteration
         ModelSplatsHost host(loc, sh, scale, opac, rot);
-        delete trainer.model;                          // the reference idiom, src/ui/UiFrame.cpp:157-158
-        trainer.model = new ModelSplatsDevice(host);
-        trainer.adoptModel();
-        trainer.captureTruths(std::vector<gs_view>(views.begin(), views.begin() + C), std::vector<gs_view>(views.begin() + C, views.end()), fw, fb);
-        std::vector<float> losses;
-        for (int s = 0; s < steps; s++) losses.push_back(trainer.train(hyper, false).loss);
-        ModelSplatsHost back(*trainer.model);
+        delete tp->model;                              // the reference idiom verbatim, src/ui/UiFrame.cpp:157-158
+        tp->model = new ModelSplatsDevice(host);
+        std::vector<Camera> cameras;
+        for (int c = 0; c < C; c++) cameras.emplace_back(&camf[7 * c], &camf[7 * c + 3], camf[7 * c + 6]);
+        tp->captureTruths(cameras, fw, fb);
+        if ((int)tp->truthCameras.size() != C) return 5;
+        for (int s = 0; s < steps; s++) tp->train(project, false);          // src/ui/UiFrame.cpp:288
+        if (project.iterations != steps) return 6;
+        ModelSplatsHost back(*tp->model);
         std::vector<uint32_t> frame((size_t)W * H);
-        trainer.render(frame.data(), W, H, 1.0f, views[C]);  // black-background pass of camera 0
+        tp->render(frame.data(), W, H, project.previewSplatScale, cameras[0]);  // src/ui/UiPanelViewOutput.cpp:52-60
         FILE* o = fopen(argv[2], "wb");
         fwrite(&back.count, 4, 1, o);
-        fwrite(losses.data(), 4, losses.size(), o);
+        fwrite(tp->truthViewsW.data(), sizeof(gs_view), tp->truthViewsW.size(), o);  // the pass parameters Camera::pass derived
+        fwrite(tp->truthViewsB.data(), sizeof(gs_view), tp->truthViewsB.size(), o);
         fwrite(back.locations, 4, 3 * (size_t)back.count, o);
         fwrite(back.opacities, 4, (size_t)back.count, o);
         fwrite(frame.data(), 4, frame.size(), o);

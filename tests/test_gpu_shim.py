@@ -28,7 +28,8 @@ def test_cpp_shim_matches_python_mirror(tmp_path, orc):
         np.array([P, M, W, H, Cn, steps], np.int32).tofile(f)
         for k in ("loc", "sh", "scale", "opac", "rot"):
             s[k].tofile(f)
-        views.tofile(f)
+        for c in cams:
+            np.concatenate([c.location, c.target, [c.fovDegY]]).astype(np.float32).tofile(f)
         for a in fw + fb:
             a.tofile(f)
     subprocess.check_call([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
@@ -36,7 +37,9 @@ def test_cpp_shim_matches_python_mirror(tmp_path, orc):
     count = int(raw[:4].view(np.int32)[0])
     assert count == P
     o = 4
-    losses = raw[o:o + 4 * steps].view(np.float32); o += 4 * steps
+    blocks = raw[o:o + 160 * 2 * Cn].view(np.float32).reshape(2 * Cn, 40); o += 160 * 2 * Cn
+    # Camera::getView / getProjection of the shim against the Python mirror's (different libm / product order: ~1 ulp)
+    assert np.allclose(blocks, views, rtol=2e-6, atol=2e-6)
     loc = raw[o:o + 12 * P].view(np.float32); o += 12 * P
     opac = raw[o:o + 4 * P].view(np.float32); o += 4 * P
     frame = raw[o:o + 4 * W * H].view(np.uint32)
@@ -44,14 +47,17 @@ def test_cpp_shim_matches_python_mirror(tmp_path, orc):
     host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
     tr = gs.Trainer(W, H)
     tr.model = gs.ModelSplatsDevice(host)
-    tr.captureTruths(cams, fw, fb)
+    tr.captureTruths(cams, fw, fb, view_blocks=blocks)   # the very pass parameters the C++ run used: results must agree bit for bit
     proj = gs.Project()
-    py_losses = [tr.train(proj, stats=True).loss for _ in range(steps)]
+    for _ in range(steps):
+        tr.train(proj)
     back = gs.ModelSplatsHost.fromDevice(tr.model)
-    assert np.array_equal(np.array(py_losses, np.float32).view(np.uint32) >> 8, losses.view(np.uint32) >> 8)  # float-atomic loss sum: order may differ in the last bits
     assert np.array_equal(back.locations[:3 * P].view(np.uint32), loc.view(np.uint32))
     assert np.array_equal(back.opacities[:P].view(np.uint32), opac.view(np.uint32))
     fb_py = tr.render(W, H, 1.0, cams[0])
-    # Trainer.render applies the reference's tan_fovx quirk (sizeX/sizeY scaling); the C++ call passed the training pass block
-    assert frame.shape == fb_py.reshape(-1).shape
+    # Trainer::render incl. the reference's tan_fovx quirk: the two camera implementations differ by an ulp, so a few
+    # pixels may land on the other side of a quantisation step
+    lv = lambda a: ((a.reshape(-1)[:, None] >> np.arange(0, 32, 8)) & 0xFF).astype(int)
+    d = np.abs(lv(frame) - lv(fb_py))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
     tr.close()

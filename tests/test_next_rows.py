@@ -129,7 +129,8 @@ def test_auto_train_driver_loop():
 
 
 def test_cpp_extras_header_and_gobj_interop(tmp_path):
-    """include/gsplat_extras.hpp (C++): grid field + .gobj writer/reader; the file it writes is read by the Python mirror."""
+    """include/gsplat_extras.hpp (C++) against the Python mirror: a .gobj written by Python and copied by C++ equals
+    Python's own copy byte for byte; the C++ grid and one-splat-per-triangle fields equal fields.py's."""
     import os
     import subprocess
     from gsplat_amd import capi
@@ -137,9 +138,24 @@ def test_cpp_extras_header_and_gobj_interop(tmp_path):
     exe = tmp_path / "extras_cpu"
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "extras_cpu.cpp"),
                            "-o", str(exe), capi.LIB_PATH, "-Wl,-rpath," + os.path.dirname(capi.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
-    path = tmp_path / "grid.gobj"
-    out = subprocess.run([str(exe), str(path)], capture_output=True, text=True)
+    s = gs.synth.random_splats(60, 4, 17)
+    s["opac"][7] = 1e-5
+    s["loc"][0] = 123456.789
+    gs.io.saveSplats(tmp_path / "py.gobj", gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"]))
+    obj = "v 0 0 0\nv 2 0 0\nv 2 0 -2\nv 0 0 -2\nv 1 3 1\nvt 0.5 0.5\nf 1/1/1 2/1/1 3/1/1 4/1/1\n# comment\nf 1 2 5\nf 3//2 5//2 4//2\n"
+    (tmp_path / "mesh.obj").write_text(obj)
+    out = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "extras ok" in out.stdout, (out.returncode, out.stderr)
-    h = gs.io.loadSplats(path)
+    # copy of a Python-written file: the same bytes as Python's own load -> save
+    gs.io.saveSplats(tmp_path / "py_copy.gobj", gs.io.loadSplats(tmp_path / "py.gobj"))
+    assert (tmp_path / "cpp_copy.gobj").read_bytes() == (tmp_path / "py_copy.gobj").read_bytes()
+    # grid: C++ indexes the lattice, the mirror accumulates floats like the reference: same file
     ref = gs.fields.initFieldGrid()
-    assert h.count == 40 and np.allclose(h.locations[:120], ref.locations[:120]) and np.allclose(h.rotations[:160], ref.rotations[:160])
+    ref.count = 40
+    gs.io.saveSplats(tmp_path / "py_grid.gobj", ref)
+    assert (tmp_path / "cpp_grid.gobj").read_bytes() == (tmp_path / "py_grid.gobj").read_bytes()
+    # one splat per triangle: same values to fp32 rounding (sqrt / acos / sin of two libms)
+    h, r = gs.io.loadSplats(tmp_path / "cpp_mesh.gobj"), gs.fields.initFieldModel(obj)
+    assert h.count == r.count == 4
+    for name, w in (("locations", 3), ("scales", 3), ("opacities", 1), ("rotations", 4)):
+        assert np.allclose(getattr(h, name)[:w * 4], getattr(r, name)[:w * 4], rtol=2e-5, atol=2e-6), name

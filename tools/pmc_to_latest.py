@@ -1,22 +1,38 @@
 #!/usr/bin/env python3
-"""profiles/pmc_latest.json from a tools/pmc_pass.sh summary (FETCH_SIZE / WRITE_SIZE passes).
-usage: tools/pmc_to_latest.py gpurun_out/pmc_c/summary.json profiles/pmc_latest.json
-FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 bytes... the guide's gfx950 note: FETCH_SIZE under-counts
-non-streaming reads by up to 2x, so `fetch_bytes_x2` is the corrected upper bound bench.py reports as traffic."""
-import json, sys
+"""profiles/pmc_latest.json from a tools/pmc_pass.sh summary (FETCH_SIZE / WRITE_SIZE / SQ passes).
+usage: tools/pmc_to_latest.py gpurun_out/<dir>/summary.json profiles/pmc_latest.json
+
+The file is STAMPED with the hash of the kernel sources it was collected from (tools/source_stamp.py: csrc/*.hip,
+csrc/*.h, csrc/Makefile, include/gsplat.h).  bench.py reports `roofline.traffic` / `roofline.valu` only when the stamp
+equals the stamp of the sources it runs from; after any kernel change the numbers are null until the counters are
+collected again.  Counter units: FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE is doubled per the gfx950 correction of
+MI355X_MICROARCH.md (an upper bound for non-streaming reads)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_stamp import source_stamp  # noqa: E402
+
 src, dst = sys.argv[1], sys.argv[2]
 s = json.load(open(src))
-stage_of = {"gs::k_render_bwd2": "render_backward", "gs::k_render_fwd": "render_forward", "gs::k_tile_build_sort": "tile_sort",
-            "void gs::k_preprocess<3>": "preprocess", "void gs::k_splat_bwd_view<3>": "splat_backward", "gs::k_coarse_scatter": "scatter",
-            "gs::k_update": "update"}
-out = {}
+stage_of = {"gs::k_render_bwd_pair": "render_backward", "gs::k_render_bwd2": "render_backward_per_pass", "gs::k_render_fwd": "render_forward",
+            "gs::k_tile_build_sort": "tile_sort", "void gs::k_preprocess<3>": "preprocess", "void gs::k_splat_bwd_view<3>": "splat_backward",
+            "gs::k_coarse_scatter": "scatter", "gs::k_update": "update"}
+out = {"_stamp": {"source_sha256": source_stamp(), "command": "tools/pmc_pass.sh (rocprofv3 --pmc, one pass per counter group) around `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`; "
+                  "per kernel the LARGEST dispatch (the 16-view launch)"}}
 for k, st in stage_of.items():
-    if k in s and "FETCH_SIZE" in s[k] and "WRITE_SIZE" in s[k]:
-        out[st] = {"kernel": k, "fetch_bytes_x2": s[k]["FETCH_SIZE"] * 1024.0 * 2.0, "write_bytes": s[k]["WRITE_SIZE"] * 1024.0,
-                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_pass.sh) of `python3 bench.py --steps 2 --warmup 1`, "
-                           "largest dispatch (16 views); counter unit 1 KiB; FETCH_SIZE doubled per the gfx950 correction (upper bound for non-streaming reads)"}
-        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES"):
-            if c in s[k]:
-                out[st][c] = s[k][c]
+    if k not in s:
+        continue
+    e = {"kernel": k}
+    if "FETCH_SIZE" in s[k]:
+        e["fetch_bytes_x2"] = s[k]["FETCH_SIZE"] * 1024.0 * 2.0
+    if "WRITE_SIZE" in s[k]:
+        e["write_bytes"] = s[k]["WRITE_SIZE"] * 1024.0
+    for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
+              "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_VALU_MFMA_BUSY_CYCLES", "TCC_HIT_sum", "TCC_MISS_sum", "grid"):
+        if c in s[k]:
+            e[c] = s[k][c]
+    out[st] = e
 json.dump(out, open(dst, "w"), indent=1)
-print(json.dumps(out, indent=1)[:600])
+print(json.dumps(out, indent=1)[:800])
