@@ -10,8 +10,9 @@ truth = quantised render of a second splat set) and resident in HBM before the t
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, parameters replicated, the 16 passes sharded round-robin over the
-ranks (strong scaling), one RCCL sum all-reduce of the averaged-gradient buffer per step.
+N > 1: one process per GPU, parameters replicated, the cameras (both passes of each) sharded over the
+ranks (strong scaling), one RCCL sum all-reduce of the averaged-gradient buffer per step
+(or, --collective *-sharded, reduce-scatter -> update of the rank's chunk -> all-gather).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -69,7 +70,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (default 3 = the metric's config)")
     ap.add_argument("--update", choices=["adam", "sgd"], default="adam")
-    ap.add_argument("--collective", choices=["torch", "rccl"], default="torch")
+    ap.add_argument("--collective", choices=["torch", "rccl", "torch-sharded", "rccl-sharded"], default="torch",
+                    help="torch / rccl: one sum all-reduce of the gradient buffer, update replicated on every rank; *-sharded: "
+                         "reduce-scatter, update of the rank's chunk, all-gather of the parameters (gs_trainer_set_sharded_update)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=16, help="views of the workload the CPU baseline leg times")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and the collective hook even with one rank (plumbing test)")
@@ -141,7 +144,9 @@ def main():
     hook = None
     if use_dist:
         from gsplat_amd import dist as gsdist
-        hook = gsdist.TorchAllReduce(tr) if args.collective == "torch" else gsdist.NativeRcclComm(tr, rank, world)
+        hook = {"torch": lambda: gsdist.TorchAllReduce(tr), "rccl": lambda: gsdist.NativeRcclComm(tr, rank, world),
+                "torch-sharded": lambda: gsdist.TorchShardedUpdate(tr, rank, world),
+                "rccl-sharded": lambda: gsdist.NativeRcclComm(tr, rank, world, sharded=True)}[args.collective]()
     setup_s = time.time() - t0
 
     def sync_all():
@@ -267,7 +272,8 @@ def main():
             "config": {"workload": WORKLOAD_TEXT[args.config] + (f" [DIAGNOSTIC: views overridden to {V_total}]" if args.views else ""), "splats": P, "sh_coeffs": M, "views_per_step": V_total,
                        "views_per_gpu": V_local, "width": W, "height": H, "update": args.update,
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
-                       "collective": (args.collective + " all-reduce of %d fp32" % ((12 + 3 * M) * P)) if use_dist else "none",
+                       "collective": (args.collective + (" reduce-scatter + all-gather" if args.collective.endswith("sharded") else " all-reduce")
+                                      + " of %d fp32" % ((12 + 3 * M) * P)) if use_dist else "none",
                        "replicas_identical_after_run": replicas_identical,
                        "mean_num_rendered_per_view": R_mean, "max_tile_list": st.max_tile_list,
                        "camera_pass_sharing": "on (default): the white/black passes of a camera share projection, tile lists and "

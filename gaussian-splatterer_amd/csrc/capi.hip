@@ -322,7 +322,7 @@ static int model_alloc(int capacity, int sh_degree, int sh_coeffs, int count, gs
     m->capacity = capacity; m->sh_degree = sh_degree; m->sh_coeffs = sh_coeffs; m->count = count;
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; set_error("hipGetDevice failed"); return GS_ERR_HIP; }
     m->Pa = std::max(64, round_up(count, 64));
-    const size_t bytes = (size_t)(11 + 3 * sh_coeffs) * m->Pa * sizeof(float);
+    const size_t bytes = plane_buffer_floats(sh_coeffs, m->Pa) * sizeof(float);  // parameter planes + spare plane + chunk padding
     hipError_t e = hipMalloc((void**)&m->planes, bytes);
     if (e != hipSuccess) { delete m; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GS_ERR_OUT_OF_MEMORY; }
     e = hipMemset(m->planes, 0, bytes);
@@ -436,6 +436,9 @@ struct gs_trainer {
     uint32_t Rcap = 0;
     gs_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
+    gs_collective_fn shard_rs = nullptr, shard_ag = nullptr;  // sharded update (gs_trainer_set_sharded_update)
+    void* shard_user = nullptr;
+    int shard_rank = 0, shard_world = 1;
     gs_step_stats last{};
     bool accumulated = false;
     // optional per-stage HIP-event timing (bench / roofline evidence)
@@ -629,7 +632,7 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
     if (V == 0) {
         // A data-parallel rank that owns no pass of this iteration (more ranks than passes): its contribution to the
         // averaged gradients is zero, and it still joins the collective and applies the common update.
-        GS_TRY(t->grad.ensure((size_t)(pl.count() + 1) * m->Pa * 4));
+        GS_TRY(t->grad.ensure(plane_buffer_floats(M, m->Pa) * 4));
         t->grad_Pa = m->Pa; t->grad_M = M;
         GS_HIP(hipMemsetAsync(t->grad.p, 0, (size_t)(pl.count() + 1) * m->Pa * 4, t->stream));
         gs_step_stats st0{};
@@ -641,7 +644,12 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
     gs_step_stats st{};
     st.count_before = st.count_after = P; st.views = V;
     // gradient planes (+ var), sized to the model's plane stride
-    GS_TRY(t->grad.ensure((size_t)(pl.count() + 1) * m->Pa * 4));
+    {
+        const void* before = t->grad.p;
+        GS_TRY(t->grad.ensure(plane_buffer_floats(M, m->Pa) * 4));
+        if (t->grad.p != before || t->grad_Pa != m->Pa)   // the tail behind the planes takes part in the collectives' chunks: keep it finite
+            GS_HIP(hipMemsetAsync(t->grad.as<float>() + (size_t)(pl.count() + 1) * m->Pa, 0, 64 * 64 * 4, t->stream));
+    }
     t->grad_Pa = m->Pa; t->grad_M = M;
     if (t->Rcap == 0) t->Rcap = g_opt_arena ? (uint32_t)g_opt_arena : (uint32_t)std::max<long long>(1 << 20, 16LL * P);
     if (t->h_flags_cap < (size_t)V * 20) {
@@ -730,7 +738,7 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
 extern "C" int gs_trainer_grad_buffer(gs_trainer* t, float** p, size_t* n) {
     if (!t || !t->model) return GS_ERR_INVALID_ARGUMENT;
     const Planes pl{ t->model->sh_coeffs };
-    GS_TRY(t->grad.ensure((size_t)(pl.count() + 1) * t->model->Pa * 4));
+    GS_TRY(t->grad.ensure(plane_buffer_floats(t->model->sh_coeffs, t->model->Pa) * 4));
     if (p) *p = t->grad.as<float>();
     if (n) *n = (size_t)(pl.count() + 1) * t->model->Pa;
     return GS_OK;
@@ -768,7 +776,7 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
     // Adam moments follow their splats (twins inherit the parent's); the step counter keeps running
     DevBuf new_m, new_v;
     if (rc == GS_OK && t->adam_valid) {
-        const size_t bytes = (size_t)(11 + 3 * M) * fresh->Pa * 4;
+        const size_t bytes = plane_buffer_floats(M, fresh->Pa) * 4;
         rc = new_m.ensure(bytes);
         if (rc == GS_OK) rc = new_v.ensure(bytes);
         if (rc == GS_OK && (hipMemsetAsync(new_m.p, 0, bytes, t->stream) != hipSuccess || hipMemsetAsync(new_v.p, 0, bytes, t->stream) != hipSuccess)) rc = GS_ERR_HIP;
@@ -789,14 +797,13 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
     return GS_OK;
 }
 
-extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, gs_step_stats* stats) {
-    if (!t || !h) return GS_ERR_INVALID_ARGUMENT;
-    if (!t->accumulated) { set_error("gs_trainer_apply called without gs_trainer_accumulate"); return GS_ERR_INVALID_ARGUMENT; }
-    GS_HIP(hipSetDevice(t->device));
+// The parameter update on the flat element range [lo, hi) of the planes (everything by default): Adam state is created
+// on first use and its step counter advanced once per call.
+static int apply_update(gs_trainer* t, const gs_hyper* h, int stage_before, size_t lo = 0, size_t hi = ~(size_t)0) {
     gs_model* m = t->model;
     const Planes pl{ m->sh_coeffs };
     if (h->update_rule == GS_UPDATE_ADAM) {
-        const size_t bytes = (size_t)pl.count() * m->Pa * 4;
+        const size_t bytes = plane_buffer_floats(m->sh_coeffs, m->Pa) * 4;
         if (!t->adam_valid) {
             GS_TRY(t->adam_m.ensure(bytes)); GS_TRY(t->adam_v.ensure(bytes));
             GS_HIP(hipMemsetAsync(t->adam_m.p, 0, bytes, t->stream));
@@ -808,12 +815,20 @@ extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, g
         set_error("unknown update rule %d", h->update_rule);
         return GS_ERR_INVALID_ARGUMENT;
     }
-    prof_stage_begin(t, 7, t->allreduce ? 8 : 6);
+    prof_stage_begin(t, 7, stage_before);
     GS_TRY(launch_update(pl, m->count, m->Pa, m->planes, t->grad.as<float>(), t->adam_m.as<float>(), t->adam_v.as<float>(),
-                         t->adam_t, *h, t->stream));
+                         t->adam_t, *h, t->stream, lo, hi));
     prof_stage_end(t, 7);
     GS_TRY(debug_check(t, 7));
     t->accumulated = false;
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, gs_step_stats* stats) {
+    if (!t || !h) return GS_ERR_INVALID_ARGUMENT;
+    if (!t->accumulated) { set_error("gs_trainer_apply called without gs_trainer_accumulate"); return GS_ERR_INVALID_ARGUMENT; }
+    GS_HIP(hipSetDevice(t->device));
+    GS_TRY(apply_update(t, h, t->allreduce ? 8 : 6));
     if (densify) {
         GS_TRY(resolve_stats(t));
         GS_TRY(trainer_densify(t, h, &t->last));
@@ -822,11 +837,46 @@ extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, g
     return GS_OK;
 }
 
+// One collective of the sharded update, timed as part of the "collective" stage.
+static int shard_call(gs_trainer* t, gs_collective_fn fn, float* buf, size_t n, const char* what) {
+    const int rc = fn(buf, n, (void*)t->stream, t->shard_user);
+    if (rc != 0) { set_error("%s hook failed with %d", what, rc); return GS_ERR_INTERNAL; }
+    return GS_OK;
+}
+
 extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs_step_stats* stats) {
     if (!t || !h) return GS_ERR_INVALID_ARGUMENT;
     // `var` (accumulateGradients, src/Trainer.cu:52) is read by the densify block of the same iteration only (:444,453)
     // and starts from zero every iteration (:304-309): a step without densify does not need per-pass gradients
     GS_TRY(accumulate_async(t, densify != 0));
+    if (t->shard_rs && t->shard_ag) {
+        // Data-parallel sharded update: every rank ends up with the sum of its own chunk of the gradient buffer only
+        // (reduce-scatter), updates that chunk of the parameters (and keeps Adam moments for that chunk only up to date),
+        // and the updated chunks are exchanged (all-gather).  Same bytes on the wire as an all-reduce; the update and
+        // the optimizer state are 1 / world per rank.  One chunking for all plane-major buffers (shard_total_floats).
+        gs_model* m = t->model;
+        const size_t n = shard_total_floats(m->sh_coeffs, m->Pa, t->shard_world), chunk = n / (size_t)t->shard_world;
+        const size_t lo = chunk * (size_t)t->shard_rank, hi = lo + chunk;
+        prof_stage_begin(t, 8, 6);
+        GS_TRY(shard_call(t, t->shard_rs, t->grad.as<float>(), n, "reduce-scatter"));
+        prof_stage_end(t, 8);
+        GS_TRY(debug_check(t, 8));
+        GS_TRY(apply_update(t, h, 8, lo, hi));
+        GS_TRY(shard_call(t, t->shard_ag, m->planes, n, "all-gather (parameters)"));
+        if (densify) {
+            // densify reads var and the averaged location gradient of EVERY splat, and re-indexes the Adam moments:
+            // complete the three buffers on every rank first (every intervalDensify-th step only)
+            GS_TRY(shard_call(t, t->shard_ag, t->grad.as<float>(), n, "all-gather (gradients)"));
+            if (t->adam_valid) {
+                GS_TRY(shard_call(t, t->shard_ag, t->adam_m.as<float>(), n, "all-gather (Adam m)"));
+                GS_TRY(shard_call(t, t->shard_ag, t->adam_v.as<float>(), n, "all-gather (Adam v)"));
+            }
+            GS_TRY(resolve_stats(t));
+            GS_TRY(trainer_densify(t, h, &t->last));
+        }
+        if (stats) { GS_TRY(resolve_stats(t)); *stats = t->last; }
+        return GS_OK;
+    }
     if (t->allreduce) {
         float* buf = nullptr; size_t n = 0;
         GS_TRY(gs_trainer_grad_buffer(t, &buf, &n));
@@ -838,6 +888,17 @@ extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs
         if (rc != 0) { set_error("all-reduce hook failed with %d", rc); return GS_ERR_INTERNAL; }
     }
     return gs_trainer_apply(t, h, densify, stats);
+}
+
+extern "C" int gs_trainer_set_sharded_update(gs_trainer* t, gs_collective_fn reduce_scatter, gs_collective_fn all_gather, void* user,
+                                             int rank, int world) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    if (!reduce_scatter || !all_gather) { t->shard_rs = t->shard_ag = nullptr; t->shard_user = nullptr; t->shard_rank = 0; t->shard_world = 1; return GS_OK; }
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) { set_error("gs_trainer_set_sharded_update: rank %d of %d (1..64 ranks)", rank, world); return GS_ERR_INVALID_ARGUMENT; }
+    GS_HIP(hipStreamSynchronize(t->stream));
+    t->shard_rs = reduce_scatter; t->shard_ag = all_gather; t->shard_user = user; t->shard_rank = rank; t->shard_world = world;
+    t->adam_valid = false; t->adam_t = 0;   // moments kept so far may be stale outside a chunk: start clean
+    return GS_OK;
 }
 
 extern "C" int gs_trainer_adam_state(gs_trainer* t, float** m, float** v, size_t* n_floats, int* steps) {
@@ -1171,11 +1232,14 @@ struct RcclId { char internal[128]; };
 typedef int (*fn_get_id)(RcclId*);
 typedef int (*fn_init_rank)(void**, int, RcclId, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_reduce_scatter)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
 struct Rccl {
     void* lib = nullptr;
     fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_allreduce allreduce = nullptr; fn_destroy destroy = nullptr;
+    fn_reduce_scatter reduce_scatter = nullptr; fn_all_gather all_gather = nullptr;
     fn_errstr errstr = nullptr;
 } g_rccl;
 int rccl_load() {
@@ -1188,6 +1252,8 @@ int rccl_load() {
     g_rccl.init_rank = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
     g_rccl.allreduce = (fn_allreduce)dlsym(lib, "ncclAllReduce");
     g_rccl.destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
+    g_rccl.reduce_scatter = (fn_reduce_scatter)dlsym(lib, "ncclReduceScatter");
+    g_rccl.all_gather = (fn_all_gather)dlsym(lib, "ncclAllGather");
     g_rccl.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
     if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.allreduce || !g_rccl.destroy) { set_error("librccl lacks expected symbols"); return GS_ERR_INTERNAL; }
     g_rccl.lib = lib;
@@ -1233,4 +1299,21 @@ extern "C" int gs_trainer_attach_comm(gs_trainer* t, gs_comm* c) {
     if (!t) return GS_ERR_INVALID_ARGUMENT;
     if (!c) return gs_trainer_set_allreduce(t, nullptr, nullptr);
     return gs_trainer_set_allreduce(t, rccl_hook, c);
+}
+// in-place forms: the rank's chunk of the buffer is both the reduce-scatter's output and the all-gather's input
+static int rccl_rs_hook(float* buf, size_t n, void* stream, void* user) {
+    gs_comm* c = static_cast<gs_comm*>(user);
+    const size_t chunk = n / (size_t)c->n_ranks;
+    return g_rccl.reduce_scatter(buf, buf + chunk * (size_t)c->rank, chunk, 7, 0, c->comm, (hipStream_t)stream);
+}
+static int rccl_ag_hook(float* buf, size_t n, void* stream, void* user) {
+    gs_comm* c = static_cast<gs_comm*>(user);
+    const size_t chunk = n / (size_t)c->n_ranks;
+    return g_rccl.all_gather(buf + chunk * (size_t)c->rank, buf, chunk, 7, c->comm, (hipStream_t)stream);
+}
+extern "C" int gs_trainer_attach_comm_sharded(gs_trainer* t, gs_comm* c) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    if (!c) return gs_trainer_set_sharded_update(t, nullptr, nullptr, nullptr, 0, 1);
+    if (!g_rccl.reduce_scatter || !g_rccl.all_gather) { set_error("librccl lacks ncclReduceScatter / ncclAllGather"); return GS_ERR_INTERNAL; }
+    return gs_trainer_set_sharded_update(t, rccl_rs_hook, rccl_ag_hook, c, c->rank, c->n_ranks);
 }

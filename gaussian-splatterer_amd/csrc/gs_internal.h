@@ -148,8 +148,17 @@ int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch&
 // Seam form: one view, reference-shaped AoS outputs with the reference's += / = discipline.
 struct SeamGrads { float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot; };
 int launch_splat_backward_seam(const Dims& d, const float* params, const Scratch& s, const SeamGrads& g, hipStream_t st);
+// updates the flat element range [lo, hi) of the parameter planes (default: all of them)
 int launch_update(const Planes& pl, int P, int Pa, float* params, float* grads, float* adam_m, float* adam_v, int adam_t,
-                  const gs_hyper& h, hipStream_t st);
+                  const gs_hyper& h, hipStream_t st, size_t lo = 0, size_t hi = ~(size_t)0);
+// Floats every plane-major buffer of a model is allocated with: the 11+3M parameter planes, one spare plane (the
+// gradient buffer's `var`), and padding so that the buffer divides into equal chunks for any rank count <= 64 (the
+// sharded update reduce-scatters gradients and all-gathers parameters with ONE chunking, gs_trainer_set_sharded_update).
+inline size_t plane_buffer_floats(int M, int Pa) { return (size_t)(12 + 3 * M) * Pa + 64 * 64; }
+inline size_t shard_total_floats(int M, int Pa, int world) {
+    const size_t n = (size_t)(12 + 3 * M) * Pa, q = (size_t)world * 64;
+    return (n + q - 1) / q * q;
+}
 int launch_aos_to_soa(int P, int Pa, int M, const float* loc, const float* sh, const float* scale, const float* opac,
                       const float* rot, float* planes, hipStream_t st);
 int launch_soa_to_aos(int P, int Pa, int M, const float* planes, float* loc, float* sh, float* scale, float* opac,

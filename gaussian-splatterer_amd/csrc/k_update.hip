@@ -4,6 +4,8 @@
 //   aos<->soa   : ModelSplatsHost layout (src/ModelSplatsHost.h:16-20) <-> plane-major device layout.
 //   image ops   : imageFloatToInt (src/Trainer.cu:19-29), imageIntToLoss (src/Trainer.cu:33-44).
 // All HBM-bound elementwise work: plane-major SoA makes every wave access 256 contiguous bytes.
+#include <algorithm>
+
 #include "gs_internal.h"
 
 namespace gs {
@@ -15,12 +17,15 @@ struct UpdateArgs {
     int M;
 };
 
+// [lo, hi): the flat element range (plane * Pa + splat) this launch owns — everything on one GPU, the rank's chunk
+// under the data-parallel sharded update; blockIdx.y counts planes from the first one the range touches.
 __global__ __launch_bounds__(WG) void k_update(UpdateArgs u, int P, int Pa, float* __restrict__ params,
                                                const float* __restrict__ grads, float* __restrict__ am,
-                                               float* __restrict__ av) {
+                                               float* __restrict__ av, size_t lo, size_t hi, int first_plane) {
     const int i = blockIdx.x * WG + threadIdx.x;
-    const int p = blockIdx.y;
+    const int p = first_plane + blockIdx.y;
     if (i >= P) return;
+    if ((size_t)p * Pa + i < lo || (size_t)p * Pa + i >= hi) return;
     const Planes pl{ u.M };
     // plane group -> learning rate / clamp
     float lr; int kind;  // 0 plain, 1 scale clamp, 2 opacity clamp
@@ -48,16 +53,19 @@ __global__ __launch_bounds__(WG) void k_update(UpdateArgs u, int P, int Pa, floa
 }
 
 int launch_update(const Planes& pl, int P, int Pa, float* params, float* grads, float* adam_m, float* adam_v, int adam_t,
-                  const gs_hyper& h, hipStream_t st) {
+                  const gs_hyper& h, hipStream_t st, size_t lo, size_t hi) {
     if (P == 0) return GS_OK;
+    hi = std::min(hi, (size_t)pl.count() * Pa);
+    if (lo >= hi) return GS_OK;
+    const int first_plane = (int)(lo / Pa), last_plane = (int)((hi - 1) / Pa);
     UpdateArgs u;
     u.lr_loc = h.lr_location; u.lr_sh = h.lr_sh; u.lr_scale = h.lr_scale; u.lr_opac = h.lr_opacity; u.lr_rot = h.lr_rotation;
     u.scale_max = h.scale_max; u.rule = h.update_rule; u.b1 = h.adam_beta1; u.b2 = h.adam_beta2; u.eps = h.adam_eps;
     u.bc1 = 1.0f - powf(h.adam_beta1, (float)adam_t);
     u.bc2 = 1.0f - powf(h.adam_beta2, (float)adam_t);
     u.M = pl.M;
-    hipLaunchKernelGGL(k_update, dim3((P + WG - 1) / WG, pl.count()), dim3(WG), 0, st, u, P, Pa, params,
-                       (const float*)grads, adam_m, adam_v);
+    hipLaunchKernelGGL(k_update, dim3((P + WG - 1) / WG, last_plane - first_plane + 1), dim3(WG), 0, st, u, P, Pa, params,
+                       (const float*)grads, adam_m, adam_v, lo, hi, first_plane);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -78,11 +78,71 @@ class TorchAllReduce:
         capi.check(capi.lib().gs_trainer_set_allreduce(trainer.handle, C.cast(self._cb, C.c_void_p), None))
 
 
-class NativeRcclComm:
-    """The library's own RCCL communicator (gs_comm_*): the 128-byte unique id is created on rank 0
-    and broadcast through torch.distributed's store; the collective itself never touches Python."""
+class TorchShardedUpdate:
+    """gs_trainer_set_sharded_update with torch.distributed: reduce_scatter_tensor / all_gather_into_tensor IN PLACE on
+    tensors that alias the library's plane-major buffers (the rank's chunk is a view of the whole buffer), enqueued
+    behind the trainer's HIP stream.  Each rank then updates 1/world of the parameters and keeps 1/world of the Adam
+    moments current; the bytes on the wire equal an all-reduce's.  Backends without reduce-scatter (gloo, used by the
+    two-processes-on-one-GPU test) fall back to an all-reduce, which leaves the same sums in the rank's chunk."""
 
     def __init__(self, trainer, rank, world):
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        self.rank, self.world = int(rank), int(world)
+        st = C.c_void_p()
+        capi.check(capi.lib().gs_trainer_get_stream(trainer.handle, C.byref(st)))
+        self.stream = torch.cuda.ExternalStream(st.value)
+        self._alias = {}
+        self.calls = {"reduce_scatter": 0, "all_gather": 0}
+
+        def alias(buf, n):
+            t = self._alias.get((buf, n))
+            if t is None:
+                if len(self._alias) > 8:
+                    self._alias.clear()
+                t = torch.as_tensor(_DevPtr(buf, n), device=torch.device("cuda", torch.cuda.current_device()))
+                self._alias[(buf, n)] = t
+            return t
+
+        def rs(buf, n, hip_stream, user):
+            try:
+                t = alias(buf, n)
+                c = n // self.world
+                with torch.cuda.stream(self.stream):
+                    try:
+                        dist.reduce_scatter_tensor(t[self.rank * c:(self.rank + 1) * c], t, op=dist.ReduceOp.SUM)
+                    except (RuntimeError, NotImplementedError):
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                self.calls["reduce_scatter"] += 1
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("reduce-scatter hook failed:", repr(e), flush=True)
+                return 1
+
+        def ag(buf, n, hip_stream, user):
+            try:
+                t = alias(buf, n)
+                c = n // self.world
+                with torch.cuda.stream(self.stream):
+                    dist.all_gather_into_tensor(t, t[self.rank * c:(self.rank + 1) * c])
+                self.calls["all_gather"] += 1
+                return 0
+            except Exception as e:
+                print("all-gather hook failed:", repr(e), flush=True)
+                return 1
+
+        self._rs, self._ag = capi.ALLREDUCE_FN(rs), capi.ALLREDUCE_FN(ag)
+        capi.check(capi.lib().gs_trainer_set_sharded_update(trainer.handle, C.cast(self._rs, C.c_void_p), C.cast(self._ag, C.c_void_p),
+                                                            None, self.rank, self.world))
+
+
+class NativeRcclComm:
+    """The library's own RCCL communicator (gs_comm_*): the 128-byte unique id is created on rank 0
+    and broadcast through torch.distributed's store; the collective itself never touches Python.
+    sharded=True installs ncclReduceScatter / ncclAllGather as the sharded update's hooks instead of the all-reduce."""
+
+    def __init__(self, trainer, rank, world, sharded=False):
         import torch.distributed as dist
         from . import capi
         L = capi.lib()
@@ -95,4 +155,4 @@ class NativeRcclComm:
             C.memmove(ident, box[0], capi.GS_COMM_ID_BYTES)
         self.handle = C.c_void_p()
         capi.check(L.gs_comm_create(ident, rank, world, C.byref(self.handle)))
-        capi.check(L.gs_trainer_attach_comm(trainer.handle, self.handle))
+        capi.check((L.gs_trainer_attach_comm_sharded if sharded else L.gs_trainer_attach_comm)(trainer.handle, self.handle))

@@ -209,6 +209,20 @@ int gs_trainer_adam_state(gs_trainer* trainer, float** moment1, float** moment2,
  * fp32 values at `device_buf` in place over all ranks, enqueued on `hip_stream`.  Return 0 on success. */
 typedef int (*gs_allreduce_fn)(float* device_buf, size_t n_floats, void* hip_stream, void* user);
 int gs_trainer_set_allreduce(gs_trainer* trainer, gs_allreduce_fn fn, void* user);
+/* Sharded update, the other data-parallel form of gs_trainer_step: instead of all-reducing the gradient buffer and
+ * repeating the whole update on every rank, the step
+ *   1. reduce-scatters the gradient buffer: rank r ends with the sums of chunk r only,
+ *   2. updates chunk r of the parameter planes (Adam moments exist and advance for that chunk only),
+ *   3. all-gathers the parameter planes.
+ * Both hooks work IN PLACE on `n_floats` fp32 at `device_buf`, enqueued on `hip_stream`; n_floats is a multiple of
+ * `world` (the library pads its plane-major buffers), chunk r = [r, r + 1) * n_floats / world.  reduce_scatter: on
+ * return chunk `rank` holds the sum over ranks of that chunk (the rest is unspecified); all_gather: every rank's
+ * chunk `rank` is copied to all ranks.  A densify step additionally all-gathers the gradient buffer (var, location
+ * gradient) and the Adam moments so that every rank densifies identically.  Replicas stay bit-identical because each
+ * element is reduced and updated on exactly one rank.  Pass NULL hooks to return to the unsharded step. */
+typedef int (*gs_collective_fn)(float* device_buf, size_t n_floats, void* hip_stream, void* user);
+int gs_trainer_set_sharded_update(gs_trainer* trainer, gs_collective_fn reduce_scatter, gs_collective_fn all_gather, void* user,
+                                  int rank, int world);
 /* The HIP stream (hipStream_t) all of this trainer's work is enqueued on. */
 int gs_trainer_get_stream(gs_trainer* trainer, void** hip_stream);
 int gs_trainer_synchronize(gs_trainer* trainer);
@@ -242,6 +256,8 @@ int gs_comm_create(const char id[GS_COMM_ID_BYTES], int rank, int n_ranks, gs_co
 int gs_comm_destroy(gs_comm* comm);
 /* Installs an RCCL sum all-reduce of the gradient buffer as the trainer's collective hook. */
 int gs_trainer_attach_comm(gs_trainer* trainer, gs_comm* comm);
+/* Installs ncclReduceScatter / ncclAllGather (in place) as the hooks of gs_trainer_set_sharded_update. */
+int gs_trainer_attach_comm_sharded(gs_trainer* trainer, gs_comm* comm);
 
 /* ------------------------------------------------------------------------------------------
  * Inner seam: the rasterizer pair the reference calls.  Same argument order as

@@ -34,7 +34,7 @@ def _scene():
     return s, cams, fw, fb
 
 
-def _train(rank, world, hook_factory):
+def _train(rank, world, hook_factory, adam_densify=False):
     import gsplat_amd as gs
     from gsplat_amd import capi
     s, cams, fw, fb = _scene()
@@ -46,8 +46,11 @@ def _train(rank, world, hook_factory):
     tr.shard(rank, world)
     hook = hook_factory(tr) if hook_factory else None
     proj = gs.Project()     # the reference's clamped ascent: linear in the gradient, so re-association of the pass sum stays tiny
-    for _ in range(STEPS):
-        tr.train(proj)          # no stats: the steps run ahead of the device, as in bench.py
+    if adam_densify:
+        proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=1e-3, lrSh=2e-3, lrScale=5e-4, lrOpacity=1e-3, lrRotation=1e-3,
+                          paramDensifyVariance=0.05, paramCullOpacity=0.15, paramSplitSize=0.06)
+    for k in range(STEPS + (2 if adam_densify else 0)):
+        tr.train(proj, densify=adam_densify and k == 2)          # no stats: the steps run ahead of the device, as in bench.py
     h = gs.ModelSplatsHost.fromDevice(tr.model)
     n = h.count
     out = np.concatenate([h.locations[:3 * n], h.shs[:3 * M * n], h.scales[:3 * n], h.opacities[:n], h.rotations[:4 * n]])
@@ -56,7 +59,7 @@ def _train(rank, world, hook_factory):
     return out, np.concatenate([s["loc"].reshape(-1), s["sh"].reshape(-1), s["scale"].reshape(-1), s["opac"].reshape(-1), s["rot"].reshape(-1)])
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sharded=False, adam_densify=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch
@@ -64,19 +67,28 @@ def _worker(rank, world, port, q):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gsplat_amd import dist as gsdist
-    out, _ = _train(rank, world, lambda tr: gsdist.TorchAllReduce(tr))
+    hooks = []
+    out, _ = _train(rank, world, lambda tr: hooks.append(gsdist.TorchShardedUpdate(tr, rank, world) if sharded else gsdist.TorchAllReduce(tr)) or hooks[-1],
+                    adam_densify)
+    if sharded and not adam_densify:
+        assert hooks[0].calls == {"reduce_scatter": STEPS, "all_gather": STEPS}, hooks[0].calls
+    if sharded and adam_densify:   # the densify step also gathers the gradient buffer and both Adam moments
+        assert hooks[0].calls == {"reduce_scatter": STEPS + 2, "all_gather": STEPS + 2 + 3}, hooks[0].calls
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_the_single_process_run():
+@pytest.mark.parametrize("sharded", [False, True])
+def test_two_ranks_on_one_gpu_match_the_single_process_run(sharded):
+    """sharded: reduce-scatter -> each rank updates its half of the plane-major parameter buffer -> all-gather
+    (gs_trainer_set_sharded_update) instead of all-reduce + replicated update."""
     import multiprocessing as mp
     sys.path.insert(0, ROOT)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sharded)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
@@ -89,6 +101,34 @@ def test_two_ranks_on_one_gpu_match_the_single_process_run():
     moved = np.abs(single - start).max()
     assert moved > 1e-7                                                     # the steps did something
     assert np.abs(a - single).max() <= 1e-4 * moved, (np.abs(a - single).max(), moved)
+
+
+def _run_two(sharded, adam_densify):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sharded, adam_densify)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res[0][1], res[1][1]
+
+
+def test_sharded_update_with_adam_and_densify_equals_the_allreduce_form():
+    """Adam moments exist per chunk only under the sharded update, and a densify step has to complete gradients and
+    moments on every rank before it re-indexes them.  With the same sums on the wire (the gloo stand-in reduces both forms
+    identically) the sharded form must leave bit for bit the model the all-reduce form leaves — through five Adam steps
+    with a split / clone / prune in the middle — and both ranks must hold it."""
+    sys.path.insert(0, ROOT)
+    a0, a1 = _run_two(False, True)
+    s0, s1 = _run_two(True, True)
+    assert a0.size != (11 + 3 * M) * P            # densify changed the splat count
+    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
+    assert s0.size == a0.size and np.array_equal(s0.view(np.uint32), a0.view(np.uint32))
 
 
 def test_eight_way_view_sharding_sums_to_the_single_shard_gradients():
