@@ -195,8 +195,9 @@ struct ScratchSet {
     }
 };
 
-// projection + everything that does not need the binning arena: the block prefixes of the offsets scan (entry count and
-// overflow bit land in flags) and the super-tile scan.  Runs for P == 0 too (the scans then define empty lists).
+// projection + everything that does not need the binning arena: the column scan of the count matrix and, in the same
+// launch, the block prefixes of the offsets scan (entry count and overflow bit land in flags).  Runs for P == 0 too
+// (the scans then define empty lists).
 static int stage_project(const Dims& d, const float* params, const Scratch& s, hipStream_t st) {
     if (d.NST > MAX_SUPER_TILES) {
         set_error("image of %dx%d has %d super-tiles; this build bins up to %d (e.g. 8192x4096)", d.W, d.H, d.NST, MAX_SUPER_TILES);
@@ -204,14 +205,14 @@ static int stage_project(const Dims& d, const float* params, const Scratch& s, h
     }
     GS_TRY(launch_preprocess(d, params, s, st));
     GS_TRY(launch_coarse_colscan(d, s, st));
-    GS_TRY(launch_project_scans(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), st));
     return GS_OK;
 }
-// coarse scatter (finishes the offsets scan), per-tile counts, their scan and the longest-first tile order
+// coarse scatter (finishes the offsets scan, scans the super-tile totals), per-tile counts, then ONE launch for the
+// per-tile segments, the tile scan and the longest-first tile order
 static int stage_bin(const Dims& d, const Scratch& s, hipStream_t st) {
     GS_TRY(launch_coarse_scatter(d, s, st));
     GS_TRY(launch_tile_count(d, s, st));
-    GS_TRY(launch_tile_scan_order(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), st));
+    GS_TRY(launch_tile_scatter(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), st));
     return GS_OK;
 }
 static int stage_bin_render(const Dims& d, const Scratch& s, hipStream_t st) {
@@ -677,7 +678,6 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
         GS_TRY(debug_check(t, 0));
         prof_stage_begin(t, 1, 0);
         GS_TRY(launch_coarse_colscan(d, s, t->stream));
-        GS_TRY(launch_project_scans(d, s, s.block_sums + (size_t)std::max(d.VG, 1) * splat_blocks(d.Pa), t->stream));
         GS_HIP(hipMemcpyAsync(t->h_flags, s.flags, (size_t)t->VG * 16, hipMemcpyDeviceToHost, t->stream));
         GS_HIP(hipEventRecord(t->ev_flags, t->stream));
         prof_stage_end(t, 1);  // the scans and the publication of their overflow verdict

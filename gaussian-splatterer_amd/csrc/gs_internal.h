@@ -124,10 +124,9 @@ struct Scratch {
 // kernel launchers (one translation unit each)
 // ---------------------------------------------------------------------------------------------
 int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st);
-// after preprocess, one launch: prefix of the per-block tile sums (-> flags: num_rendered, arena overflow) and the
-// inclusive scan of the super-tile counters
+// after preprocess, one launch: column scan of the (block x super-tile) count matrix + the prefix of the per-block tile
+// sums (-> flags: num_rendered, arena overflow); the scan of the super-tile totals happens inside k_coarse_scatter
 int launch_coarse_colscan(const Dims& d, const Scratch& s, hipStream_t st);
-int launch_project_scans(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st);
 // batched inclusive scan of u32: one workgroup per batch entry up to g_scan_single_max items, three phases beyond
 int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int batch, uint32_t* partials, hipStream_t st);
 size_t scan_partials_count(int n, int batch);
@@ -135,7 +134,8 @@ extern int g_scan_single_max;
 __host__ __device__ inline int splat_blocks(int Pa) { return (Pa + WG - 1) / WG; }
 int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st);
-int launch_tile_scan_order(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st);
+// per-tile segments filled from the super-tile lists + tile_end + longest-first tile order (one launch)
+int launch_tile_scatter(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st);
 int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t st);
 // loss_total[v] = sum over tiles of loss[v][tile], in a fixed order (the statistic is reproducible bit for bit)

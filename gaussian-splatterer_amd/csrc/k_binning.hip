@@ -131,33 +131,12 @@ int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int ba
 // candidate count).  With the scan of the totals this gives every block its private output range per super-tile:
 // the scatter needs LDS cursors only.
 __global__ __launch_bounds__(WG) void k_coarse_colscan(Dims d, Scratch s) {
-    const int st = blockIdx.x * (WG / 64) + (threadIdx.x >> 6), v = blockIdx.y, lane = threadIdx.x & 63;
-    if (st >= d.NST) return;
-    const int nb = (d.P + WG - 1) / WG;
-    uint32_t* col = s.wg_hist + (size_t)v * splat_blocks(d.Pa) * d.NST + st;
-    uint32_t carry = 0;
-    for (int b0 = 0; b0 < nb; b0 += 64) {
-        const int b = b0 + lane;
-        const uint32_t x = b < nb ? col[(size_t)b * d.NST] : 0u;
-        const uint32_t inc = wave_incl_scan(x);
-        if (b < nb) col[(size_t)b * d.NST] = carry + inc - x;
-        carry += (uint32_t)__shfl((int)inc, 63);
-    }
-    if (lane == 0) s.coarse_count[(size_t)v * d.NST + st] = carry;
-}
-int launch_coarse_colscan(const Dims& d, const Scratch& s, hipStream_t st) {
-    if (d.NST == 0 || d.VG == 0) return GS_OK;
-    hipLaunchKernelGGL(k_coarse_colscan, dim3((d.NST + WG / 64 - 1) / (WG / 64), d.VG), dim3(WG), 0, st, d, s);
-    GS_HIP(hipGetLastError());
-    return GS_OK;
-}
-
-// After preprocess, per geometry group: blockIdx.y == 0 turns the per-block tile sums into exclusive prefixes and
-// publishes the group's entry count (flags[2]) and the arena-overflow bit (flags[0]); blockIdx.y == 1 scans the
-// super-tile counters (unless they are too many for one workgroup: then launch_project_scans scans them separately).
-__global__ __launch_bounds__(WG) void k_project_scans(Dims d, Scratch s) {
-    const int v = blockIdx.x;
-    if (blockIdx.y == 0) {
+    const int v = blockIdx.y;
+    const int col_wgs = (d.NST + WG / 64 - 1) / (WG / 64);
+    if ((int)blockIdx.x == col_wgs) {
+        // The launch's extra workgroup: turns the per-block tile sums (k_preprocess) into exclusive prefixes and
+        // publishes the group's entry count (flags[2]) and the arena-overflow bit (flags[0]).  It needs nothing of the
+        // column scan, so it rides in the same launch (one dependent launch less per step).
         const int nb = (d.P + WG - 1) / WG;
         uint32_t* p = s.block_sums + (size_t)v * splat_blocks(d.Pa);
         uint32_t carry = 0;
@@ -174,18 +153,29 @@ __global__ __launch_bounds__(WG) void k_project_scans(Dims d, Scratch s) {
             s.flags[v * 4 + 0] = carry > d.Rcap ? 1u : 0u;  // arena too small: the later stages skip the group, the host grows and replays
             s.flags[v * 4 + 3] = 0u;  // (every flag word is rewritten each step: nothing to clear beforehand)
         }
-    } else {
-        scan_single(s.coarse_count + (size_t)v * d.NST, s.coarse_end + (size_t)v * d.NST, d.NST);
+        return;
     }
+    const int st = blockIdx.x * (WG / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (st >= d.NST) return;
+    const int nb = (d.P + WG - 1) / WG;
+    uint32_t* col = s.wg_hist + (size_t)v * splat_blocks(d.Pa) * d.NST + st;
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+        const int b = b0 + lane;
+        const uint32_t x = b < nb ? col[(size_t)b * d.NST] : 0u;
+        const uint32_t inc = wave_incl_scan(x);
+        if (b < nb) col[(size_t)b * d.NST] = carry + inc - x;
+        carry += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) s.coarse_count[(size_t)v * d.NST + st] = carry;
 }
-
-int launch_project_scans(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st) {
-    if (d.VG == 0) return GS_OK;
-    const int n = d.NST;
-    const bool fused = n <= g_scan_single_max;
-    hipLaunchKernelGGL(k_project_scans, dim3(d.VG, fused ? 2 : 1), dim3(WG), 0, st, d, s);
+// Column scan of the count matrix + (extra workgroup) the prefix of the block tile sums with the entry count and the
+// overflow verdict.  The scan of the super-tile totals that used to be a launch of its own is done by the consumer
+// (k_coarse_scatter): NST is at most MAX_SUPER_TILES, a few LDS scan trips per workgroup.
+int launch_coarse_colscan(const Dims& d, const Scratch& s, hipStream_t st) {
+    if (d.NST == 0 || d.VG == 0) return GS_OK;
+    hipLaunchKernelGGL(k_coarse_colscan, dim3((d.NST + WG / 64 - 1) / (WG / 64) + 1, d.VG), dim3(WG), 0, st, d, s);
     GS_HIP(hipGetLastError());
-    if (!fused) GS_TRY(launch_scan_u32(s.coarse_count, s.coarse_end, n, n, d.VG, partials, st));
     return GS_OK;
 }
 
@@ -201,13 +191,26 @@ __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
     const int v = blockIdx.y;
     const size_t pv = (size_t)v * d.Pa;
     {
-        const uint32_t* cend = s.coarse_end + (size_t)v * d.NST;
+        // exclusive scan of the super-tile totals (the start of every super-tile's candidate list), done by every
+        // workgroup for itself in LDS; workgroup 0 also stores the inclusive scan for the per-tile kernels
         const uint32_t* ccnt = s.coarse_count + (size_t)v * d.NST;
         const uint32_t* row = s.wg_hist + ((size_t)v * splat_blocks(d.Pa) + blockIdx.x) * d.NST;
-        for (int k = threadIdx.x; k < d.NST; k += WG) { base[k] = cend[k] - ccnt[k] + row[k]; cur[k] = 0; }
+        uint32_t* cend = s.coarse_end + (size_t)v * d.NST;
+        uint32_t carry = 0;
+        for (int k0 = 0; k0 < d.NST; k0 += WG) {
+            const int k = k0 + threadIdx.x;
+            const uint32_t c = k < d.NST ? ccnt[k] : 0u;
+            uint32_t total;
+            const uint32_t ex = carry + block_excl_scan(c, &total);
+            if (k < d.NST) {
+                base[k] = ex + row[k]; cur[k] = 0;
+                if (blockIdx.x == 0) cend[k] = ex + c;
+            }
+            carry += total;
+        }
     }
     const uint32_t tiles = i < d.P ? s.tiles_touched[pv + i] : 0u;
-    // finish the offsets scan inside the block: exclusive prefix of the block (k_project_scans) + in-block scan
+    // finish the offsets scan inside the block: exclusive prefix of the block (k_coarse_colscan's extra workgroup) + in-block scan
     const uint32_t slot_base = s.block_sums[(size_t)v * splat_blocks(d.Pa) + blockIdx.x] + block_excl_scan(tiles, nullptr);  // syncs: base/cur are ready
     if (i >= d.P) return;
     s.point_offsets[pv + i] = slot_base + tiles;
@@ -273,23 +276,106 @@ int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// longest-list-first tile order.  The per-tile kernels take tiles in this order, so the heaviest workgroups start
+// first and the tail of a launch is made of light ones (a one-camera launch is only ~3 waves of workgroups deep:
+// row-major order leaves the CUs that drew a heavy tile last running alone).  Counting sort on min(count, 1023) / 4.
+// ---------------------------------------------------------------------------------------------
+constexpr int ORDER_BINS = 256;
+// bin of a list length: 8-wide bins below 1024 entries, 64-wide bins from there to 9216 (bin boundaries fall on
+// SORT_SMALL_CAP = 2048: "long" tiles, sorted by k_tile_sort_long, are exactly the bins >= ORDER_LONG_BIN)
+__device__ inline int order_bin(uint32_t c) { return c < 1024u ? (int)(c >> 3) : min(ORDER_BINS - 1, 128 + (int)((c - 1024u) >> 6)); }
+constexpr int ORDER_LONG_BIN = 128 + (SORT_SMALL_CAP - 1024) / 64;
+// One workgroup per camera: tile_end = inclusive scan of tile_count (SCAN), tile_order, the longest list (flags[1]) and
+// the number of long tiles (flags[3]).
+template <bool SCAN>
+__device__ inline void tile_scan_order_body(const Dims& d, const Scratch& s, int v) {
+    __shared__ uint32_t hist[ORDER_BINS], start[ORDER_BINS];
+    const uint32_t* cnt = s.tile_count + (size_t)v * d.T;
+    uint32_t* order = s.tile_order + (size_t)v * d.T;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t longest = 0;
+    for (int t = threadIdx.x; t < d.T; t += WG) {
+        const uint32_t c = cnt[t];
+        longest = max(longest, c);
+        atomicAdd(&hist[ORDER_BINS - 1 - order_bin(c)], 1u);  // bin 0 = longest
+    }
+    // statistic: the longest tile list of the group (a global atomicMax per TILE cost 210 us: same-address atomics serialise)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
+    __shared__ uint32_t wmax[WG / 64];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = longest;
+    __syncthreads();
+    if (threadIdx.x == 0) s.flags[v * 4 + 1] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    if (SCAN) scan_single(cnt, s.tile_end + (size_t)v * d.T, d.T);  // tile_end: the same workgroup has the counts in cache
+    __syncthreads();
+    const uint32_t h = hist[threadIdx.x];
+    const uint32_t ex = block_excl_scan(h, nullptr);
+    start[threadIdx.x] = ex;
+    // the long tiles are the first entries of the order: publish how many there are for k_tile_sort_long
+    if (threadIdx.x == ORDER_BINS - ORDER_LONG_BIN) s.flags[v * 4 + 3] = ex;
+    __syncthreads();
+    for (int t = threadIdx.x; t < d.T; t += WG) order[atomicAdd(&start[ORDER_BINS - 1 - order_bin(cnt[t])], 1u)] = (uint32_t)t;
+}
+__global__ __launch_bounds__(WG) void k_tile_scan_order_noscan(Dims d, Scratch s) { tile_scan_order_body<false>(d, s, blockIdx.x); }
+
+// ---------------------------------------------------------------------------------------------
 // per-tile scatter: the super-tile's workgroup walks its candidates a second time and appends every (candidate, tile)
 // entry to the tile's segment [tile_end - tile_count, tile_end) — LDS cursors, no global atomics.  Entries land
 // unsorted: key (depth_bits << 32 | slot) in the not yet used gradient-row buffer (u64 index 2 * start + pos: the
 // segment doubles as the in-place area of the long-list bitonic sort), splat id in point_list.  The per-tile sort
 // then reads exactly its own entries; before, every tile re-scanned all candidates of its super-tile (16 scans).
+//
+// SELF: the launch carries one extra workgroup per camera that does the tile scan + longest-first order
+// (tile_scan_order_body) while the scatter workgroups run, and every scatter workgroup derives the starts of its own
+// 16 tile segments from tile_count itself (the exclusive prefix at its four tile rows: one pass over the counts in
+// front of it) instead of waiting for the scan as a launch of its own: two dependent launches less per step, and
+// the single-workgroup scan (14 us) disappears behind the scatter.  !SELF (images with more tiles than one workgroup
+// scans, or the "scan_single_max" test switch): tile_end comes from the separate scan launches in front.
 // ---------------------------------------------------------------------------------------------
+template <bool SELF>
 __global__ __launch_bounds__(WG) void k_tile_scatter(Dims d, Scratch s) {
     __shared__ uint32_t cur[STILE * STILE], first[STILE * STILE], big[STILE * STILE];
+    __shared__ uint32_t rowsum[STILE][WG / 64];
     const int st = blockIdx.x, v = blockIdx.y;
+    if (SELF && st == d.NST) { tile_scan_order_body<true>(d, s, v); return; }
     if (s.flags[v * 4 + 0] & 1u) return;
     const int stx = st % d.sgx, sty = st / d.sgx;
     const int tx0 = stx * STILE, ty0 = sty * STILE;
+    const uint32_t* __restrict__ cnt = s.tile_count + (size_t)v * d.T;
+    if (SELF) {
+        // exclusive prefix of tile_count at the first tile of each of this super-tile's four tile rows
+        int rs[STILE];
+#pragma unroll
+        for (int r = 0; r < STILE; r++) rs[r] = min(d.T, (ty0 + r) * d.gx + tx0);
+        uint32_t acc[STILE] = { 0, 0, 0, 0 };
+        for (int t = threadIdx.x; t < rs[STILE - 1]; t += WG) {
+            const uint32_t c = cnt[t];
+#pragma unroll
+            for (int r = 0; r < STILE; r++) acc[r] += t < rs[r] ? c : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < STILE; r++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[r] += (uint32_t)__shfl_xor((int)acc[r], o);
+            if ((threadIdx.x & 63) == 0) rowsum[r][threadIdx.x >> 6] = acc[r];
+        }
+        __syncthreads();
+    }
     if (threadIdx.x < STILE * STILE) {
-        const int tx = tx0 + (threadIdx.x % STILE), ty = ty0 + (threadIdx.x / STILE);
-        uint32_t n = 0, e = 0;
-        if (tx < d.gx && ty < d.gy) { n = s.tile_count[(size_t)v * d.T + ty * d.gx + tx]; e = s.tile_end[(size_t)v * d.T + ty * d.gx + tx]; }
-        cur[threadIdx.x] = 0; first[threadIdx.x] = e - n; big[threadIdx.x] = n > (uint32_t)SORT_LDS_CAP;  // only these take the global-scratch sort, which needs ids by slot
+        const int lx = threadIdx.x % STILE, ly = threadIdx.x / STILE;
+        const int tx = tx0 + lx, ty = ty0 + ly;
+        uint32_t n = 0, f = 0;
+        if (tx < d.gx && ty < d.gy) {
+            n = cnt[ty * d.gx + tx];
+            if (SELF) {
+                f = rowsum[ly][0] + rowsum[ly][1] + rowsum[ly][2] + rowsum[ly][3];
+                for (int x = 0; x < lx; x++) f += cnt[ty * d.gx + tx0 + x];
+            } else {
+                f = s.tile_end[(size_t)v * d.T + ty * d.gx + tx] - n;
+            }
+        }
+        cur[threadIdx.x] = 0; first[threadIdx.x] = f; big[threadIdx.x] = n > (uint32_t)SORT_LDS_CAP;  // only these take the global-scratch sort, which needs ids by slot
     }
     __syncthreads();
     const size_t c0 = (size_t)v * d.NST + st;
@@ -319,63 +405,17 @@ __global__ __launch_bounds__(WG) void k_tile_scatter(Dims d, Scratch s) {
     }
 }
 
-int launch_tile_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
-    if (d.NST == 0 || d.VG == 0) return GS_OK;
-    hipLaunchKernelGGL(k_tile_scatter, dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
-    GS_HIP(hipGetLastError());
-    return GS_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// longest-list-first tile order.  The per-tile kernels take tiles in this order, so the heaviest workgroups start
-// first and the tail of a launch is made of light ones (a one-camera launch is only ~3 waves of workgroups deep:
-// row-major order leaves the CUs that drew a heavy tile last running alone).  Counting sort on min(count, 1023) / 4.
-// ---------------------------------------------------------------------------------------------
-constexpr int ORDER_BINS = 256;
-// bin of a list length: 8-wide bins below 1024 entries, 64-wide bins from there to 9216 (bin boundaries fall on
-// SORT_SMALL_CAP = 2048: "long" tiles, sorted by k_tile_sort_long, are exactly the bins >= ORDER_LONG_BIN)
-__device__ inline int order_bin(uint32_t c) { return c < 1024u ? (int)(c >> 3) : min(ORDER_BINS - 1, 128 + (int)((c - 1024u) >> 6)); }
-constexpr int ORDER_LONG_BIN = 128 + (SORT_SMALL_CAP - 1024) / 64;
-template <bool SCAN>
-__global__ __launch_bounds__(WG) void k_tile_scan_order(Dims d, Scratch s) {
-    __shared__ uint32_t hist[ORDER_BINS], start[ORDER_BINS];
-    const int v = blockIdx.x;
-    const uint32_t* cnt = s.tile_count + (size_t)v * d.T;
-    uint32_t* order = s.tile_order + (size_t)v * d.T;
-    hist[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t longest = 0;
-    for (int t = threadIdx.x; t < d.T; t += WG) {
-        const uint32_t c = cnt[t];
-        longest = max(longest, c);
-        atomicAdd(&hist[ORDER_BINS - 1 - order_bin(c)], 1u);  // bin 0 = longest
-    }
-    // statistic: the longest tile list of the group (a global atomicMax per TILE cost 210 us: same-address atomics serialise)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
-    __shared__ uint32_t wmax[WG / 64];
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = longest;
-    __syncthreads();
-    if (threadIdx.x == 0) s.flags[v * 4 + 1] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-    if (SCAN) scan_single(cnt, s.tile_end + (size_t)v * d.T, d.T);  // tile_end: the same workgroup has the counts in cache
-    __syncthreads();
-    const uint32_t h = hist[threadIdx.x];
-    const uint32_t ex = block_excl_scan(h, nullptr);
-    start[threadIdx.x] = ex;
-    // the long tiles are the first entries of the order: publish how many there are for k_tile_sort_long
-    if (threadIdx.x == ORDER_BINS - ORDER_LONG_BIN) s.flags[v * 4 + 3] = ex;
-    __syncthreads();
-    for (int t = threadIdx.x; t < d.T; t += WG) order[atomicAdd(&start[ORDER_BINS - 1 - order_bin(cnt[t])], 1u)] = (uint32_t)t;
-}
-// tile_end = inclusive scan of tile_count, tile_order = tiles by descending count; one launch unless the scan is too long
-int launch_tile_scan_order(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st) {
-    if (d.T == 0 || d.VG == 0) return GS_OK;
+// Per-tile segments + tile_end (inclusive scan of tile_count) + tile_order (tiles by descending count) — one launch.
+// Only when the tile count exceeds what one workgroup scans are the scan (three phases) and the order launches of their own.
+int launch_tile_scatter(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st) {
+    if (d.NST == 0 || d.VG == 0 || d.T == 0) return GS_OK;
     static_assert(ORDER_BINS == WG, "one bin per thread");
     if (d.T <= g_scan_single_max) {
-        hipLaunchKernelGGL(k_tile_scan_order<true>, dim3(d.VG), dim3(WG), 0, st, d, s);
+        hipLaunchKernelGGL(k_tile_scatter<true>, dim3(d.NST + 1, d.VG), dim3(WG), 0, st, d, s);
     } else {
         GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.VG, partials, st));
-        hipLaunchKernelGGL(k_tile_scan_order<false>, dim3(d.VG), dim3(WG), 0, st, d, s);
+        hipLaunchKernelGGL(k_tile_scan_order_noscan, dim3(d.VG), dim3(WG), 0, st, d, s);
+        hipLaunchKernelGGL(k_tile_scatter<false>, dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
     }
     GS_HIP(hipGetLastError());
     return GS_OK;
@@ -542,7 +582,6 @@ __global__ __launch_bounds__(LONG_NT) void k_tile_sort_long(Dims d, Scratch s) {
 
 int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.T == 0 || d.VG == 0) return GS_OK;
-    GS_TRY(launch_tile_scatter(d, s, st));
     hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T, d.VG), dim3(WG), 0, st, d, s);
     // one long-list workgroup fills a CU (96 KB LDS): about one per CU over all cameras
     const int per_cam = std::min(d.T, std::max(16, std::min(256, 256 / std::max(d.VG, 1))));

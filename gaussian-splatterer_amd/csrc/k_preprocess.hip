@@ -196,7 +196,7 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
     __syncthreads();
     uint32_t n = 0;
     if (i < d.P) n = preprocess_one<D>(d, params, s, i, v, hist);
-    // the block's share of the offsets scan (k_project_scans turns the block sums into prefixes, the coarse
+    // the block's share of the offsets scan (k_coarse_colscan's extra workgroup turns the block sums into prefixes, the coarse
     // scatter finishes the scan inside each block): no separate pass over tiles_touched
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
