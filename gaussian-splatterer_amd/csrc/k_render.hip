@@ -7,18 +7,21 @@
 //   * workgroup = one 16x16 tile = 4 wave64; each WAVE owns an 8x8 pixel block, lane = pixel.
 //   * the tile's depth-ordered list is staged through LDS (48-byte records gathered from the
 //     64-byte per-splat lines written by preprocess, conic pre-scaled to base 2): 256 entries per round
-//     forward, 64 (two passes fused) or 128 backward (22-25 KB of LDS per workgroup, 7 / 6 workgroups per CU).
+//     forward, 64 backward (12.6 - 22 KB of LDS per workgroup, 8 / 7 waves per SIMD).
 //   * workgroups take tiles longest list first (tile_order), so a launch ends on light tiles.
 //   * per 64 staged entries every lane tests ONE entry's "alpha >= 1/255" box against the wave's
 //     8x8 block; the ballot is a scalar bit list and only surviving entries are evaluated — the
 //     skipped pairs are exactly ones the reference blend would skip too, so results are unchanged.
-//     The next surviving entry's record is read from LDS while the current one is evaluated.
+//     (Reading the next surviving entry's record one iteration early was measured slower: at 8 waves
+//     per SIMD the LDS latency is covered and the extra selects cost issue slots.)
 //   * backward: the nine per-pair partial derivatives are reduced across the 64 lanes by a DPP
 //     reduce-scatter (24 VALU instructions instead of 54: every stage halves the number of live
 //     values; bank masks give the per-lane value selection for free; the four 16-lane rows are folded
 //     by two ds_bpermute on the LDS pipe), each wave parks its sums in
 //     its own LDS slot, the four slots are added in fixed order and written as ONE 36-byte row per
 //     (splat,tile) entry.  No global atomic anywhere; the result is bitwise reproducible.
+//     A step without densify runs this once per CAMERA on the sum of its passes' residual images
+//     (render_bwd_body<1, 2>), not once per pass.
 #include "gs_internal.h"
 
 namespace gs {
