@@ -99,3 +99,24 @@ def test_pcg32_reference_vector_and_ranges():
     a = gs.synth.random_splats(100, 4, 7)
     b = gs.synth.random_splats(100, 4, 7)
     assert all(np.array_equal(a[k], b[k]) for k in ("loc", "sh", "scale", "opac", "rot"))
+
+
+def test_source_stamp_ignores_comments_only(tmp_path):
+    """tools/source_stamp.py identifies the kernel sources a counter collection belongs to: a comment or white-space edit
+    keeps the stamp, a code edit changes it (bench.py reports counters only for matching stamps)."""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_stamp import source_stamp
+    root = tmp_path / "r"
+    shutil.copytree(os.path.join(ROOT, "gaussian-splatterer_amd", "csrc"), root / "gaussian-splatterer_amd" / "csrc", ignore=shutil.ignore_patterns("_obj", "*.o"))
+    os.makedirs(root / "include")
+    shutil.copy(os.path.join(ROOT, "include", "gsplat.h"), root / "include" / "gsplat.h")
+    base = source_stamp(str(root))
+    assert base == source_stamp(ROOT)
+    f = root / "gaussian-splatterer_amd" / "csrc" / "k_update.hip"
+    text = f.read_text()
+    f.write_text("// a new comment\n" + text.replace("\n", "\n   ", 3) + "\n/* trailing\n block */\n")
+    assert source_stamp(str(root)) == base
+    f.write_text(text.replace("1.0f - u.b1", "1.0f - u.b2", 1))
+    assert source_stamp(str(root)) != base
