@@ -182,6 +182,26 @@ def main():
     capi.check(L.gs_trainer_stage_times(tr.handle, ms, launches))
     capi.check(L.gs_trainer_set_profiling(tr.handle, 0))
     st = tr.train(proj, densify=False, stats=True) if st is None else st
+    # untimed, reported separately: the same steps in the per-pass form (option "fuse_camera_passes" off: one backward per
+    # PASS, `var` produced on every step like the reference's accumulateGradients does), so that the cost of the dead
+    # value the default step does not compute is on record
+    per_pass = None
+    if not use_dist:
+        capi.check(L.gs_set_option(b"fuse_camera_passes", 0))
+        try:
+            for _ in range(3):
+                tr.train(proj, densify=False)
+            tr.synchronize()
+            n_pp = max(10, min(args.steps, 30))
+            t_pp = time.perf_counter()
+            for _ in range(n_pp):
+                tr.train(proj, densify=False)
+            tr.synchronize()
+            per_pass = {"value": n_pp / (time.perf_counter() - t_pp), "unit": "steps/s", "steps": n_pp,
+                        "note": "gs_set_option('fuse_camera_passes', 0): one backward per pass and `var` on every step (what a densify step runs); "
+                                "measured after the timed region"}
+        finally:
+            capi.check(L.gs_set_option(b"fuse_camera_passes", 1))
     # untimed, reported separately: one step WITH densify/prune, as the driver loop runs every 200th iteration
     densify_ms = None
     if not use_dist:
@@ -290,6 +310,7 @@ def main():
                          "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
             "stages_note": "all-stage table: HIP events over %d extra steps run after the timed region (timing every stage costs ~3 us of stream time per event)" % min(args.steps, 10),
+            "per_pass_form": per_pass,
             "densify_step": None if densify_ms is None else {"ms": round(densify_ms, 3), "count_before": st_d.count_before, "count_after": st_d.count_after,
                              "note": "one extra step with densify/prune after the timed region (the driver loop does this every 200th iteration); includes the step itself"},
             "setup_seconds": round(setup_s, 2),

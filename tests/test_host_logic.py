@@ -120,3 +120,13 @@ def test_source_stamp_ignores_comments_only(tmp_path):
     assert source_stamp(str(root)) == base
     f.write_text(text.replace("1.0f - u.b1", "1.0f - u.b2", 1))
     assert source_stamp(str(root)) != base
+
+
+def test_cpp_shim_and_its_reference_call_sites_compile():
+    """include/gsplat_shim.hpp + the program that uses it exactly like the reference's UI does (tests/cpp/shim_step.cpp:
+    `delete trainer->model; trainer->model = new ...`, `train(project, densify)`, `render(fb, w, h, scale, camera)`,
+    `truthCameras`) compile with a plain host compiler (the run itself needs the GPU: tests/test_gpu_shim.py)."""
+    import subprocess
+    for src in ("shim_step.cpp", "extras_cpu.cpp"):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", src)])
