@@ -318,6 +318,7 @@ __device__ inline void tile_scan_order_body(const Dims& d, const Scratch& s, int
     for (int t = threadIdx.x; t < d.T; t += WG) order[atomicAdd(&start[ORDER_BINS - 1 - order_bin(cnt[t])], 1u)] = (uint32_t)t;
 }
 __global__ __launch_bounds__(WG) void k_tile_scan_order_noscan(Dims d, Scratch s) { tile_scan_order_body<false>(d, s, blockIdx.x); }
+__global__ __launch_bounds__(WG) void k_tile_scan_order_scan(Dims d, Scratch s) { tile_scan_order_body<true>(d, s, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------
 // per-tile scatter: the super-tile's workgroup walks its candidates a second time and appends every (candidate, tile)
@@ -410,8 +411,13 @@ __global__ __launch_bounds__(WG) void k_tile_scatter(Dims d, Scratch s) {
 int launch_tile_scatter(const Dims& d, const Scratch& s, uint32_t* partials, hipStream_t st) {
     if (d.NST == 0 || d.VG == 0 || d.T == 0) return GS_OK;
     static_assert(ORDER_BINS == WG, "one bin per thread");
-    if (d.T <= g_scan_single_max) {
+    // every scatter workgroup of the one-launch form reads the tile counts in front of its rows: T / 2 words on average,
+    // 64 MB per camera at 2048 x 2048 (T = 16384) — beyond that the separate scan is cheaper than the repeated reads
+    if (d.T <= g_scan_single_max && d.T <= 16384) {
         hipLaunchKernelGGL(k_tile_scatter<true>, dim3(d.NST + 1, d.VG), dim3(WG), 0, st, d, s);
+    } else if (d.T <= g_scan_single_max) {
+        hipLaunchKernelGGL(k_tile_scan_order_scan, dim3(d.VG), dim3(WG), 0, st, d, s);
+        hipLaunchKernelGGL(k_tile_scatter<false>, dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
     } else {
         GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.VG, partials, st));
         hipLaunchKernelGGL(k_tile_scan_order_noscan, dim3(d.VG), dim3(WG), 0, st, d, s);

@@ -400,6 +400,35 @@ def test_scan_forms_agree(orc):
         assert np.array_equal(res[0][3][k].view(np.uint32), res[1][3][k].view(np.uint32)), k
 
 
+def test_images_beyond_16384_tiles_take_the_separate_tile_scan(orc):
+    """Up to 16384 tiles (2048 x 2048) the tile scan + order ride in the tile-scatter launch and every scatter workgroup
+    derives its segment starts itself; beyond, the scan is a launch of its own (and beyond "scan_single_max" tiles a
+    three-phase one).  2064 x 2064 = 129 x 129 tiles takes the middle form: same bits as the three-phase form."""
+    P, M, n_cams, W, H = 1500, 4, 1, 2064, 2064
+    s = gs.synth.random_splats(P, M, 77)
+    cams = gs.camera.get_cameras(n_cams)
+    rng = np.random.default_rng(2)
+    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32)]
+    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32)]
+    res = []
+    for limit in (0, 4096):
+        capi.check(capi.lib().gs_set_option(b"scan_single_max", limit))
+        try:
+            host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+            host.shDegree = s["D"]
+            tr = gs.Trainer(W, H)
+            tr.model = gs.ModelSplatsDevice(host)
+            tr.captureTruths(cams, fw, fb)
+            st = tr.train(gs.Project(), stats=True)
+            res.append((st.num_rendered, st.max_tile_list, st.loss, _read_grads(tr, P, M)))
+            tr.close()
+        finally:
+            capi.check(capi.lib().gs_set_option(b"scan_single_max", 0))
+    assert res[0][:3] == res[1][:3] and res[0][0] > 0
+    for k in res[0][3]:
+        assert np.array_equal(res[0][3][k].view(np.uint32), res[1][3][k].view(np.uint32)), k
+
+
 def test_steps_without_stats_run_ahead_and_agree(orc):
     """gs_trainer_step without a stats request returns while the device is still working (the host only waits for the
     early overflow verdict).  Six such steps back to back must leave exactly the model that six observed steps leave,
