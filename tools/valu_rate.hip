@@ -58,6 +58,42 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
             REP16(asm volatile("v_permlane16_swap_b32_e32 %0, %1\n v_permlane16_swap_b32_e32 %2, %3\n v_permlane16_swap_b32_e32 %0, %2\n v_permlane16_swap_b32_e32 %1, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
         } else if (KIND == 13) {  // swap + dependent add (the reduce-scatter step)
             REP16(asm volatile("v_permlane32_swap_b32_e32 %0, %1\n v_add_f32 %0, %0, %1\n v_permlane32_swap_b32_e32 %2, %3\n v_add_f32 %2, %2, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == 14) {  // 8 INDEPENDENT full-mask DPP adds (a dependent one only every 8 instructions)
+            REP4(asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_ror:12 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xf"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+                 asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_ror:12 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xf"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (KIND == 15) {  // the same with bank-masked writes (the reduce-scatter's stage A / B form)
+            REP4(asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                              "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n v_add_f32_dpp %3, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+                              "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n v_add_f32_dpp %5, %5, %5 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+                              "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n v_add_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+                 asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                              "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n v_add_f32_dpp %3, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+                              "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n v_add_f32_dpp %5, %5, %5 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+                              "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n v_add_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (KIND == 16) {  // 8 independent plain adds, same structure
+            REP4(asm volatile("v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n v_add_f32 %4, %4, %4\n v_add_f32 %5, %5, %5\n v_add_f32 %6, %6, %6\n v_add_f32 %7, %7, %7"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+                 asm volatile("v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n v_add_f32 %4, %4, %4\n v_add_f32 %5, %5, %5\n v_add_f32 %6, %6, %6\n v_add_f32 %7, %7, %7"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (KIND == 17) {  // v_mov_b32_dpp (move only) + separate plain add: the two-instruction alternative
+            REP4(asm volatile("v_mov_b32_dpp %4, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+                              "v_mov_b32_dpp %6, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %3 row_ror:12 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %6\n v_add_f32 %3, %3, %7"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+                 asm volatile("v_mov_b32_dpp %4, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+                              "v_mov_b32_dpp %6, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %3 row_ror:12 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %6\n v_add_f32 %3, %3, %7"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
         } else if (KIND == 10) {  // ds_read_b128 broadcast (uniform address)
             __shared__ float4 sm[256];
             if (i == 0) sm[threadIdx.x] = make_float4(a0, a1, a2, a3);
@@ -106,6 +142,10 @@ int main() {
         run<11>("v_permlane32_swap", 64, w);
         run<12>("v_permlane16_swap", 64, w);
         run<13>("swap32 + dependent add", 64, w);
+        run<14>("dpp add, 8 independent", 64, w);
+        run<15>("dpp add bank-masked, 8 indep", 64, w);
+        run<16>("plain add, 8 independent", 64, w);
+        run<17>("mov_dpp + plain add (counts both)", 64, w);
     }
     return 0;
 }
