@@ -265,3 +265,42 @@ def test_uniform_scaling_of_scene_and_camera_leaves_the_image_unchanged(orc):
     assert imgs[0].std() > 0.01
     # not 1e-9: upstream divides by (w + 1e-7), and that epsilon does not scale with the scene (1e-8 relative at w = 10)
     assert np.abs(imgs[0] - imgs[1]).max() < 2e-6
+
+
+def test_sh_basis_is_an_orthonormal_real_sh_basis(orc):
+    """Source-independent pin of the colour model: with SH coefficient k set to 1/2 (others 0) the oracle's colour is
+    0.5 + Y_k(direction) / 2 (never negative, so never clamped), so probing it over the whole sphere gives the sixteen
+    basis functions the path uses.  They must be orthonormal under the sphere's surface measure (the real spherical
+    harmonics up to sign and order: wrong constants or polynomials break this), and the degree-0 / degree-1 ones have
+    the closed forms 1/(2 sqrt(pi)) and sqrt(3/(4 pi)) * {y, z, x} up to sign."""
+    n = 4000
+    pts = gs.camera.fibonacci_sphere(n, 3.0).astype(np.float64)          # quasi-uniform quadrature nodes, radius 3
+    dirs = pts / np.linalg.norm(pts, axis=1, keepdims=True)
+    M, W, H = 16, 64, 64
+    Y = np.full((n, M), np.nan)
+    # six cube-face cameras at the origin (tan 1.3 > 1: every direction is inside some frustum).  view = an orthonormal
+    # frame whose +z is the face normal; the projection only has to put the splat inside the image.
+    I3 = np.eye(3)
+    faces = [np.stack([I3[(a + 1) % 3], I3[(a + 2) % 3], sgn * I3[a]]) for a in range(3) for sgn in (1.0, -1.0)]
+    tan = 1.3
+    col = lambda m: np.ascontiguousarray(m.T.reshape(-1), np.float32)     # glm column-major
+    for Rw in faces:
+        view = np.eye(4); view[:3, :3] = Rw
+        proj = np.zeros((4, 4)); proj[0, 0] = 1 / tan; proj[1, 1] = 1 / tan; proj[2, 2] = 1.0; proj[3, 2] = 1.0
+        pv = proj @ view
+        for k in range(M):
+            sh = np.zeros((n, M, 3), np.float32); sh[:, k, :] = 0.5
+            r = orc.Rasterizer(np.float32)
+            r.forward(3, M, np.zeros(3, np.float32), W, H, pts.astype(np.float32), sh, np.full(n, 0.5, np.float32),
+                      np.full(3 * n, 0.05, np.float32), 1.0, np.tile(np.array([1, 0, 0, 0], np.float32), n), col(view), col(pv),
+                      np.zeros(3, np.float32), tan, tan)
+            vis = r.get("radii") > 0
+            assert not r.get("clamped")[np.repeat(vis, 3)].any()
+            Y[vis, k] = (r.get("rgb").reshape(n, 3)[vis, 0].astype(np.float64) - 0.5) * 2.0
+    assert not np.isnan(Y).any()                                          # the six frusta cover the sphere
+    gram = (4.0 * math.pi / n) * (Y.T @ Y)
+    assert np.abs(gram - np.eye(M)).max() < 5e-3, np.abs(gram - np.eye(M)).max()
+    assert np.allclose(Y[:, 0], 0.5 / math.sqrt(math.pi), atol=1e-6)
+    c1 = math.sqrt(3.0 / (4.0 * math.pi))
+    for k, axis in ((1, 1), (2, 2), (3, 0)):                               # |Y_1..3| = c1 * |y|, |z|, |x|
+        assert np.allclose(np.abs(Y[:, k]), c1 * np.abs(dirs[:, axis]), atol=2e-6), k
