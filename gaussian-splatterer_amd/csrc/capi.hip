@@ -303,6 +303,19 @@ extern "C" int gs_debug_wave_reduce9(const float* in_host, float* out_host) {
     return rc;
 }
 
+extern "C" int gs_debug_group8_reduce9(const float* in_host, float* out_host) {
+    if (!in_host || !out_host) return GS_ERR_INVALID_ARGUMENT;
+    GS_TRY(require_device());
+    float *din = nullptr, *dout = nullptr;
+    GS_HIP(hipMalloc((void**)&din, 9 * 64 * 4));
+    GS_HIP(hipMalloc((void**)&dout, 128 * 4));
+    GS_HIP(hipMemcpy(din, in_host, 9 * 64 * 4, hipMemcpyHostToDevice));
+    int rc = launch_debug_group8(din, dout, 0);
+    if (rc == GS_OK && hipMemcpy(out_host, dout, 128 * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = GS_ERR_HIP;
+    (void)hipFree(din); (void)hipFree(dout);
+    return rc;
+}
+
 extern "C" int gs_hyper_defaults(gs_hyper* h) {
     if (!h) return GS_ERR_INVALID_ARGUMENT;
     h->lr_location = 0.00005f; h->lr_sh = 0.0001f; h->lr_scale = 0.00002f; h->lr_opacity = 0.0001f; h->lr_rotation = 0.000025f;

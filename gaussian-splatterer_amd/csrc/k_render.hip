@@ -35,7 +35,7 @@ constexpr int BWD_ROUND = 128;  // entries staged per backward round
 #define GS_BWD_ROUND_PAIR 64  // fused-pair kernel (tuning hook): 64 entries, 12.6 KB LDS and 64 VGPRs -> 8 waves per SIMD
 #endif                        // measured 0.903 ms per 16-view launch against 0.938 at 128 entries / 6 waves
 #ifndef GS_BWD_PAIR_WAVES
-#define GS_BWD_PAIR_WAVES 8
+#define GS_BWD_PAIR_WAVES 7
 #endif
 #ifndef GS_BWD_ROUND_K2
 #define GS_BWD_ROUND_K2 (BWD_ROUND / 2)  // tuning hook (tools/build_variant.sh)
@@ -298,6 +298,121 @@ int launch_debug_reduce9(const float* in, float* out, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// pixel sums by LDS hand-off (single gradient set: the step's fused-pair kernel and the rasterizer seam)
+// ---------------------------------------------------------------------------------------------
+// The nine per-(entry, 8x8 block) sums are contractions over the block's 64 pixels of two per-pixel values,
+//   w = alpha * T (with the per-pixel constant dL/dpixel)   and   u = G * dL/dalpha (with 1, dx, dy, dx^2, dx dy, dy^2).
+// A hit therefore parks only (w, u) of its 64 lanes in a per-wave LDS buffer (one ds_write2_b32) and goes on; after
+// BATCH = 8 hits the wave contracts the buffer with PLAIN fp32 FMAs: lane (hit h = lane / 8, pixel row r = lane % 8)
+// reads the eight pixels of row r of hit h (eight conflict-free ds_read_b64: the hit stride of 520 bytes puts the 32
+// lanes of a half wave on 32 different 8-byte bank pairs), forms the row's partial sums — dy is constant along a row,
+// so only  sum u, sum u dx, sum u dx^2  and the three colour sums are accumulated per pixel (8 VALU per pixel) — and the
+// eight rows of a hit are folded by a 20-instruction DPP reduce-scatter over 8 lanes.  Per hit that is ~8 full-rate
+// VALU + 2.5 DPP instead of the 9 multiplies + 24 half-rate DPP adds + 2 ds_bpermute of wave_reduce_scatter9_rows
+// (still used by the two-gradient-set kernel), measured in profiles/r03/.
+#ifndef GS_PARK_BATCH
+#define GS_PARK_BATCH 4                   // tuning hook: 8 = 8 lanes x 8 pixels per hit (16.6 KB, 5 waves/SIMD), 4 = 16 lanes x 4 pixels (8.3 KB, 7 waves/SIMD)
+#endif
+constexpr int PARK_BATCH = GS_PARK_BATCH; // hits per contraction
+constexpr int PARK_LPH = 64 / PARK_BATCH; // lanes per hit
+constexpr int PARK_PPL = 64 / PARK_LPH;   // pixels per lane: consecutive pixels of one row of the 8x8 block
+static_assert(PARK_BATCH == 4 || PARK_BATCH == 8, "a hit's 64 pixels go to 16 or 8 lanes");
+constexpr int PARK_STRIDE = 2 * 64 + 2;   // floats per parked hit: w[64] | u[64] | 8 bytes of padding (conflict-free ds_read_b64)
+
+// Reduce-scatter of eight per-lane values over every group of 8 consecutive lanes, plus the group total of a ninth.
+// Returns r such that lane (8h + r) holds the group-h total of value q(r) = (r & 4) + ((r >> 1) & 1) + 2 * (r & 1);
+// s8 comes back as the group total in every lane.  EXEC must be all ones.
+__device__ inline float group8_reduce_scatter9(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7,
+                                               float& s8) {
+    float t0, t1;
+    const unsigned long long mask_bit1 = 0xCCCCCCCCCCCCCCCCull;  // lanes with bit 1 set
+    const unsigned long long mask_bit0 = 0xAAAAAAAAAAAAAAAAull;  // lanes with bit 0 set
+    asm volatile(
+        "s_nop 1\n\t"
+        // stage A, lane ^ 4: banks 0,2 (bit2 = 0) keep s0..s3, banks 1,3 keep s4..s7 (bank_mask selects, no v_cndmask)
+        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        // stage B, lane ^ 2: bit1 ? keep the odd one of a pair, send the even one : the other way round
+        "v_cndmask_b32_e64 %9, %0, %1, %11\n\t"
+        "v_cndmask_b32_e64 %10, %1, %0, %11\n\t"
+        "v_cndmask_b32_e64 %4, %2, %3, %11\n\t"
+        "v_cndmask_b32_e64 %5, %3, %2, %11\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %9, %10, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %5, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        // stage C, lane ^ 1
+        "v_cndmask_b32_e64 %10, %9, %4, %12\n\t"
+        "v_cndmask_b32_e64 %5, %4, %9, %12\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %10, %5, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7), "+v"(s8), "=&v"(t0), "=&v"(t1)
+        : "s"(mask_bit1), "s"(mask_bit0));
+    return t1;
+}
+
+// debug entry: one wave, in[q][lane] -> out[lane] = group8_reduce_scatter9(...), out[64 + lane] = s8 (tests/test_gpu_raster.py)
+__global__ void k_debug_group8(const float* __restrict__ in, float* __restrict__ out) {
+    const int l = threadIdx.x;
+    float s8 = in[512 + l];
+    out[l] = group8_reduce_scatter9(in[l], in[64 + l], in[128 + l], in[192 + l], in[256 + l], in[320 + l], in[384 + l], in[448 + l], s8);
+    out[64 + l] = s8;
+}
+int launch_debug_group8(const float* in, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_debug_group8, dim3(1), dim3(64), 0, st, in, out);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// Contracts the wave's parked hits (nb <= PARK_BATCH of them; entry indices packed 8 bits apiece in blo | bhi) and stores
+// the nine sums of every hit in the wave's accumulator slots acc[entry * ACC_STRIDE + q].
+//   dpr[c][i]  dL/dpixel channel c of pixel (row lane % 8, column i) of the wave's block;  pxcol0 = x of column 0;
+//   pyrow      y of this lane's row.
+template <int N>
+__device__ __forceinline__ void contract_parked(const float* __restrict__ park, const StagedTile<N>& st, float* __restrict__ acc, int nb,
+                                                uint32_t blo, uint32_t bhi, const float (&dpr)[3][PARK_PPL], float pxcol0, float pyrow, int lane) {
+    const int h = lane / PARK_LPH, sub = lane % PARK_LPH;
+    const int jj = (int)__builtin_amdgcn_ubfe((PARK_BATCH == 4 || h < 4) ? blo : bhi, (uint32_t)(8 * (h & 3)), 8u);
+    const float2 xy = *reinterpret_cast<const float2*>(&st.A[jj]);
+    const float2* row = reinterpret_cast<const float2*>(park + h * PARK_STRIDE + sub * PARK_PPL);
+    float w[PARK_PPL], u[PARK_PPL];
+#pragma unroll
+    for (int k = 0; k < PARK_PPL / 2; k++) { const float2 t = row[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
+#pragma unroll
+    for (int k = 0; k < PARK_PPL / 2; k++) { const float2 t = row[32 + k]; u[2 * k] = t.x; u[2 * k + 1] = t.y; }
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PARK_PPL; i++) {
+        const float dx = xy.x - (pxcol0 + (float)i);  // the same difference the hit formed for this pixel
+        const float ux = u[i] * dx;
+        m0 += u[i]; m1 += ux; m2 = fmaf(ux, dx, m2);
+        a0 = fmaf(w[i], dpr[0][i], a0); a1 = fmaf(w[i], dpr[1][i], a1); a2 = fmaf(w[i], dpr[2][i], a2);
+    }
+    const float dy = xy.y - pyrow;
+    const float m0y = m0 * dy;
+    // order of the nine sums as everywhere else: colour(3), u dx, u dy, u dx dx, u dx dy, u dy dy, u
+    if constexpr (PARK_BATCH == 8) {
+        float s8 = m0;
+        const float red = group8_reduce_scatter9(a0, a1, a2, m1, m0y, m2, m1 * dy, m0y * dy, s8);
+        if (h < nb) {
+            const int q = (sub & 4) + ((sub >> 1) & 1) + 2 * (sub & 1);
+            acc[jj * ACC_STRIDE + q] = red;
+            if (sub == 0) acc[jj * ACC_STRIDE + 8] = s8;
+        }
+    } else {
+        const float red = wave_reduce_scatter9_rows(a0, a1, a2, m1, m0y, m2, m1 * dy, m0y * dy, m0);  // per 16-lane row: lane 2q -> q, lane 1 -> 8
+        if (h < nb && ((sub & 1) == 0 || sub == 1)) acc[jj * ACC_STRIDE + ((sub & 1) ? 8 : (sub >> 1))] = red;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
 // One workgroup = one tile of one camera, the passes of that camera at once (the reference's white- and
@@ -318,8 +433,10 @@ template <int K, int F>
 __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s, const int* __restrict__ items) {
 #pragma clang fp contract(fast)
     static_assert(K * F <= 2, "an item carries two passes");
-    constexpr int ROUND = (K == 2) ? GS_BWD_ROUND_K2 : (F == 2 ? GS_BWD_ROUND_PAIR : BWD_ROUND);  // entries staged per round
+    constexpr bool PARK = (K == 1);  // one gradient set: pixel sums by LDS hand-off + FMA contraction (contract_parked)
+    constexpr int ROUND = (K == 2) ? GS_BWD_ROUND_K2 : GS_BWD_ROUND_PAIR;  // entries staged per round
     __shared__ StagedTile<ROUND> st;
+    __shared__ __attribute__((aligned(16))) float sPark[PARK ? 4 * PARK_BATCH * PARK_STRIDE : 1];
     __shared__ uint32_t sSlot[ROUND];
     __shared__ float sAcc[K * 4 * ROUND * ACC_STRIDE];
     __shared__ unsigned long long sTouched[4][(ROUND + 63) / 64];
@@ -388,6 +505,9 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
     uint32_t wave_max_last = last_contributor;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wave_max_last = max(wave_max_last, (uint32_t)__shfl_xor((int)wave_max_last, o));
+    // tell the compiler it is wave-uniform: branches on it become scalar, and what they guard (batch counter, touched bits)
+    // stays in SGPRs
+    wave_max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_last);
     if (lane == 0) atomicMax(&sMaxLast, wave_max_last);
     if (s.loss && !s.dL_dpix) {
 #pragma unroll
@@ -420,6 +540,24 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
     const int wslot = (lane & 1) ? 8 : (lane >> 1);
     const int fold16 = (lane ^ 16) << 2, fold32 = (lane ^ 32) << 2;  // ds_bpermute byte addresses of the row partners
     float* const acc_lane = &sAcc[wave * ROUND * ACC_STRIDE + wslot];  // this lane's column of the wave's slots
+    // hand-off form: the wave's parking area, and dL/dpixel of the eight pixels of row (lane % 8) for the contraction
+    float* const park = &sPark[PARK ? wave * PARK_BATCH * PARK_STRIDE : 0];
+    float dpr[3][PARK_PPL];
+    const int psub = lane % PARK_LPH;  // this lane's pixels in a contraction: psub * PARK_PPL .. + PARK_PPL - 1 of the block (row-major)
+    if constexpr (PARK) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) park[c * 64 + lane] = dpx[0][c];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int i = 0; i < PARK_PPL; i++) dpr[c][i] = park[c * 64 + psub * PARK_PPL + i];
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float pyrow = (float)(by0 + ((psub * PARK_PPL) >> 3));
+    const float pxcol0 = (float)(bx0 + ((psub * PARK_PPL) & 7));
+    int nb = 0;                     // hits parked and not yet contracted (wave-uniform)
+    unsigned long long bidx = 0ull;  // their entry indices, 8 bits apiece
 
     for (int r = rounds - 1; r >= 0; r--) {
         const int base = r * ROUND;
@@ -444,7 +582,8 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
                 hit = block_reaches(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
             }
             unsigned long long mask = __ballot(hit);
-            while (mask) {
+            for (;;) {
+              if (mask != 0ull) {
                 const int kk = 63 - __clzll((long long)mask);
                 mask &= ~(1ull << kk);
                 const int jj = sub + kk;
@@ -487,7 +626,16 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
                         u[p] = dL * GT + tfbg[p] * Gi;  // G * (dL_dalpha * T + tfbg / (1 - alpha)),  tfbg = -T_final * (bg . dL_dpix)
                     }
                 }
-                if (any_act != 0ull) {
+                if constexpr (PARK) {
+                    if (any_act != 0ull) {
+                        // inactive lanes park exact zeros: dchannel_dcolor = u = 0 there
+                        park[nb * PARK_STRIDE + lane] = dchannel_dcolor;
+                        park[nb * PARK_STRIDE + 64 + lane] = u[0];
+                        bidx |= (unsigned long long)jj << (8 * nb);
+                        touched[sb] |= 1ull << kk;
+                        nb++;
+                    }
+                } else if (any_act != 0ull) {
                     // inactive lanes contribute exact zeros: dchannel_dcolor = u = 0 there
 #pragma unroll
                     for (int p = 0; p < K; p++) {
@@ -500,6 +648,18 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
                     }
                     touched[sb] |= 1ull << kk;
                 }
+              }
+              if constexpr (PARK) {
+                // ONE contraction site: a full batch, or the round's last, partly filled one (sub-block 0 is the last one
+                // walked; its entries are flushed and st restaged right after)
+                if (nb == PARK_BATCH || (mask == 0ull && sb == 0 && nb != 0)) {
+                    __builtin_amdgcn_wave_barrier();
+                    contract_parked(park, st, &sAcc[wave * ROUND * ACC_STRIDE], nb, (uint32_t)bidx, (uint32_t)(bidx >> 32), dpr, pxcol0, pyrow, lane);
+                    __builtin_amdgcn_wave_barrier();
+                    nb = 0; bidx = 0ull;
+                }
+              }
+              if (mask == 0ull) break;
             }
         }
         if (lane == 0) {

@@ -78,6 +78,10 @@ int gs_set_option(const char* name, int value);
  * (q = 0..8), out_host[lane]: lane 2q of every 16-lane row holds the wave total of value q (q < 8), lane 1
  * the total of value 8. */
 int gs_debug_wave_reduce9(const float* in_host, float* out_host);
+/* Diagnostic: the 8-lane-group form the single-gradient-set backward uses after its LDS hand-off.  in_host[q*64 + lane]
+ * (q = 0..8), out_host[0..63]: lane 8h + r holds the total over lanes 8h..8h+7 of value (r & 4) + ((r >> 1) & 1) + 2 (r & 1);
+ * out_host[64..127]: the group total of value 8 in every lane. */
+int gs_debug_group8_reduce9(const float* in_host, float* out_host);
 
 /* ------------------------------------------------------------------------------------------
  * Raw device-memory helpers (current HIP device).  They exist so that C / ctypes callers and the

@@ -306,6 +306,22 @@ def test_wave_reduce_scatter9_layout():
         assert out[16 * row + 1] == tot[8], (row, out.reshape(4, 16), tot)
 
 
+def test_group8_reduce_scatter9_layout():
+    """The 8-lane-group reduce-scatter behind the LDS hand-off backward: exact on integer data, documented layout."""
+    import ctypes as C
+    from gsplat_amd import capi
+    rng = np.random.default_rng(1)
+    vals = rng.integers(-50, 50, (9, 64)).astype(np.float32)
+    out = np.zeros(128, np.float32)
+    capi.check(capi.lib().gs_debug_group8_reduce9(vals.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+    tot = vals.reshape(9, 8, 8).sum(2)   # [value][group]
+    for h in range(8):
+        for r in range(8):
+            q = (r & 4) + ((r >> 1) & 1) + 2 * (r & 1)
+            assert out[8 * h + r] == tot[q, h], (h, r, q, out[:64].reshape(8, 8), tot)
+            assert out[64 + 8 * h + r] == tot[8, h], (h, r, out[64:].reshape(8, 8), tot[8])
+
+
 def test_rigid_motion_invariance_on_the_gpu():
     """The source-independent pin of tests/test_oracle_kat.py on the HIP path: moving scene and camera by one rigid
     transform leaves the picture unchanged (fp32: 1e-4 on all but a handful of threshold pixels)."""
