@@ -371,15 +371,16 @@ int launch_debug_group8(const float* in, float* out, hipStream_t st) {
     return GS_OK;
 }
 
-// Contracts the wave's parked hits (nb <= PARK_BATCH of them; entry indices packed 8 bits apiece in blo | bhi) and stores
+// Contracts the wave's parked hits (nb <= PARK_BATCH of them; their staging slots packed 8 bits apiece in blo, newest in the low byte) and stores
 // the nine sums of every hit in the wave's accumulator slots acc[entry * ACC_STRIDE + q].
 //   dpr[c][i]  dL/dpixel channel c of pixel (row lane % 8, column i) of the wave's block;  pxcol0 = x of column 0;
 //   pyrow      y of this lane's row.
 template <int N>
 __device__ __forceinline__ void contract_parked(const float* __restrict__ park, const StagedTile<N>& st, float* __restrict__ acc, int nb,
-                                                uint32_t blo, uint32_t bhi, const float (&dpr)[3][PARK_PPL], float pxcol0, float pyrow, int lane) {
+                                                uint32_t blo, const float (&dpr)[3][PARK_PPL], float pxcol0, float pyrow, int lane) {
+    static_assert(PARK_BATCH == 4, "the packed slot word holds four hits");
     const int h = lane / PARK_LPH, sub = lane % PARK_LPH;
-    const int jj = (int)__builtin_amdgcn_ubfe((PARK_BATCH == 4 || h < 4) ? blo : bhi, (uint32_t)(8 * (h & 3)), 8u);
+    const int jj = (int)__builtin_amdgcn_ubfe(blo, (uint32_t)(8 * (nb - 1 - h)) & 31u, 8u);  // hit h of the batch (parking order)
     const float2 xy = *reinterpret_cast<const float2*>(&st.A[jj]);
     const float2* row = reinterpret_cast<const float2*>(park + h * PARK_STRIDE + sub * PARK_PPL);
     float w[PARK_PPL], u[PARK_PPL];
@@ -433,10 +434,9 @@ template <int K, int F>
 __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s, const int* __restrict__ items) {
 #pragma clang fp contract(fast)
     static_assert(K * F <= 2, "an item carries two passes");
-    constexpr bool PARK = (K == 1);  // one gradient set: pixel sums by LDS hand-off + FMA contraction (contract_parked)
-    constexpr int ROUND = (K == 2) ? GS_BWD_ROUND_K2 : GS_BWD_ROUND_PAIR;  // entries staged per round
+    static_assert(K == 2, "single gradient sets take render_bwd_single");
+    constexpr int ROUND = GS_BWD_ROUND_K2;  // entries staged per round
     __shared__ StagedTile<ROUND> st;
-    __shared__ __attribute__((aligned(16))) float sPark[PARK ? 4 * PARK_BATCH * PARK_STRIDE : 1];
     __shared__ uint32_t sSlot[ROUND];
     __shared__ float sAcc[K * 4 * ROUND * ACC_STRIDE];
     __shared__ unsigned long long sTouched[4][(ROUND + 63) / 64];
@@ -505,9 +505,7 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
     uint32_t wave_max_last = last_contributor;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wave_max_last = max(wave_max_last, (uint32_t)__shfl_xor((int)wave_max_last, o));
-    // tell the compiler it is wave-uniform: branches on it become scalar, and what they guard (batch counter, touched bits)
-    // stays in SGPRs
-    wave_max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_last);
+    wave_max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_last);  // uniform: branches on it become scalar
     if (lane == 0) atomicMax(&sMaxLast, wave_max_last);
     if (s.loss && !s.dL_dpix) {
 #pragma unroll
@@ -540,24 +538,6 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
     const int wslot = (lane & 1) ? 8 : (lane >> 1);
     const int fold16 = (lane ^ 16) << 2, fold32 = (lane ^ 32) << 2;  // ds_bpermute byte addresses of the row partners
     float* const acc_lane = &sAcc[wave * ROUND * ACC_STRIDE + wslot];  // this lane's column of the wave's slots
-    // hand-off form: the wave's parking area, and dL/dpixel of the eight pixels of row (lane % 8) for the contraction
-    float* const park = &sPark[PARK ? wave * PARK_BATCH * PARK_STRIDE : 0];
-    float dpr[3][PARK_PPL];
-    const int psub = lane % PARK_LPH;  // this lane's pixels in a contraction: psub * PARK_PPL .. + PARK_PPL - 1 of the block (row-major)
-    if constexpr (PARK) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) park[c * 64 + lane] = dpx[0][c];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int i = 0; i < PARK_PPL; i++) dpr[c][i] = park[c * 64 + psub * PARK_PPL + i];
-        __builtin_amdgcn_wave_barrier();
-    }
-    const float pyrow = (float)(by0 + ((psub * PARK_PPL) >> 3));
-    const float pxcol0 = (float)(bx0 + ((psub * PARK_PPL) & 7));
-    int nb = 0;                     // hits parked and not yet contracted (wave-uniform)
-    unsigned long long bidx = 0ull;  // their entry indices, 8 bits apiece
 
     for (int r = rounds - 1; r >= 0; r--) {
         const int base = r * ROUND;
@@ -582,8 +562,7 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
                 hit = block_reaches(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
             }
             unsigned long long mask = __ballot(hit);
-            for (;;) {
-              if (mask != 0ull) {
+            while (mask) {
                 const int kk = 63 - __clzll((long long)mask);
                 mask &= ~(1ull << kk);
                 const int jj = sub + kk;
@@ -626,16 +605,7 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
                         u[p] = dL * GT + tfbg[p] * Gi;  // G * (dL_dalpha * T + tfbg / (1 - alpha)),  tfbg = -T_final * (bg . dL_dpix)
                     }
                 }
-                if constexpr (PARK) {
-                    if (any_act != 0ull) {
-                        // inactive lanes park exact zeros: dchannel_dcolor = u = 0 there
-                        park[nb * PARK_STRIDE + lane] = dchannel_dcolor;
-                        park[nb * PARK_STRIDE + 64 + lane] = u[0];
-                        bidx |= (unsigned long long)jj << (8 * nb);
-                        touched[sb] |= 1ull << kk;
-                        nb++;
-                    }
-                } else if (any_act != 0ull) {
+                if (any_act != 0ull) {
                     // inactive lanes contribute exact zeros: dchannel_dcolor = u = 0 there
 #pragma unroll
                     for (int p = 0; p < K; p++) {
@@ -648,18 +618,6 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
                     }
                     touched[sb] |= 1ull << kk;
                 }
-              }
-              if constexpr (PARK) {
-                // ONE contraction site: a full batch, or the round's last, partly filled one (sub-block 0 is the last one
-                // walked; its entries are flushed and st restaged right after)
-                if (nb == PARK_BATCH || (mask == 0ull && sb == 0 && nb != 0)) {
-                    __builtin_amdgcn_wave_barrier();
-                    contract_parked(park, st, &sAcc[wave * ROUND * ACC_STRIDE], nb, (uint32_t)bidx, (uint32_t)(bidx >> 32), dpr, pxcol0, pyrow, lane);
-                    __builtin_amdgcn_wave_barrier();
-                    nb = 0; bidx = 0ull;
-                }
-              }
-              if (mask == 0ull) break;
             }
         }
         if (lane == 0) {
@@ -700,6 +658,219 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
     }
 }
 
+// Single gradient set (<F = 2>: the step's fused camera pair; <F = 1>: one pass — rasterizer seam, cameras with an odd
+// number of passes): the LDS hand-off form.  Differences from render_bwd_body besides the pixel sums:
+//   * a round is 64 entries = ONE ballot; slot s of the staging area holds entry 63 - s of the round, so walking the
+//     ballot's bits upwards (s_ff1 + s_bitset0) is the back-to-front traversal;
+//   * the hit is branch-free: an inactive lane (behind the pixel's last contributor, power > 0, alpha < 1/255) continues
+//     with G = alpha = 0, which leaves T and the accumulated colour unchanged and parks exact zeros — two v_cndmask
+//     instead of an exec-masked region, and every hit is parked (no "did any lane act" test: the touched bits of the
+//     round are the ballot itself);
+//   * all loop state (hit counter, packed slot indices, ballot) is wave-uniform and lives in SGPRs.
+// The scalar unit is shared by the CU's four SIMDs (4.7 cycles per SALU instruction per SIMD, tools/valu_rate.hip): the
+// first hand-off version spent 40 SALU instructions per hit on loop control, as much SIMD time as its VALU work.
+template <int F>
+__device__ __forceinline__ void render_bwd_single(const Dims& d, const Scratch& s, const int* __restrict__ items) {
+#pragma clang fp contract(fast)
+    constexpr int ROUND = 64;
+    __shared__ StagedTile<ROUND> st;
+    __shared__ uint32_t sSlot[ROUND];
+    __shared__ float sAcc[4 * ROUND * ACC_STRIDE];
+    __shared__ __attribute__((aligned(16))) float sPark[4 * PARK_BATCH * PARK_STRIDE];
+    __shared__ unsigned long long sTouched[4];
+    __shared__ uint32_t sMaxLast;
+    __shared__ float sLoss[F][4];
+    const int* item = items + 3 * blockIdx.y;  // {group, pass 0, pass 1}
+    const int g = item[0];                     // geometry group: lists, records, T and n_contrib live there
+    const int tile = (int)s.tile_order[(size_t)g * d.T + blockIdx.x];
+    int vin[F];  // the passes whose residual images are summed; the rows go to the slice of the first one
+#pragma unroll
+    for (int q = 0; q < F; q++) vin[q] = item[1 + q];
+    if (s.flags[g * 4 + 0] & 1u) return;
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bx0 = tx * TILE + (wave & 1) * 8, by0 = ty * TILE + (wave >> 1) * 8;
+    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+    const bool inside = px < d.W && py < d.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float bxlo = (float)bx0, bxhi = (float)(bx0 + 7), bylo = (float)by0, byhi = (float)(by0 + 7);
+
+    const int n = (int)s.tile_count[(size_t)g * d.T + tile];
+    const uint32_t start = s.tile_end[(size_t)g * d.T + tile] - (uint32_t)n;
+    const uint32_t* __restrict__ plist = s.point_list + (size_t)g * d.Rcap + start;
+    const uint32_t* __restrict__ slist = s.slot_list + (size_t)g * d.Rcap + start;
+    const GeomRec* __restrict__ geom = s.geom + (size_t)g * d.Pa;
+    float* const Gout = s.G + (size_t)vin[0] * d.Rcap * G_STRIDE;
+
+    // per-pixel state
+    float T_final = 0.0f;
+    uint32_t last_contributor = 0;
+    float dpx0 = 0.0f, dpx1 = 0.0f, dpx2 = 0.0f, tfbg = 0.0f, res2[F];
+#pragma unroll
+    for (int q = 0; q < F; q++) res2[q] = 0.0f;
+    if (inside) {
+        const size_t pix = (size_t)py * d.W + px;
+        T_final = s.final_T[(size_t)g * d.N + pix];
+        last_contributor = s.n_contrib[(size_t)g * d.N + pix];
+#pragma unroll
+        for (int q = 0; q < F; q++) {
+            const int v = vin[q];
+            float r0, r1, r2;
+            if (s.dL_dpix) {
+                const float* gp = s.dL_dpix + (size_t)v * 3 * d.N;
+                r0 = gp[pix]; r1 = gp[(size_t)d.N + pix]; r2 = gp[2 * (size_t)d.N + pix];
+            } else {
+                // imageIntToLoss, src/Trainer.cu:33-44: truth/255 - rasterized
+                const uint32_t t = s.truth[(size_t)v * d.N + pix];
+                const float* out = s.out_color + (size_t)v * 3 * d.N;
+                r0 = ((float)(t & 0xFF) / 255.0f) - out[pix];
+                r1 = ((float)((t >> 8) & 0xFF) / 255.0f) - out[(size_t)d.N + pix];
+                r2 = ((float)((t >> 16) & 0xFF) / 255.0f) - out[2 * (size_t)d.N + pix];
+                res2[q] = r0 * r0 + r1 * r1 + r2 * r2;
+            }
+            const float* bg = s.views[v].bg;
+            dpx0 += r0; dpx1 += r1; dpx2 += r2;
+            tfbg += -T_final * (bg[0] * r0 + bg[1] * r1 + bg[2] * r2);
+        }
+    }
+    if (tid == 0) sMaxLast = 0;
+    __syncthreads();
+    // wave-uniform and block-uniform bounds on the traversal
+    uint32_t wave_max_last = last_contributor;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wave_max_last = max(wave_max_last, (uint32_t)__shfl_xor((int)wave_max_last, o));
+    wave_max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_last);  // uniform: branches on it become scalar
+    if (lane == 0) atomicMax(&sMaxLast, wave_max_last);
+    if (s.loss && !s.dL_dpix) {
+#pragma unroll
+        for (int q = 0; q < F; q++) {
+            const float l = wave_sum_to_lane63(res2[q]);
+            if (lane == 63) sLoss[q][wave] = l;
+        }
+    }
+    // dL/dpixel of the pixels this lane contracts (PARK_PPL consecutive pixels of one row), through the parking area
+    float* const park = &sPark[wave * PARK_BATCH * PARK_STRIDE];
+    float dpr[3][PARK_PPL];
+    const int psub = lane % PARK_LPH;
+    park[lane] = dpx0; park[64 + lane] = dpx1; park[128 + lane] = dpx2;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int i = 0; i < PARK_PPL; i++) dpr[c][i] = park[c * 64 + psub * PARK_PPL + i];
+    const float pyrow = (float)(by0 + ((psub * PARK_PPL) >> 3));
+    const float pxcol0 = (float)(bx0 + ((psub * PARK_PPL) & 7));
+    __syncthreads();
+    const int max_last = (int)sMaxLast;
+    if (s.loss && !s.dL_dpix && tid < F)  // fixed summation order: the loss statistic is reproducible too
+        s.loss[(size_t)vin[tid] * d.T + tile] = (sLoss[tid][0] + sLoss[tid][1]) + (sLoss[tid][2] + sLoss[tid][3]);
+    if (n == 0) return;
+    const int rounds = (max_last + ROUND - 1) / ROUND;
+    // entries no pixel reaches still own a gradient row: zero it
+    for (int e = rounds * ROUND + tid; e < n; e += WG) {
+        Row3* row = reinterpret_cast<Row3*>(Gout + (size_t)slist[e] * G_STRIDE);
+        row[0] = Row3{ 0, 0, 0 }; row[1] = Row3{ 0, 0, 0 }; row[2] = Row3{ 0, 0, 0 };
+    }
+
+    float T = T_final;
+    float ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f;  // accum_rec, already blended with the previously visited entry
+    const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
+    float* const acc = &sAcc[wave * ROUND * ACC_STRIDE];
+
+    for (int r = rounds - 1; r >= 0; r--) {
+        const int base = r * ROUND;
+        const int cnt = min(ROUND, n - base);
+        __syncthreads();  // previous round's flush has consumed st / sAcc / sTouched
+        if (tid < ROUND && ROUND - 1 - tid < cnt) {  // slot tid <- entry ROUND-1-tid of the round
+            const int e = base + ROUND - 1 - tid;
+            stage_entry(st, tid, geom + plist[e]);
+            sSlot[tid] = slist[e];
+        }
+        __syncthreads();
+        bool hit = false;
+        {
+            const int j = ROUND - 1 - lane;
+            if (j < cnt && (uint32_t)(base + j) < wave_max_last) {
+                const float4 a = st.A[lane];
+                hit = block_reaches(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * st.B[lane].x, st.C[lane].y, bxlo, bxhi, bylo, byhi);
+            }
+        }
+        unsigned long long mask = __ballot(hit);
+        const unsigned long long touched = mask;
+        const uint32_t pos_slot0 = (uint32_t)(base + ROUND - 1);  // upstream's `contributor` (after its decrement) of slot 0
+        int nb = 0;          // hits parked and not yet contracted
+        uint32_t blo = 0;    // their slots, 8 bits apiece, newest in the low byte
+        while (mask != 0ull) {
+            const int k = __builtin_ctzll(mask);
+            asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(k));
+            const float4 Ac = st.A[k], Bc = st.B[k];
+            const float cbc = st.C[k].x;
+            const uint32_t pos = pos_slot0 - (uint32_t)k;
+            const float dx = Ac.x - pxf, dy = Ac.y - pyf;
+            const float power = dx * (Ac.z * dx + Ac.w * dy) + Bc.x * dy * dy;  // log2 of the Gaussian weight
+            const float G0 = __builtin_amdgcn_exp2f(power);
+            const float alpha0 = fminf(ALPHA_MAX, Bc.y * G0);
+            const bool act = (pos < last_contributor) & (power <= 0.0f) & (alpha0 >= ALPHA_MIN);
+            const float G = act ? G0 : 0.0f, alpha = act ? alpha0 : 0.0f;
+            const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);  // exactly 1 for an inactive lane
+            T = T * inv1ma;
+            const float w = alpha * T;
+            // upstream blends (last_alpha, last_color) into accum_rec BEFORE using it; doing the same blend with
+            // this entry's (alpha, colour) AFTER use is the identical recurrence one step early
+            const float c0 = Bc.z - ar0, c1 = Bc.w - ar1, c2 = cbc - ar2;
+            ar0 = fmaf(alpha, c0, ar0);
+            ar1 = fmaf(alpha, c1, ar1);
+            ar2 = fmaf(alpha, c2, ar2);
+            float dL = c0 * dpx0;
+            dL += c1 * dpx1;
+            dL += c2 * dpx2;
+            const float u = dL * (G * T) + tfbg * (G * inv1ma);  // G * (dL_dalpha * T + tfbg / (1 - alpha)),  tfbg = -T_final * (bg . dL_dpix)
+            park[nb * PARK_STRIDE + lane] = w;
+            park[nb * PARK_STRIDE + 64 + lane] = u;
+            blo = (blo << 8) | (uint32_t)k;
+            if (++nb == PARK_BATCH) {
+                __builtin_amdgcn_wave_barrier();
+                contract_parked(park, st, acc, PARK_BATCH, blo, dpr, pxcol0, pyrow, lane);
+                __builtin_amdgcn_wave_barrier();
+                nb = 0;
+            }
+        }
+        if (nb != 0) {  // the round's last, partly filled batch
+            __builtin_amdgcn_wave_barrier();
+            contract_parked(park, st, acc, nb, blo, dpr, pxcol0, pyrow, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) sTouched[wave] = touched;
+        __syncthreads();
+        if (tid < ROUND && ROUND - 1 - tid < cnt) {
+            // moments -> the reference's nine sums (dx = mean2D.x - pixel.x as upstream):
+            //   dL_dmean2D.x = -0.5 W op (conA * S[u dx] + conB * S[u dy]),  .y = -0.5 H op (conC * S[u dy] + conB * S[u dx])
+            //   dL_dconic    = -0.5 op (S[u dx dx], S[u dx dy], S[u dy dy]),  dL_dopacity = S[u]
+            const float4 Af = st.A[tid], Bf = st.B[tid];
+            const float op = Bf.y, hop = -0.5f * op;
+            float conA, conB, conC;
+            unscaled_conic(Af, Bf, conA, conB, conC);
+            float sum[ACC_STRIDE];
+#pragma unroll
+            for (int q = 0; q < ACC_STRIDE; q++) sum[q] = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {  // fixed order over the four waves; only slots written this round are read
+                if ((sTouched[w] >> tid) & 1ull) {
+                    const float* a = &sAcc[(w * ROUND + tid) * ACC_STRIDE];
+#pragma unroll
+                    for (int q = 0; q < ACC_STRIDE; q++) sum[q] += a[q];
+                }
+            }
+            const float gmx = -ddelx_dx * op * (conA * sum[3] + conB * sum[4]);
+            const float gmy = -ddely_dy * op * (conC * sum[4] + conB * sum[3]);
+            Row3* row = reinterpret_cast<Row3*>(Gout + (size_t)sSlot[tid] * G_STRIDE);
+            row[0] = Row3{ sum[0], sum[1], sum[2] };
+            row[1] = Row3{ gmx, gmy, hop * sum[5] };
+            row[2] = Row3{ hop * sum[6], hop * sum[7], sum[8] };
+        }
+    }
+}
+
 __global__ __launch_bounds__(WG) void k_loss_sum(Dims d, Scratch s) {
     __shared__ float part[WG];
     const int v = blockIdx.x;
@@ -728,10 +899,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     render_bwd_body<2, 1>(d, s, items);
 }
 __global__ __launch_bounds__(WG) void k_render_bwd1(Dims d, Scratch s, const int* __restrict__ items) {
-    render_bwd_body<1, 1>(d, s, items);
+    render_bwd_single<1>(d, s, items);
 }
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GS_BWD_PAIR_WAVES, GS_BWD_PAIR_WAVES))) void k_render_bwd_pair(Dims d, Scratch s, const int* __restrict__ items) {
-    render_bwd_body<1, 2>(d, s, items);
+    render_bwd_single<2>(d, s, items);
 }
 
 // items: n2 pairs {group, pass a, pass b} followed by n1 singles {group, pass, -1} (device array of 3*(n2+n1) ints).
