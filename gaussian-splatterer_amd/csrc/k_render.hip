@@ -388,14 +388,22 @@ __device__ __forceinline__ void contract_parked(const float* __restrict__ park, 
     for (int k = 0; k < PARK_PPL / 2; k++) { const float2 t = row[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
 #pragma unroll
     for (int k = 0; k < PARK_PPL / 2; k++) { const float2 t = row[32 + k]; u[2 * k] = t.x; u[2 * k + 1] = t.y; }
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+    // colour sums, and the moments of u over the lane's pixel INDEX i (dx_i = X0 - i with X0 = x - first pixel's x):
+    //   sum u dx = X0 n0 - n1,   sum u dx^2 = X0 (X0 n0 - 2 n1) + n2.
+    // The expansion loses log2(X0^2 / dx^2) bits against forming dx per pixel; over a span of four pixels and with the
+    // 0.3 px^2 low-pass on every splat that is < 6 bits in the worst case (a minimal splat centred inside the span) —
+    // the budget of the parity tests is 1e-4 of sum |term| — and it halves the VALU work of the moments.
+    float a0 = w[0] * dpr[0][0], a1 = w[0] * dpr[1][0], a2 = w[0] * dpr[2][0];
+    float n0 = u[0], n1 = 0.0f, n2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < PARK_PPL; i++) {
-        const float dx = xy.x - (pxcol0 + (float)i);  // the same difference the hit formed for this pixel
-        const float ux = u[i] * dx;
-        m0 += u[i]; m1 += ux; m2 = fmaf(ux, dx, m2);
+    for (int i = 1; i < PARK_PPL; i++) {
         a0 = fmaf(w[i], dpr[0][i], a0); a1 = fmaf(w[i], dpr[1][i], a1); a2 = fmaf(w[i], dpr[2][i], a2);
+        n0 += u[i]; n1 = fmaf((float)i, u[i], n1); n2 = fmaf((float)(i * i), u[i], n2);
     }
+    const float X0 = xy.x - pxcol0;
+    const float m0 = n0;
+    const float m1 = fmaf(X0, n0, -n1);
+    const float m2 = fmaf(X0, m1 - n1, n2);
     const float dy = xy.y - pyrow;
     const float m0y = m0 * dy;
     // order of the nine sums as everywhere else: colour(3), u dx, u dy, u dx dx, u dx dy, u dy dy, u
@@ -773,7 +781,7 @@ __device__ __forceinline__ void render_bwd_single(const Dims& d, const Scratch& 
     }
 
     float T = T_final;
-    float ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f;  // accum_rec, already blended with the previously visited entry
+    float arp = 0.0f;  // accum_rec . dL_dpixel, already blended with the previously visited entry
     const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
     float* const acc = &sAcc[wave * ROUND * ACC_STRIDE];
 
@@ -796,6 +804,9 @@ __device__ __forceinline__ void render_bwd_single(const Dims& d, const Scratch& 
             }
         }
         unsigned long long mask = __ballot(hit);
+#ifdef GS_DIAG_NO_HITS  // timing experiments only (tools/build_variant.sh): the round skeleton without the hit loop
+        mask = 0ull;
+#endif
         const unsigned long long touched = mask;
         const uint32_t pos_slot0 = (uint32_t)(base + ROUND - 1);  // upstream's `contributor` (after its decrement) of slot 0
         int nb = 0;          // hits parked and not yet contracted
@@ -815,22 +826,22 @@ __device__ __forceinline__ void render_bwd_single(const Dims& d, const Scratch& 
             const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);  // exactly 1 for an inactive lane
             T = T * inv1ma;
             const float w = alpha * T;
-            // upstream blends (last_alpha, last_color) into accum_rec BEFORE using it; doing the same blend with
-            // this entry's (alpha, colour) AFTER use is the identical recurrence one step early
-            const float c0 = Bc.z - ar0, c1 = Bc.w - ar1, c2 = cbc - ar2;
-            ar0 = fmaf(alpha, c0, ar0);
-            ar1 = fmaf(alpha, c1, ar1);
-            ar2 = fmaf(alpha, c2, ar2);
-            float dL = c0 * dpx0;
-            dL += c1 * dpx1;
-            dL += c2 * dpx2;
-            const float u = dL * (G * T) + tfbg * (G * inv1ma);  // G * (dL_dalpha * T + tfbg / (1 - alpha)),  tfbg = -T_final * (bg . dL_dpix)
+            // upstream: dL_dalpha = sum_ch (colour_ch - accum_rec_ch) * dL_dpixel_ch with accum_rec blended per channel,
+            // accum_rec = last_alpha * last_colour + (1 - last_alpha) * accum_rec.  Only the contraction with dL_dpixel is ever
+            // used, and it obeys the same recurrence: arp = sum_ch accum_rec_ch * dL_dpixel_ch  ->  arp += alpha * (cd - arp)
+            // with cd = sum_ch colour_ch * dL_dpixel_ch (blend applied AFTER use: the identical recurrence one step early).
+            const float cd = Bc.z * dpx0 + Bc.w * dpx1 + cbc * dpx2;
+            const float dL = cd - arp;
+            arp = fmaf(alpha, dL, arp);
+            const float u = G * (dL * T + tfbg * inv1ma);  // G * (dL_dalpha * T + tfbg / (1 - alpha)),  tfbg = -T_final * (bg . dL_dpix)
             park[nb * PARK_STRIDE + lane] = w;
             park[nb * PARK_STRIDE + 64 + lane] = u;
             blo = (blo << 8) | (uint32_t)k;
             if (++nb == PARK_BATCH) {
                 __builtin_amdgcn_wave_barrier();
+#ifndef GS_DIAG_NO_CONTRACT
                 contract_parked(park, st, acc, PARK_BATCH, blo, dpr, pxcol0, pyrow, lane);
+#endif
                 __builtin_amdgcn_wave_barrier();
                 nb = 0;
             }
