@@ -785,16 +785,37 @@ __device__ __forceinline__ void render_bwd_single(const Dims& d, const Scratch& 
     const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
     float* const acc = &sAcc[wave * ROUND * ACC_STRIDE];
 
+    // Staging is spread over the workgroup and runs one round ahead: wave w < 3 fetches 16-byte part w of the record of slot
+    // `lane` (slot s <- entry ROUND-1-s of the round), wave 3 the entry's gradient-row slot.  The record of round r-1 is
+    // requested right after round r has been staged and arrives during round r's hit loop; its index was requested a round
+    // earlier still.  Only the first round of a tile pays the two dependent global latencies.
+    // (Every round below the first one walked is full; the first may be the list's partial tail.)
+    auto entry_of = [&](int r) { return r * ROUND + ROUND - 1 - lane; };  // this lane's entry in round r
+    const bool first_valid = rounds > 0 && entry_of(rounds - 1) < n;
+    uint32_t idx_next = 0;   // waves 0-2: splat id of this lane's entry in the NEXT round to stage; wave 3: its row slot
+    float4 part = make_float4(0, 0, 0, 0);
+    {
+        const uint32_t* __restrict__ src = wave < 3 ? plist : slist;
+        const uint32_t idx0 = first_valid ? src[entry_of(rounds - 1)] : 0u;
+        if (rounds > 1) idx_next = src[entry_of(rounds - 2)];
+        if (wave < 3) { if (first_valid) part = reinterpret_cast<const float4*>(geom + idx0)[wave]; }
+        else part.x = __uint_as_float(idx0);
+    }
+
     for (int r = rounds - 1; r >= 0; r--) {
         const int base = r * ROUND;
         const int cnt = min(ROUND, n - base);
         __syncthreads();  // previous round's flush has consumed st / sAcc / sTouched
-        if (tid < ROUND && ROUND - 1 - tid < cnt) {  // slot tid <- entry ROUND-1-tid of the round
-            const int e = base + ROUND - 1 - tid;
-            stage_entry(st, tid, geom + plist[e]);
-            sSlot[tid] = slist[e];
-        }
+        if (wave == 0) { part.z *= -0.5f * LOG2E; part.w *= -LOG2E; st.A[lane] = part; }   // conic pre-scaled to base 2 (stage_entry)
+        else if (wave == 1) { part.x *= -0.5f * LOG2E; st.B[lane] = part; }
+        else if (wave == 2) { part.y *= LOG2E; st.C[lane] = part; }
+        else sSlot[lane] = __float_as_uint(part.x);
         __syncthreads();
+        if (r > 0) {  // request round r-1 (always a full round)
+            if (wave < 3) part = reinterpret_cast<const float4*>(geom + idx_next)[wave];
+            else part.x = __uint_as_float(idx_next);
+            if (r > 1) idx_next = (wave < 3 ? plist : slist)[entry_of(r - 2)];
+        }
         bool hit = false;
         {
             const int j = ROUND - 1 - lane;
