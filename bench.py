@@ -187,7 +187,7 @@ def main():
     # value the default step does not compute is on record
     per_pass = None
     if not use_dist:
-        capi.check(L.gs_set_option(b"fuse_camera_passes", 0))
+        tr.set_option("fuse_camera_passes", 0)
         try:
             for _ in range(3):
                 tr.train(proj, densify=False)
@@ -198,10 +198,10 @@ def main():
                 tr.train(proj, densify=False)
             tr.synchronize()
             per_pass = {"value": n_pp / (time.perf_counter() - t_pp), "unit": "steps/s", "steps": n_pp,
-                        "note": "gs_set_option('fuse_camera_passes', 0): one backward per pass and `var` on every step (what a densify step runs); "
+                        "note": "gs_trainer_set_option('fuse_camera_passes', 0): one backward per pass and `var` on every step (what a densify step runs); "
                                 "measured after the timed region"}
         finally:
-            capi.check(L.gs_set_option(b"fuse_camera_passes", 1))
+            tr.set_option("fuse_camera_passes", 1)
     # untimed, reported separately: one step WITH densify/prune, as the driver loop runs every 200th iteration
     densify_ms = None
     if not use_dist:

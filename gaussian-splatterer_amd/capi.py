@@ -50,13 +50,13 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void
 
 # every symbol include/gsplat.h declares (tests/test_capi_symbols.py checks the library exports them all)
 SYMBOLS = [
-    "gs_last_error", "gs_status_string", "gs_version", "gs_device_count", "gs_set_option", "gs_debug_wave_reduce9", "gs_debug_group8_reduce9", "gs_device_malloc", "gs_device_free",
+    "gs_last_error", "gs_status_string", "gs_version", "gs_device_count", "gs_set_option", "gs_debug_wave_reduce9", "gs_device_malloc", "gs_device_free",
     "gs_memcpy_h2d", "gs_memcpy_d2h", "gs_memset_d", "gs_device_synchronize", "gs_model_create", "gs_model_clone",
     "gs_model_download", "gs_model_info", "gs_model_destroy", "gs_hyper_defaults", "gs_trainer_create",
     "gs_trainer_destroy", "gs_trainer_set_model", "gs_trainer_get_model", "gs_trainer_set_views", "gs_trainer_step",
     "gs_trainer_accumulate", "gs_trainer_grad_buffer", "gs_trainer_apply", "gs_trainer_set_allreduce",
     "gs_trainer_get_stream", "gs_trainer_synchronize", "gs_trainer_render", "gs_trainer_read_image",
-    "gs_trainer_set_sharded_update", "gs_trainer_attach_comm_sharded", "gs_trainer_set_profiling", "gs_trainer_stage_times", "gs_stage_name", "gs_trainer_adam_state",
+    "gs_trainer_set_option", "gs_trainer_set_sharded_update", "gs_trainer_attach_comm_sharded", "gs_trainer_set_profiling", "gs_trainer_stage_times", "gs_stage_name", "gs_trainer_adam_state",
     "gs_comm_unique_id", "gs_comm_create", "gs_comm_destroy", "gs_trainer_attach_comm", "gs_rasterize_forward",
     "gs_rasterize_backward", "gs_raster_chunk_field", "gs_image_float_to_int", "gs_image_int_to_loss",
 ]
@@ -79,7 +79,6 @@ def lib():
     vp, i, f = C.c_void_p, C.c_int, C.c_float
     L.gs_set_option.argtypes = [C.c_char_p, i]
     L.gs_debug_wave_reduce9.argtypes = [vp, vp]
-    L.gs_debug_group8_reduce9.argtypes = [vp, vp]
     L.gs_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.gs_device_free.argtypes = [vp]
     L.gs_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
@@ -97,6 +96,7 @@ def lib():
     L.gs_trainer_get_model.argtypes = [vp]
     L.gs_trainer_get_model.restype = vp
     L.gs_trainer_set_views.argtypes = [vp, i, vp, vp, i, i]
+    L.gs_trainer_set_option.argtypes = [vp, C.c_char_p, i]
     L.gs_trainer_step.argtypes = [vp, C.POINTER(gs_hyper), i, C.POINTER(gs_step_stats)]
     L.gs_trainer_accumulate.argtypes = [vp, C.POINTER(gs_step_stats)]
     L.gs_trainer_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]

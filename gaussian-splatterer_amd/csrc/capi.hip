@@ -21,13 +21,27 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static int g_opt_cull = 1;
-int option_cull() { return g_opt_cull; }
-static int g_opt_share = 1;
-int option_share_passes() { return g_opt_share; }
-static int g_opt_arena = 0;  // initial binning-arena entries per camera (0 = default max(2^20, 16 P))
-static int g_opt_fuse = 1;   // gs_trainer_step without densify: one backward per camera pair (the step's `var` has no reader)
-static int g_opt_debug_sync = 0;  // wait and check for errors after every stage, like the reference's debug=true rasterizer calls
+// Switches of a trainer (gs_trainer_set_option).  gs_set_option edits the process-wide DEFAULTS: a trainer copies them when
+// it is created and is not affected by later changes; the rasterizer seam (which has no trainer) reads `cull` from them.
+struct Options {
+    int cull = 1;
+    int share = 1;       // passes with bit-identical cameras share projection, lists and the forward blend
+    int arena = 0;       // initial binning-arena entries per camera (0 = default max(2^20, 16 P))
+    int fuse = 1;        // gs_trainer_step without densify: one backward per camera pair (the step's `var` has no reader)
+    int debug_sync = 0;  // wait and check for errors after every stage, like the reference's debug=true rasterizer calls
+    int sh_fp16 = 0;     // the projection reads SH coefficients from a half-precision copy (BASELINE cfg5); fp32 master and gradients
+};
+static Options g_defaults;
+// returns false for an unknown name
+static bool set_option(Options& o, const char* name, int value) {
+    if (strcmp(name, "cull") == 0) { o.cull = value != 0; return true; }
+    if (strcmp(name, "share_camera_passes") == 0) { o.share = value != 0; return true; }
+    if (strcmp(name, "fuse_camera_passes") == 0) { o.fuse = value != 0; return true; }
+    if (strcmp(name, "arena_entries") == 0) { o.arena = value > 0 ? value : 0; return true; }
+    if (strcmp(name, "debug_sync") == 0) { o.debug_sync = value != 0; return true; }
+    if (strcmp(name, "sh_fp16") == 0) { o.sh_fp16 = value != 0; return true; }
+    return false;
+}
 
 // grow-only device buffer
 struct DevBuf {
@@ -56,12 +70,12 @@ static int effective_degree(int sh_degree, int M, int* D_out) {
     return GS_OK;
 }
 
-static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t Rcap, float mod, int VG = -1) {
+static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t Rcap, float mod, int VG = -1, int cull = -1) {
     Dims d;
     d.P = P; d.Pa = Pa; d.D = D; d.M = M; d.W = W; d.H = H; d.N = W * H;
     d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
     d.sgx = (d.gx + STILE - 1) / STILE; d.sgy = (d.gy + STILE - 1) / STILE; d.NST = d.sgx * d.sgy;
-    d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = g_opt_cull;
+    d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = cull < 0 ? g_defaults.cull : cull;
     return d;
 }
 
@@ -278,18 +292,14 @@ extern "C" int gs_device_synchronize(void) { GS_HIP(hipDeviceSynchronize()); ret
 
 extern "C" int gs_set_option(const char* name, int value) {
     if (!name) return GS_ERR_INVALID_ARGUMENT;
-    if (strcmp(name, "cull") == 0) { g_opt_cull = value != 0; return GS_OK; }
-    if (strcmp(name, "share_camera_passes") == 0) { g_opt_share = value != 0; return GS_OK; }
-    if (strcmp(name, "fuse_camera_passes") == 0) { g_opt_fuse = value != 0; return GS_OK; }
-    if (strcmp(name, "arena_entries") == 0) { g_opt_arena = value > 0 ? value : 0; return GS_OK; }
-    if (strcmp(name, "debug_sync") == 0) { g_opt_debug_sync = value != 0; return GS_OK; }
+    if (set_option(g_defaults, name, value)) return GS_OK;
     if (strcmp(name, "scan_single_max") == 0) { gs::g_scan_single_max = value > 0 ? value : (1 << 16); return GS_OK; }
     set_error("gs_set_option: unknown option '%s'", name);
     return GS_ERR_INVALID_ARGUMENT;
 }
 
-// Diagnostic: the render-backward kernel's 9-value wave reduce-scatter on one wave.
-// in_host[q*64 + lane], out_host[lane]: lane 2q of every 16-lane row = total of q (q < 8), lane 1 = total of q = 8.
+// Diagnostic: the render-backward kernel's 9-value reduce-scatter over the 16-lane rows of one wave.
+// in_host[q*64 + lane], out_host[lane]: lane 2q of a row = that ROW's total of q (q < 8), lane 1 = its total of q = 8.
 extern "C" int gs_debug_wave_reduce9(const float* in_host, float* out_host) {
     if (!in_host || !out_host) return GS_ERR_INVALID_ARGUMENT;
     GS_TRY(require_device());
@@ -299,19 +309,6 @@ extern "C" int gs_debug_wave_reduce9(const float* in_host, float* out_host) {
     GS_HIP(hipMemcpy(din, in_host, 9 * 64 * 4, hipMemcpyHostToDevice));
     int rc = launch_debug_reduce9(din, dout, 0);
     if (rc == GS_OK && hipMemcpy(out_host, dout, 64 * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = GS_ERR_HIP;
-    (void)hipFree(din); (void)hipFree(dout);
-    return rc;
-}
-
-extern "C" int gs_debug_group8_reduce9(const float* in_host, float* out_host) {
-    if (!in_host || !out_host) return GS_ERR_INVALID_ARGUMENT;
-    GS_TRY(require_device());
-    float *din = nullptr, *dout = nullptr;
-    GS_HIP(hipMalloc((void**)&din, 9 * 64 * 4));
-    GS_HIP(hipMalloc((void**)&dout, 128 * 4));
-    GS_HIP(hipMemcpy(din, in_host, 9 * 64 * 4, hipMemcpyHostToDevice));
-    int rc = launch_debug_group8(din, dout, 0);
-    if (rc == GS_OK && hipMemcpy(out_host, dout, 128 * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = GS_ERR_HIP;
     (void)hipFree(din); (void)hipFree(dout);
     return rc;
 }
@@ -429,6 +426,9 @@ extern "C" int gs_model_destroy(gs_model* m) {
 // trainer
 // =============================================================================================
 struct gs_trainer {
+    Options opt;                  // copied from the process defaults at creation; gs_trainer_set_option edits them
+    DevBuf sh16;                  // [3M][Pa] half: read copy of the SH planes (option "sh_fp16")
+    const void* sh16_of = nullptr;  // the parameter planes the copy was made from and kept current with (null: stale)
     int device = 0, W = 0, H = 0;
     hipStream_t stream = nullptr;
     gs_model* model = nullptr;
@@ -501,7 +501,7 @@ void prof_stage_end(gs_trainer* t, int stage) {
 // "debug_sync": the reference passes debug=true to every rasterizer call (src/Trainer.cu:201,360,412), which makes it
 // synchronise and check for errors after each internal kernel; this names the stage a fault belongs to.
 int debug_check(gs_trainer* t, int stage) {
-    if (!g_opt_debug_sync) return GS_OK;
+    if (!t->opt.debug_sync) return GS_OK;
     hipError_t e = hipStreamSynchronize(t->stream);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { set_error("stage '%s' failed: %s", kStageNames[stage], hipGetErrorString(e)); return GS_ERR_HIP; }
@@ -533,6 +533,7 @@ extern "C" int gs_trainer_create(int width, int height, gs_trainer** out) {
     }
     GS_TRY(require_device());
     gs_trainer* t = new gs_trainer();
+    t->opt = g_defaults;
     t->W = width; t->H = height;
     if (hipGetDevice(&t->device) != hipSuccess || hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
         delete t; set_error("stream creation failed: %s", hipGetErrorString(hipGetLastError())); return GS_ERR_HIP;
@@ -548,7 +549,7 @@ extern "C" int gs_trainer_destroy(gs_trainer* t) {
     if (!t) return GS_OK;
     (void)hipStreamSynchronize(t->stream);
     gs_model_destroy(t->model);
-    t->truth.release(); t->grad.release(); t->adam_m.release(); t->adam_v.release();
+    t->truth.release(); t->grad.release(); t->adam_m.release(); t->adam_v.release(); t->sh16.release();
     t->train.release(); t->preview.release();
     if (t->h_flags) (void)hipHostFree(t->h_flags);
     if (t->ev_flags) (void)hipEventDestroy(t->ev_flags);
@@ -566,6 +567,7 @@ extern "C" int gs_trainer_set_model(gs_trainer* t, gs_model* m) {
     if (t->model != m) gs_model_destroy(t->model);
     t->model = m;
     t->adam_valid = false; t->adam_t = 0; t->accumulated = false;
+    t->sh16_of = nullptr;
     return GS_OK;
 }
 extern "C" gs_model* gs_trainer_get_model(gs_trainer* t) { return t ? t->model : nullptr; }
@@ -586,7 +588,7 @@ extern "C" int gs_trainer_set_views(gs_trainer* t, int n_views, const gs_view* v
     }
     t->h_views.assign(views, views + n_views);
     t->V = n_views;
-    t->VG = build_view_block(views, n_views, g_opt_share != 0, t->h_view_block, &t->bwd_pairs, &t->bwd_singles);
+    t->VG = build_view_block(views, n_views, t->opt.share != 0, t->h_view_block, &t->bwd_pairs, &t->bwd_singles);
     {
         const int* vg = reinterpret_cast<const int*>(t->h_view_block.data() + (size_t)n_views * 2 * sizeof(gs_view));
         t->h_view_group.assign(vg, vg + n_views);
@@ -601,7 +603,7 @@ extern "C" int gs_trainer_set_views(gs_trainer* t, int n_views, const gs_view* v
 static int trainer_dims(gs_trainer* t, Dims* d) {
     int D = 0;
     GS_TRY(effective_degree(t->model->sh_degree, t->model->sh_coeffs, &D));
-    *d = make_dims(t->model->count, t->model->Pa, D, t->model->sh_coeffs, t->W, t->H, t->V, t->Rcap, 1.0f, t->VG);
+    *d = make_dims(t->model->count, t->model->Pa, D, t->model->sh_coeffs, t->W, t->H, t->V, t->Rcap, 1.0f, t->VG, t->opt.cull);
     return GS_OK;
 }
 
@@ -665,7 +667,7 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
             GS_HIP(hipMemsetAsync(t->grad.as<float>() + (size_t)(pl.count() + 1) * m->Pa, 0, 64 * 64 * 4, t->stream));
     }
     t->grad_Pa = m->Pa; t->grad_M = M;
-    if (t->Rcap == 0) t->Rcap = g_opt_arena ? (uint32_t)g_opt_arena : (uint32_t)std::max<long long>(1 << 20, 16LL * P);
+    if (t->Rcap == 0) t->Rcap = t->opt.arena ? (uint32_t)t->opt.arena : (uint32_t)std::max<long long>(1 << 20, 16LL * P);
     if (t->h_flags_cap < (size_t)V * 20) {
         GS_HIP(hipStreamSynchronize(t->stream));
         if (t->h_flags) (void)hipHostFree(t->h_flags);
@@ -681,6 +683,16 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
         d.Rcap = t->train.Rcap;
         Scratch s = t->train.s;
         s.truth = t->truth.as<uint32_t>();
+        if (t->opt.sh_fp16 && P > 0) {
+            // the half-precision read copy: made here when it does not belong to these planes (new model, densify, a
+            // sharded update that refreshed only this rank's chunk), otherwise kept current by the update kernel
+            if (t->sh16_of != (const void*)m->planes) {
+                GS_TRY(t->sh16.ensure((size_t)3 * M * m->Pa * sizeof(uint16_t)));
+                GS_TRY(launch_sh_to_half(M, P, m->Pa, m->planes, t->sh16.as<uint16_t>(), t->stream));
+                t->sh16_of = (const void*)m->planes;
+            }
+            s.sh16 = t->sh16.as<uint16_t>();
+        }
         if (t->views_on_device != (const void*)s.views) {  // the view block only changes with gs_trainer_set_views
             GS_HIP(hipMemcpyAsync((void*)s.views, t->h_view_block.data(), t->h_view_block.size(), hipMemcpyHostToDevice, t->stream));
             t->views_on_device = (const void*)s.views;
@@ -710,7 +722,7 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
         if (P > 0) {  // an empty model has no gradients: its image is the background, its loss the residual against it
             const int* items = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.views) + view_block_items_offset(V));
             prof_stage_begin(t, 5, 4);
-            const bool fuse = !need_var && g_opt_fuse != 0;
+            const bool fuse = !need_var && t->opt.fuse != 0;
             GS_TRY(launch_render_backward(d, s, items, t->bwd_pairs, t->bwd_singles, fuse, t->stream));
             prof_stage_end(t, 5);
             GS_TRY(debug_check(t, 5));
@@ -801,6 +813,7 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
     if (rc != GS_OK) { if (fresh) gs_model_destroy(fresh); new_m.release(); new_v.release(); return rc; }
     std::swap(m->planes, fresh->planes);
     m->Pa = fresh->Pa; m->count = fresh->count;
+    t->sh16_of = nullptr;
     gs_model_destroy(fresh);
     if (t->adam_valid) {
         t->adam_m.release(); t->adam_v.release();
@@ -829,8 +842,13 @@ static int apply_update(gs_trainer* t, const gs_hyper* h, int stage_before, size
         return GS_ERR_INVALID_ARGUMENT;
     }
     prof_stage_begin(t, 7, stage_before);
+    // the update keeps the fp16 SH copy current for the elements it touches; a partial (sharded) update leaves the other
+    // ranks' chunks to the all-gather, so the copy is rebuilt before the next projection
+    const bool whole = lo == 0 && hi >= (size_t)pl.count() * m->Pa;
+    uint16_t* sh16 = (t->opt.sh_fp16 && whole && t->sh16_of == (const void*)m->planes) ? t->sh16.as<uint16_t>() : nullptr;
+    if (!sh16) t->sh16_of = nullptr;
     GS_TRY(launch_update(pl, m->count, m->Pa, m->planes, t->grad.as<float>(), t->adam_m.as<float>(), t->adam_v.as<float>(),
-                         t->adam_t, *h, t->stream, lo, hi));
+                         t->adam_t, *h, t->stream, lo, hi, sh16));
     prof_stage_end(t, 7);
     GS_TRY(debug_check(t, 7));
     t->accumulated = false;
@@ -925,6 +943,20 @@ extern "C" int gs_trainer_adam_state(gs_trainer* t, float** m, float** v, size_t
     return GS_OK;
 }
 
+extern "C" int gs_trainer_set_option(gs_trainer* t, const char* name, int value) {
+    if (!t || !name) return GS_ERR_INVALID_ARGUMENT;
+    const int share_before = t->opt.share;
+    if (!set_option(t->opt, name, value)) { set_error("gs_trainer_set_option: unknown option '%s'", name); return GS_ERR_INVALID_ARGUMENT; }
+    if (t->opt.share != share_before && t->V > 0) {  // regroup the passes already set
+        t->VG = build_view_block(t->h_views.data(), t->V, t->opt.share != 0, t->h_view_block, &t->bwd_pairs, &t->bwd_singles);
+        const int* vg = reinterpret_cast<const int*>(t->h_view_block.data() + (size_t)t->V * 2 * sizeof(gs_view));
+        t->h_view_group.assign(vg, vg + t->V);
+        t->views_on_device = nullptr;
+    }
+    if (strcmp(name, "sh_fp16") == 0) t->sh16_of = nullptr;
+    return GS_OK;
+}
+
 extern "C" int gs_trainer_set_allreduce(gs_trainer* t, gs_allreduce_fn fn, void* user) {
     if (!t) return GS_ERR_INVALID_ARGUMENT;
     t->allreduce = fn; t->allreduce_user = user;
@@ -979,7 +1011,7 @@ extern "C" int gs_trainer_render(gs_trainer* t, uint32_t* fb, int fb_on_device, 
     DevBuf fbdev;
     for (int attempt = 0;; attempt++) {
         GS_TRY(t->preview.ensure(m->count, 1, w, h, rcap));
-        Dims d = make_dims(m->count, m->Pa, D, m->sh_coeffs, w, h, 1, t->preview.Rcap, splat_scale);
+        Dims d = make_dims(m->count, m->Pa, D, m->sh_coeffs, w, h, 1, t->preview.Rcap, splat_scale, -1, t->opt.cull);
         Scratch s = t->preview.s;
         std::vector<char> vb;
         build_view_block(view, 1, false, vb);

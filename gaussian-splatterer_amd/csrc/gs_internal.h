@@ -13,8 +13,6 @@ namespace gs {
 // error plumbing
 // ---------------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
-int option_cull();
-int option_share_passes();
 #define GS_HIP(expr)                                                                           \
     do {                                                                                       \
         hipError_t e__ = (expr);                                                               \
@@ -110,6 +108,7 @@ struct Scratch {
     float* G;                  // [V][Rcap][G_STRIDE]
     float* splat_grads;        // [V][Pa][16]  per-(view,splat) backward records (trainer only)
     float* sh_jac;             // [G][Pa][12]  d colour / d view direction (9 used), written by the projection (trainer only, else null)
+    const uint16_t* sh16;      // [3M][Pa] IEEE half read copy of the SH planes (trainer option "sh_fp16"), or null: read the fp32 planes
     float* out_color;          // [V][3][N]
     float* final_T;            // [V][N]
     uint32_t* n_contrib;       // [V][N]
@@ -149,8 +148,11 @@ int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch&
 struct SeamGrads { float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot; };
 int launch_splat_backward_seam(const Dims& d, const float* params, const Scratch& s, const SeamGrads& g, hipStream_t st);
 // updates the flat element range [lo, hi) of the parameter planes (default: all of them)
+// sh16 != null: the fp16 read copy of every SH element this launch updates is refreshed in the same pass
 int launch_update(const Planes& pl, int P, int Pa, float* params, float* grads, float* adam_m, float* adam_v, int adam_t,
-                  const gs_hyper& h, hipStream_t st, size_t lo = 0, size_t hi = ~(size_t)0);
+                  const gs_hyper& h, hipStream_t st, size_t lo = 0, size_t hi = ~(size_t)0, uint16_t* sh16 = nullptr);
+// fp16 read copy of all SH planes: sh16[k * Pa + i] = half(planes[(3 + k) * Pa + i]), round to nearest even
+int launch_sh_to_half(int M, int P, int Pa, const float* planes, uint16_t* sh16, hipStream_t st);
 // Floats every plane-major buffer of a model is allocated with: the 11+3M parameter planes, one spare plane (the
 // gradient buffer's `var`), and padding so that the buffer divides into equal chunks for any rank count <= 64 (the
 // sharded update reduce-scatters gradients and all-gathers parameters with ONE chunking, gs_trainer_set_sharded_update).
@@ -167,7 +169,6 @@ int launch_image_float_to_int(const float* src, uint32_t* fb, int w, int h, hipS
 int launch_image_int_to_loss(const uint32_t* truth, const float* rast, float* loss, int w, int h, hipStream_t st);
 int launch_ranges(const Dims& d, const Scratch& s, uint32_t* ranges, hipStream_t st);
 int launch_debug_reduce9(const float* in, float* out, hipStream_t st);
-int launch_debug_group8(const float* in, float* out, hipStream_t st);
 
 // densify / prune on the device (k_densify.hip; the reference does it on the CPU, src/Trainer.cu:433-542)
 int launch_densify_classify(int count, int Pa, int M, const float* params, const float* grad, const gs_hyper& h, uint32_t* flags,

@@ -6,6 +6,8 @@
 // 256-byte coalesced wave loads.  Built with -ffp-contract=off: every fp32 operation here is an
 // individually rounded IEEE operation in the same order as oracle/gs_oracle.cpp::preprocess, so
 // depth, radius and tile rectangle (and therefore the sorted tile lists) are bit-identical.
+#include <hip/hip_fp16.h>
+
 #include "gs_internal.h"
 #include "sh_jac.h"
 
@@ -20,7 +22,9 @@ __device__ __constant__ float SH_C3[7] = { -0.5900435899266435f, 2.8906114426405
                                            -0.5900435899266435f };
 
 // one (view, splat): writes the record and tiles_touched, counts the splat into its super-tiles; returns tiles_touched
-template <int D>
+// H: the SH coefficients come from the trainer's half-precision read copy (s.sh16) instead of the fp32 planes; everything
+// else — geometry, lists, ranges — does not touch SH and is bit-identical in both modes.
+template <int D, bool H>
 __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict__ params, const Scratch& s, int i, int v,
                                           uint32_t* hist) {
     const gs_view& vp = s.gviews[v];  // v indexes geometry groups here
@@ -118,33 +122,38 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict
     dx = dx / len; dy = dy / len; dz = dz / len;
     float res[3], jac[9];
     uint32_t flags = 0;
+    const __half* sh16 = reinterpret_cast<const __half*>(s.sh16);
+    auto shv = [&](int k, int c) -> float {
+        if constexpr (H) return __half2float(sh16[(size_t)(3 * k + c) * st + i]);
+        else return params[pl.sh(k, c) * st + i];
+    };
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        float val = SH_C0 * params[pl.sh(0, c) * st + i];
+        float val = SH_C0 * shv(0, c);
         if (D > 0) {
             const float X = dx, Y = dy, Z = dz;
-            val = val - SH_C1 * Y * params[pl.sh(1, c) * st + i] + SH_C1 * Z * params[pl.sh(2, c) * st + i] -
-                  SH_C1 * X * params[pl.sh(3, c) * st + i];
+            val = val - SH_C1 * Y * shv(1, c) + SH_C1 * Z * shv(2, c) -
+                  SH_C1 * X * shv(3, c);
             if (D > 1) {
                 const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
-                val = val + SH_C2[0] * xy * params[pl.sh(4, c) * st + i] + SH_C2[1] * yz * params[pl.sh(5, c) * st + i] +
-                      SH_C2[2] * (2.0f * zz - xx - yy) * params[pl.sh(6, c) * st + i] +
-                      SH_C2[3] * xz * params[pl.sh(7, c) * st + i] + SH_C2[4] * (xx - yy) * params[pl.sh(8, c) * st + i];
+                val = val + SH_C2[0] * xy * shv(4, c) + SH_C2[1] * yz * shv(5, c) +
+                      SH_C2[2] * (2.0f * zz - xx - yy) * shv(6, c) +
+                      SH_C2[3] * xz * shv(7, c) + SH_C2[4] * (xx - yy) * shv(8, c);
                 if (D > 2) {
-                    val = val + SH_C3[0] * Y * (3.0f * xx - yy) * params[pl.sh(9, c) * st + i] +
-                          SH_C3[1] * xy * Z * params[pl.sh(10, c) * st + i] +
-                          SH_C3[2] * Y * (4.0f * zz - xx - yy) * params[pl.sh(11, c) * st + i] +
-                          SH_C3[3] * Z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * params[pl.sh(12, c) * st + i] +
-                          SH_C3[4] * X * (4.0f * zz - xx - yy) * params[pl.sh(13, c) * st + i] +
-                          SH_C3[5] * Z * (xx - yy) * params[pl.sh(14, c) * st + i] +
-                          SH_C3[6] * X * (xx - 3.0f * yy) * params[pl.sh(15, c) * st + i];
+                    val = val + SH_C3[0] * Y * (3.0f * xx - yy) * shv(9, c) +
+                          SH_C3[1] * xy * Z * shv(10, c) +
+                          SH_C3[2] * Y * (4.0f * zz - xx - yy) * shv(11, c) +
+                          SH_C3[3] * Z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * shv(12, c) +
+                          SH_C3[4] * X * (4.0f * zz - xx - yy) * shv(13, c) +
+                          SH_C3[5] * Z * (xx - yy) * shv(14, c) +
+                          SH_C3[6] * X * (xx - 3.0f * yy) * shv(15, c);
                 }
             }
         }
         val += 0.5f;
         if (val < 0.0f) flags |= (1u << c);
         res[c] = fmaxf(val, 0.0f);
-        if (s.sh_jac) sh_direction_jacobian<D>(dx, dy, dz, [&](int k) { return params[pl.sh(k, c) * st + i]; }, jac[3 * c], jac[3 * c + 1], jac[3 * c + 2]);
+        if (s.sh_jac) sh_direction_jacobian<D>(dx, dy, dz, [&](int k) { return shv(k, c); }, jac[3 * c], jac[3 * c + 1], jac[3 * c + 2]);
     }
     if (s.sh_jac) {  // for the per-splat backward of every pass of this camera (sh_jac.h)
         float4* jrec = reinterpret_cast<float4*>(s.sh_jac + ((size_t)v * st + i) * 12);
@@ -186,7 +195,7 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict
     return ntiles;
 }
 
-template <int D>
+template <int D, bool H>
 __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restrict__ params, Scratch s) {
     extern __shared__ uint32_t hist[];  // [NST] candidates of this block per super-tile
     __shared__ uint32_t wsum[WG / 64];
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
     for (int k = threadIdx.x; k < d.NST; k += WG) hist[k] = 0;
     __syncthreads();
     uint32_t n = 0;
-    if (i < d.P) n = preprocess_one<D>(d, params, s, i, v, hist);
+    if (i < d.P) n = preprocess_one<D, H>(d, params, s, i, v, hist);
     // the block's share of the offsets scan (k_coarse_colscan's extra workgroup turns the block sums into prefixes, the coarse
     // scatter finishes the scan inside each block): no separate pass over tiles_touched
 #pragma unroll
@@ -212,11 +221,20 @@ int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipS
     if (d.P == 0 || d.VG == 0) return GS_OK;
     dim3 grid((d.P + WG - 1) / WG, d.VG);
     const size_t lds = (size_t)d.NST * sizeof(uint32_t);
-    switch (d.D) {
-        case 0: hipLaunchKernelGGL(k_preprocess<0>, grid, dim3(WG), lds, st, d, params, s); break;
-        case 1: hipLaunchKernelGGL(k_preprocess<1>, grid, dim3(WG), lds, st, d, params, s); break;
-        case 2: hipLaunchKernelGGL(k_preprocess<2>, grid, dim3(WG), lds, st, d, params, s); break;
-        default: hipLaunchKernelGGL(k_preprocess<3>, grid, dim3(WG), lds, st, d, params, s); break;
+    if (s.sh16) {
+        switch (d.D) {
+            case 0: hipLaunchKernelGGL((k_preprocess<0, true>), grid, dim3(WG), lds, st, d, params, s); break;
+            case 1: hipLaunchKernelGGL((k_preprocess<1, true>), grid, dim3(WG), lds, st, d, params, s); break;
+            case 2: hipLaunchKernelGGL((k_preprocess<2, true>), grid, dim3(WG), lds, st, d, params, s); break;
+            default: hipLaunchKernelGGL((k_preprocess<3, true>), grid, dim3(WG), lds, st, d, params, s); break;
+        }
+    } else {
+        switch (d.D) {
+            case 0: hipLaunchKernelGGL((k_preprocess<0, false>), grid, dim3(WG), lds, st, d, params, s); break;
+            case 1: hipLaunchKernelGGL((k_preprocess<1, false>), grid, dim3(WG), lds, st, d, params, s); break;
+            case 2: hipLaunchKernelGGL((k_preprocess<2, false>), grid, dim3(WG), lds, st, d, params, s); break;
+            default: hipLaunchKernelGGL((k_preprocess<3, false>), grid, dim3(WG), lds, st, d, params, s); break;
+        }
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

@@ -7,21 +7,19 @@
 //   * workgroup = one 16x16 tile = 4 wave64; each WAVE owns an 8x8 pixel block, lane = pixel.
 //   * the tile's depth-ordered list is staged through LDS (48-byte records gathered from the
 //     64-byte per-splat lines written by preprocess, conic pre-scaled to base 2): 256 entries per round
-//     forward, 64 backward (12.6 - 22 KB of LDS per workgroup, 8 / 7 waves per SIMD).
+//     forward, 64 backward (12.5 / 20.9 KB of LDS per workgroup, 8 / 7 waves per SIMD).
 //   * workgroups take tiles longest list first (tile_order), so a launch ends on light tiles.
 //   * per 64 staged entries every lane tests ONE entry's "alpha >= 1/255" box against the wave's
 //     8x8 block; the ballot is a scalar bit list and only surviving entries are evaluated — the
 //     skipped pairs are exactly ones the reference blend would skip too, so results are unchanged.
 //     (Reading the next surviving entry's record one iteration early was measured slower: at 8 waves
 //     per SIMD the LDS latency is covered and the extra selects cost issue slots.)
-//   * backward: the nine per-pair partial derivatives are reduced across the 64 lanes by a DPP
-//     reduce-scatter (24 VALU instructions instead of 54: every stage halves the number of live
-//     values; bank masks give the per-lane value selection for free; the four 16-lane rows are folded
-//     by two ds_bpermute on the LDS pipe), each wave parks its sums in
-//     its own LDS slot, the four slots are added in fixed order and written as ONE 36-byte row per
-//     (splat,tile) entry.  No global atomic anywhere; the result is bitwise reproducible.
-//     A step without densify runs this once per CAMERA on the sum of its passes' residual images
-//     (render_bwd_body<1, 2>), not once per pass.
+//   * backward: a hit parks two values per pixel (w = alpha T, u = G dL/dalpha) in a per-wave LDS buffer; every four hits
+//     the wave contracts the buffer over the pixels with plain FMAs (lane = (hit, four pixels of a row)) and folds the 16
+//     lanes of a hit with a 24-instruction DPP reduce-scatter; each wave keeps its nine sums per entry in its own LDS
+//     slot, the four slots are added in fixed order and written as ONE 36-byte row per (splat, tile) entry.  No global
+//     atomic anywhere; the result is bitwise reproducible.  A step without densify runs this once per CAMERA on the sum
+//     of its passes' residual images (render_bwd<2>), not once per pass.
 #include "gs_internal.h"
 
 namespace gs {
@@ -30,15 +28,8 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_STOP = 0.0001f;
 constexpr int ACC_STRIDE = 9;
-constexpr int BWD_ROUND = 128;  // entries staged per backward round
-#ifndef GS_BWD_ROUND_PAIR
-#define GS_BWD_ROUND_PAIR 64  // fused-pair kernel (tuning hook): 64 entries, 12.6 KB LDS and 64 VGPRs -> 8 waves per SIMD
-#endif                        // measured 0.903 ms per 16-view launch against 0.938 at 128 entries / 6 waves
 #ifndef GS_BWD_PAIR_WAVES
-#define GS_BWD_PAIR_WAVES 7
-#endif
-#ifndef GS_BWD_ROUND_K2
-#define GS_BWD_ROUND_K2 (BWD_ROUND / 2)  // tuning hook (tools/build_variant.sh)
+#define GS_BWD_PAIR_WAVES 7  // occupancy target of the fused-pair backward (tuning hook, tools/build_variant.sh)
 #endif
 
 // Exact "can this splat reach alpha >= 1/255 anywhere in the 8x8 block" test: the minimum of the conic's
@@ -190,66 +181,14 @@ __device__ inline float wave_sum_to_lane63(float x) {
     return x;
 }
 
-// Reduce-scatter of nine per-lane values over the wave.  Returns r such that, in EVERY 16-lane row,
-// lane 2q (q = 0..7) holds the wave total of g_q and lane 1 holds the wave total of g8.
+// Reduce-scatter of nine per-lane values over every 16-lane ROW of the wave.  Returns r such that lane 2q (q = 0..7) of
+// a row holds the row total of g_q and lane 1 the row total of g8.
 //   stage A  lane ^ 8 (row_ror:8): lanes with bit3 = 0 keep g0..g3, lanes with bit3 = 1 keep g4..g7
 //   stage B  bank ^ 1 (row_ror:12 / row_ror:4): bit2 selects the lower / upper two of the four
 //   stage C  lane ^ 2 (quad_perm):               bit1 selects one of the two
-//   stage D  lane ^ 1, then the four rows are folded with permlane16/32 swaps (lane-wise)
-// bank_mask predicates whole 4-lane banks, so stages A and B need no select instructions.
-// EXEC must be all ones (the callers are in wave-uniform control flow).
-__device__ inline float wave_reduce_scatter9(float g0, float g1, float g2, float g3, float g4, float g5, float g6, float g7,
-                                             float g8) {
-    float t0, t1;
-    const unsigned long long mask_bit1 = 0xCCCCCCCCCCCCCCCCull;  // lanes with bit 1 set
-    const unsigned long long mask_lane1 = 0x0002000200020002ull;  // lane % 16 == 1
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        // stage B: banks 0,2 (bit2 = 0) pair with bank+1 (row_ror:12 reads lane+4); banks 1,3 with bank-1 (row_ror:4)
-        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %1, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
-        // stage C: bit1 ? keep g1 / send g0 : keep g0 / send g1
-        "v_cndmask_b32_e64 %9, %0, %1, %11\n\t"
-        "v_cndmask_b32_e64 %10, %1, %0, %11\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %9, %10, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        // lane 1 of every row (a duplicate of lane 0) takes the row sum of g8, then fold the rows lane-wise
-        "v_cndmask_b32_e64 %9, %9, %8, %12\n\t"
-        "v_mov_b32_e32 %10, %9\n\t"
-        "s_nop 1\n\t"
-        "v_permlane16_swap_b32_e32 %9, %10\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_e32 %9, %9, %10\n\t"
-        "v_mov_b32_e32 %10, %9\n\t"
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32_e32 %9, %10\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_e32 %9, %9, %10\n\t"
-        : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7), "+v"(g8), "=&v"(t0), "=&v"(t1)
-        : "s"(mask_bit1), "s"(mask_lane1));
-    return t0;
-}
-
-// Form used by the backward kernel: stages A-D and the g8 merge only — on return every 16-lane ROW holds its own
-// row totals (lane 2q: value q, lane 1: value 8).  The caller folds the four rows lane-wise with two
-// ds_bpermute_b32 (the LDS crossbar, no VALU issue slot): v_permlane16/32_swap cost 8.2 cycles each on gfx950
-// (tools/valu_rate.hip) and needed a v_mov and wait states apiece.
+//   stage D  lane ^ 1
+// bank_mask predicates whole 4-lane banks, so stages A and B need no select instructions (24 instructions instead of the
+// 36 of nine butterflies).  EXEC must be all ones (the callers are in wave-uniform control flow).
 __device__ inline float wave_reduce_scatter9_rows(float g0, float g1, float g2, float g3, float g4, float g5, float g6, float g7,
                                                   float g8) {
     float t0, t1;
@@ -285,10 +224,10 @@ __device__ inline float wave_reduce_scatter9_rows(float g0, float g1, float g2, 
     return t0;
 }
 
-// debug entry: one wave, in[q][lane] -> out[lane] = wave_reduce_scatter9(...) (tests/test_gpu_raster.py)
+// debug entry: one wave, in[q][lane] -> out[lane] = wave_reduce_scatter9_rows(...) (tests/test_gpu_raster.py)
 __global__ void k_debug_reduce9(const float* __restrict__ in, float* __restrict__ out) {
     const int l = threadIdx.x;
-    out[l] = wave_reduce_scatter9(in[l], in[64 + l], in[128 + l], in[192 + l], in[256 + l], in[320 + l], in[384 + l],
+    out[l] = wave_reduce_scatter9_rows(in[l], in[64 + l], in[128 + l], in[192 + l], in[256 + l], in[320 + l], in[384 + l],
                                   in[448 + l], in[512 + l]);
 }
 int launch_debug_reduce9(const float* in, float* out, hipStream_t st) {
@@ -298,87 +237,30 @@ int launch_debug_reduce9(const float* in, float* out, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// pixel sums by LDS hand-off (single gradient set: the step's fused-pair kernel and the rasterizer seam)
+// pixel sums of the backward by LDS hand-off
 // ---------------------------------------------------------------------------------------------
 // The nine per-(entry, 8x8 block) sums are contractions over the block's 64 pixels of two per-pixel values,
 //   w = alpha * T (with the per-pixel constant dL/dpixel)   and   u = G * dL/dalpha (with 1, dx, dy, dx^2, dx dy, dy^2).
-// A hit therefore parks only (w, u) of its 64 lanes in a per-wave LDS buffer (one ds_write2_b32) and goes on; after
-// BATCH = 8 hits the wave contracts the buffer with PLAIN fp32 FMAs: lane (hit h = lane / 8, pixel row r = lane % 8)
-// reads the eight pixels of row r of hit h (eight conflict-free ds_read_b64: the hit stride of 520 bytes puts the 32
-// lanes of a half wave on 32 different 8-byte bank pairs), forms the row's partial sums — dy is constant along a row,
-// so only  sum u, sum u dx, sum u dx^2  and the three colour sums are accumulated per pixel (8 VALU per pixel) — and the
-// eight rows of a hit are folded by a 20-instruction DPP reduce-scatter over 8 lanes.  Per hit that is ~8 full-rate
-// VALU + 2.5 DPP instead of the 9 multiplies + 24 half-rate DPP adds + 2 ds_bpermute of wave_reduce_scatter9_rows
-// (still used by the two-gradient-set kernel), measured in profiles/r03/.
-#ifndef GS_PARK_BATCH
-#define GS_PARK_BATCH 4                   // tuning hook: 8 = 8 lanes x 8 pixels per hit (16.6 KB, 5 waves/SIMD), 4 = 16 lanes x 4 pixels (8.3 KB, 7 waves/SIMD)
-#endif
-constexpr int PARK_BATCH = GS_PARK_BATCH; // hits per contraction
-constexpr int PARK_LPH = 64 / PARK_BATCH; // lanes per hit
-constexpr int PARK_PPL = 64 / PARK_LPH;   // pixels per lane: consecutive pixels of one row of the 8x8 block
-static_assert(PARK_BATCH == 4 || PARK_BATCH == 8, "a hit's 64 pixels go to 16 or 8 lanes");
+// A hit therefore parks only (w, u) of its 64 lanes in a per-wave LDS buffer (one ds_write2st64_b32) and goes on; after
+// PARK_BATCH = 4 hits the wave contracts the buffer with PLAIN fp32 FMAs: lane (hit h = lane / 16, sub = lane % 16) reads
+// pixels 4 sub .. 4 sub + 3 of hit h (four consecutive pixels of one row; conflict-free ds_read_b64: the hit stride of 520
+// bytes puts the 32 lanes of a half wave on 32 different 8-byte bank pairs), forms the partial colour sums and the
+// moments of u in dx — dy is constant for the lane — and the 16 lanes of a hit, one DPP row, are folded
+// by the 24-instruction reduce-scatter above.  Per hit: ~8 full-rate VALU + 6 DPP, against the 9 multiplies + 24
+// half-rate DPP adds + 2 ds_bpermute of reducing every hit in registers (round 2: 0.90 ms per 16-view launch; this
+// form 0.66).  A batch of 8 hits (8 lanes x 8 pixels, a 20-instruction fold) was built as well: its 16.6 KB of parking
+// space and 24 registers of dL/dpixel limit the kernel to 5 waves per SIMD, where it is latency-bound (0.90 ms).
+constexpr int PARK_BATCH = 4;             // hits per contraction
+constexpr int PARK_LPH = 64 / PARK_BATCH; // lanes per hit: one 16-lane DPP row
+constexpr int PARK_PPL = 64 / PARK_LPH;   // pixels per lane: four consecutive pixels of one row of the 8x8 block
 constexpr int PARK_STRIDE = 2 * 64 + 2;   // floats per parked hit: w[64] | u[64] | 8 bytes of padding (conflict-free ds_read_b64)
 
-// Reduce-scatter of eight per-lane values over every group of 8 consecutive lanes, plus the group total of a ninth.
-// Returns r such that lane (8h + r) holds the group-h total of value q(r) = (r & 4) + ((r >> 1) & 1) + 2 * (r & 1);
-// s8 comes back as the group total in every lane.  EXEC must be all ones.
-__device__ inline float group8_reduce_scatter9(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7,
-                                               float& s8) {
-    float t0, t1;
-    const unsigned long long mask_bit1 = 0xCCCCCCCCCCCCCCCCull;  // lanes with bit 1 set
-    const unsigned long long mask_bit0 = 0xAAAAAAAAAAAAAAAAull;  // lanes with bit 0 set
-    asm volatile(
-        "s_nop 1\n\t"
-        // stage A, lane ^ 4: banks 0,2 (bit2 = 0) keep s0..s3, banks 1,3 keep s4..s7 (bank_mask selects, no v_cndmask)
-        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %0, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %1, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %2, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %3, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        // stage B, lane ^ 2: bit1 ? keep the odd one of a pair, send the even one : the other way round
-        "v_cndmask_b32_e64 %9, %0, %1, %11\n\t"
-        "v_cndmask_b32_e64 %10, %1, %0, %11\n\t"
-        "v_cndmask_b32_e64 %4, %2, %3, %11\n\t"
-        "v_cndmask_b32_e64 %5, %3, %2, %11\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %9, %10, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %5, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        // stage C, lane ^ 1
-        "v_cndmask_b32_e64 %10, %9, %4, %12\n\t"
-        "v_cndmask_b32_e64 %5, %4, %9, %12\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %10, %5, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7), "+v"(s8), "=&v"(t0), "=&v"(t1)
-        : "s"(mask_bit1), "s"(mask_bit0));
-    return t1;
-}
-
-// debug entry: one wave, in[q][lane] -> out[lane] = group8_reduce_scatter9(...), out[64 + lane] = s8 (tests/test_gpu_raster.py)
-__global__ void k_debug_group8(const float* __restrict__ in, float* __restrict__ out) {
-    const int l = threadIdx.x;
-    float s8 = in[512 + l];
-    out[l] = group8_reduce_scatter9(in[l], in[64 + l], in[128 + l], in[192 + l], in[256 + l], in[320 + l], in[384 + l], in[448 + l], s8);
-    out[64 + l] = s8;
-}
-int launch_debug_group8(const float* in, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_debug_group8, dim3(1), dim3(64), 0, st, in, out);
-    GS_HIP(hipGetLastError());
-    return GS_OK;
-}
-
-// Contracts the wave's parked hits (nb <= PARK_BATCH of them; their staging slots packed 8 bits apiece in blo, newest in the low byte) and stores
-// the nine sums of every hit in the wave's accumulator slots acc[entry * ACC_STRIDE + q].
-//   dpr[c][i]  dL/dpixel channel c of pixel (row lane % 8, column i) of the wave's block;  pxcol0 = x of column 0;
-//   pyrow      y of this lane's row.
+// Contracts the wave's parked hits (nb <= PARK_BATCH of them; their staging slots packed 8 bits apiece in blo, newest in
+// the low byte) and stores the nine sums of every hit in the wave's accumulator slots acc[slot * ACC_STRIDE + q].
+//   dpr[c][i]  dL/dpixel channel c of this lane's i-th pixel;  pxcol0 = x of its first pixel;  pyrow = y of its row.
 template <int N>
 __device__ __forceinline__ void contract_parked(const float* __restrict__ park, const StagedTile<N>& st, float* __restrict__ acc, int nb,
                                                 uint32_t blo, const float (&dpr)[3][PARK_PPL], float pxcol0, float pyrow, int lane) {
-    static_assert(PARK_BATCH == 4, "the packed slot word holds four hits");
     const int h = lane / PARK_LPH, sub = lane % PARK_LPH;
     const int jj = (int)__builtin_amdgcn_ubfe(blo, (uint32_t)(8 * (nb - 1 - h)) & 31u, 8u);  // hit h of the batch (parking order)
     const float2 xy = *reinterpret_cast<const float2*>(&st.A[jj]);
@@ -388,288 +270,41 @@ __device__ __forceinline__ void contract_parked(const float* __restrict__ park, 
     for (int k = 0; k < PARK_PPL / 2; k++) { const float2 t = row[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
 #pragma unroll
     for (int k = 0; k < PARK_PPL / 2; k++) { const float2 t = row[32 + k]; u[2 * k] = t.x; u[2 * k + 1] = t.y; }
-    // colour sums, and the moments of u over the lane's pixel INDEX i (dx_i = X0 - i with X0 = x - first pixel's x):
-    //   sum u dx = X0 n0 - n1,   sum u dx^2 = X0 (X0 n0 - 2 n1) + n2.
-    // The expansion loses log2(X0^2 / dx^2) bits against forming dx per pixel; over a span of four pixels and with the
-    // 0.3 px^2 low-pass on every splat that is < 6 bits in the worst case (a minimal splat centred inside the span) —
-    // the budget of the parity tests is 1e-4 of sum |term| — and it halves the VALU work of the moments.
-    float a0 = w[0] * dpr[0][0], a1 = w[0] * dpr[1][0], a2 = w[0] * dpr[2][0];
-    float n0 = u[0], n1 = 0.0f, n2 = 0.0f;
+    // colour sums and the moments of u; dx is formed per pixel exactly as the hit formed it.  (Moments over the pixel INDEX,
+    // sum u dx^2 = X0 (X0 n0 - 2 n1) + n2 with X0 = x - first pixel, cost 7 VALU less per contraction and were built: they
+    // cancel catastrophically for a splat centred on a pixel column whose neighbours fall under the alpha cut — one live
+    // pixel with dx ~ 0.01 per lane — and failed the long-list parity test by 15 x sum|term|.)
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
-    for (int i = 1; i < PARK_PPL; i++) {
+    for (int i = 0; i < PARK_PPL; i++) {
+        const float dx = xy.x - (pxcol0 + (float)i);
+        const float ux = u[i] * dx;
+        m0 += u[i]; m1 += ux; m2 = fmaf(ux, dx, m2);
         a0 = fmaf(w[i], dpr[0][i], a0); a1 = fmaf(w[i], dpr[1][i], a1); a2 = fmaf(w[i], dpr[2][i], a2);
-        n0 += u[i]; n1 = fmaf((float)i, u[i], n1); n2 = fmaf((float)(i * i), u[i], n2);
     }
-    const float X0 = xy.x - pxcol0;
-    const float m0 = n0;
-    const float m1 = fmaf(X0, n0, -n1);
-    const float m2 = fmaf(X0, m1 - n1, n2);
     const float dy = xy.y - pyrow;
     const float m0y = m0 * dy;
     // order of the nine sums as everywhere else: colour(3), u dx, u dy, u dx dx, u dx dy, u dy dy, u
-    if constexpr (PARK_BATCH == 8) {
-        float s8 = m0;
-        const float red = group8_reduce_scatter9(a0, a1, a2, m1, m0y, m2, m1 * dy, m0y * dy, s8);
-        if (h < nb) {
-            const int q = (sub & 4) + ((sub >> 1) & 1) + 2 * (sub & 1);
-            acc[jj * ACC_STRIDE + q] = red;
-            if (sub == 0) acc[jj * ACC_STRIDE + 8] = s8;
-        }
-    } else {
-        const float red = wave_reduce_scatter9_rows(a0, a1, a2, m1, m0y, m2, m1 * dy, m0y * dy, m0);  // per 16-lane row: lane 2q -> q, lane 1 -> 8
-        if (h < nb && ((sub & 1) == 0 || sub == 1)) acc[jj * ACC_STRIDE + ((sub & 1) ? 8 : (sub >> 1))] = red;
-    }
+    const float red = wave_reduce_scatter9_rows(a0, a1, a2, m1, m0y, m2, m1 * dy, m0y * dy, m0);  // per 16-lane row: lane 2q -> q, lane 1 -> 8
+    if (h < nb && ((sub & 1) == 0 || sub == 1)) acc[jj * ACC_STRIDE + ((sub & 1) ? 8 : (sub >> 1))] = red;
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-// One workgroup = one tile of one camera, the passes of that camera at once (the reference's white- and
-// black-background pair).  Everything that does not depend on dL/dpixel — pair geometry, exp, alpha, the
-// transmittance recurrence, the accumulated colour behind — is evaluated once and shared.
-//   <K = 2, F = 1>  two gradient sets: the dL/dalpha chain, the nine sums and their reduction run per pass; one
-//                   gradient row per (entry, pass).  Needed when per-pass gradients are: accumulateGradients'
-//                   `var += |g_loc| / S` (src/Trainer.cu:52) takes the norm of every pass's location gradient.
-//   <K = 1, F = 2>  ONE gradient set for the pair.  Every other output of accumulateGradients is a plain sum over the
-//                   passes, and the whole backward is linear in dL/dpixel for a fixed camera, so the two residual
-//                   images are added per pixel (dL/dpixel = r_white + r_black, and T_final * (bg . r) likewise) and
-//                   the pair costs one single-pass backward: one row per (entry, camera), half the reductions.
-//                   `var` is not produced — the trainer takes this form on steps whose `var` nobody reads
-//                   (gs_trainer_step without densify; the reference recomputes var from zero every iteration and
-//                   reads it only inside the densify block, src/Trainer.cu:304-309,444,453).
-//   <K = 1, F = 1>  a single pass (rasterizer seam, cameras with an odd number of passes).
-template <int K, int F>
-__device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s, const int* __restrict__ items) {
-#pragma clang fp contract(fast)
-    static_assert(K * F <= 2, "an item carries two passes");
-    static_assert(K == 2, "single gradient sets take render_bwd_single");
-    constexpr int ROUND = GS_BWD_ROUND_K2;  // entries staged per round
-    __shared__ StagedTile<ROUND> st;
-    __shared__ uint32_t sSlot[ROUND];
-    __shared__ float sAcc[K * 4 * ROUND * ACC_STRIDE];
-    __shared__ unsigned long long sTouched[4][(ROUND + 63) / 64];
-    __shared__ uint32_t sMaxLast;
-    __shared__ float sLoss[K * F][4];
-    const int* item = items + 3 * blockIdx.y;  // {group, pass 0, pass 1}
-    const int g = item[0];                     // geometry group: lists, records, T and n_contrib live there
-    const int tile = (int)s.tile_order[(size_t)g * d.T + blockIdx.x];
-    int vin[K * F];  // the passes read: gradient set p sums passes vin[p * F .. p * F + F - 1]
-    int vp[K];       // where gradient set p's rows go: the slice of its first pass
-#pragma unroll
-    for (int q = 0; q < K * F; q++) vin[q] = item[1 + q];
-#pragma unroll
-    for (int p = 0; p < K; p++) vp[p] = vin[p * F];
-    if (s.flags[g * 4 + 0] & 1u) return;
-    const int tx = tile % d.gx, ty = tile / d.gx;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int bx0 = tx * TILE + (wave & 1) * 8, by0 = ty * TILE + (wave >> 1) * 8;
-    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
-    const bool inside = px < d.W && py < d.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float bxlo = (float)bx0, bxhi = (float)(bx0 + 7), bylo = (float)by0, byhi = (float)(by0 + 7);
-
-    const int n = (int)s.tile_count[(size_t)g * d.T + tile];
-    const uint32_t start = s.tile_end[(size_t)g * d.T + tile] - (uint32_t)n;
-    const uint32_t* __restrict__ plist = s.point_list + (size_t)g * d.Rcap + start;
-    const uint32_t* __restrict__ slist = s.slot_list + (size_t)g * d.Rcap + start;
-    const GeomRec* __restrict__ geom = s.geom + (size_t)g * d.Pa;
-
-    // per-pixel state
-    float T_final = 0.0f;
-    uint32_t last_contributor = 0;
-    float dpx[K][3], res2[K * F], tfbg[K];
-#pragma unroll
-    for (int p = 0; p < K; p++) { dpx[p][0] = dpx[p][1] = dpx[p][2] = 0.0f; tfbg[p] = 0.0f; }
-#pragma unroll
-    for (int q = 0; q < K * F; q++) res2[q] = 0.0f;
-    if (inside) {
-        const size_t pix = (size_t)py * d.W + px;
-        T_final = s.final_T[(size_t)g * d.N + pix];
-        last_contributor = s.n_contrib[(size_t)g * d.N + pix];
-#pragma unroll
-        for (int q = 0; q < K * F; q++) {
-            const int v = vin[q], p = q / F;
-            float r0, r1, r2;
-            if (s.dL_dpix) {
-                const float* gp = s.dL_dpix + (size_t)v * 3 * d.N;
-                r0 = gp[pix]; r1 = gp[(size_t)d.N + pix]; r2 = gp[2 * (size_t)d.N + pix];
-            } else {
-                // imageIntToLoss, src/Trainer.cu:33-44: truth/255 - rasterized
-                const uint32_t t = s.truth[(size_t)v * d.N + pix];
-                const float* out = s.out_color + (size_t)v * 3 * d.N;
-                r0 = ((float)(t & 0xFF) / 255.0f) - out[pix];
-                r1 = ((float)((t >> 8) & 0xFF) / 255.0f) - out[(size_t)d.N + pix];
-                r2 = ((float)((t >> 16) & 0xFF) / 255.0f) - out[2 * (size_t)d.N + pix];
-                res2[q] = r0 * r0 + r1 * r1 + r2 * r2;
-            }
-            const float* bg = s.views[v].bg;
-            dpx[p][0] += r0; dpx[p][1] += r1; dpx[p][2] += r2;
-            tfbg[p] += -T_final * (bg[0] * r0 + bg[1] * r1 + bg[2] * r2);
-        }
-    }
-    if (tid == 0) sMaxLast = 0;
-    __syncthreads();
-    // wave-uniform and block-uniform bounds on the traversal
-    uint32_t wave_max_last = last_contributor;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wave_max_last = max(wave_max_last, (uint32_t)__shfl_xor((int)wave_max_last, o));
-    wave_max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_last);  // uniform: branches on it become scalar
-    if (lane == 0) atomicMax(&sMaxLast, wave_max_last);
-    if (s.loss && !s.dL_dpix) {
-#pragma unroll
-        for (int q = 0; q < K * F; q++) {
-            const float l = wave_sum_to_lane63(res2[q]);
-            if (lane == 63) sLoss[q][wave] = l;
-        }
-    }
-    __syncthreads();
-    const int max_last = (int)sMaxLast;
-    if (s.loss && !s.dL_dpix && tid < K * F)  // fixed summation order: the loss statistic is reproducible too
-        s.loss[(size_t)vin[tid] * d.T + tile] = (sLoss[tid][0] + sLoss[tid][1]) + (sLoss[tid][2] + sLoss[tid][3]);
-    if (n == 0) return;
-    const int rounds = (max_last + ROUND - 1) / ROUND;
-    // entries no pixel reaches still own a gradient row per pass: zero it
-    for (int e = rounds * ROUND + tid; e < n; e += WG) {
-        const uint32_t slot = slist[e];
-#pragma unroll
-        for (int p = 0; p < K; p++) {
-            Row3* row = reinterpret_cast<Row3*>(s.G + ((size_t)vp[p] * d.Rcap + slot) * G_STRIDE);
-            row[0] = Row3{ 0, 0, 0 }; row[1] = Row3{ 0, 0, 0 }; row[2] = Row3{ 0, 0, 0 };
-        }
-    }
-
-    float T = T_final;
-    float ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f;  // accum_rec, already blended with the previously visited entry
-    const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
-    // where this lane parks a reduced value: lane 2q -> q, lane 1 -> 8 (row 0 only)
-    const bool writer = lane < 16 && (((lane & 1) == 0) || lane == 1);
-    const int wslot = (lane & 1) ? 8 : (lane >> 1);
-    const int fold16 = (lane ^ 16) << 2, fold32 = (lane ^ 32) << 2;  // ds_bpermute byte addresses of the row partners
-    float* const acc_lane = &sAcc[wave * ROUND * ACC_STRIDE + wslot];  // this lane's column of the wave's slots
-
-    for (int r = rounds - 1; r >= 0; r--) {
-        const int base = r * ROUND;
-        const int cnt = min(ROUND, n - base);
-        __syncthreads();  // previous round's flush has consumed st / sAcc / sTouched
-        if (tid < cnt) {
-            stage_entry(st, tid, geom + plist[base + tid]);
-            sSlot[tid] = slist[base + tid];
-        }
-        __syncthreads();
-        unsigned long long touched[(ROUND + 63) / 64];
-#pragma unroll
-        for (int sb = 0; sb < (ROUND + 63) / 64; sb++) touched[sb] = 0ull;
-#pragma unroll
-        for (int sb = (ROUND + 63) / 64 - 1; sb >= 0; sb--) {
-            const int sub = sb * 64;
-            if (sub >= cnt || (uint32_t)(base + sub) >= wave_max_last) continue;
-            const int j = sub + lane;
-            bool hit = false;
-            if (j < cnt && (uint32_t)(base + j) < wave_max_last) {
-                const float4 a = st.A[j];
-                hit = block_reaches(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
-            }
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int kk = 63 - __clzll((long long)mask);
-                mask &= ~(1ull << kk);
-                const int jj = sub + kk;
-                const float4 Ac = st.A[jj], Bc = st.B[jj];
-                const float cbc = st.C[jj].x;
-                asm volatile("" ::"v"(Bc.z), "v"(Bc.w), "v"(cbc));  // issue all three LDS reads up front, not inside the branch
-                const uint32_t pos = (uint32_t)(base + jj);  // upstream's `contributor` after its decrement
-                const float dx = Ac.x - pxf, dy = Ac.y - pyf;
-                const float power = dx * (Ac.z * dx + Ac.w * dy) + Bc.x * dy * dy;  // log2 of the Gaussian weight
-                const float G = __builtin_amdgcn_exp2f(power);
-                const float alpha = fminf(ALPHA_MAX, Bc.y * G);
-                const bool act = (pos < last_contributor) && power <= 0.0f && alpha >= ALPHA_MIN;
-                // (ballots of the three bare comparisons fold into the v_cmp results; a ballot of `act` itself costs a
-                // v_cndmask + v_cmp round trip through a VGPR)
-                const unsigned long long any_act = __builtin_amdgcn_ballot_w64(pos < last_contributor) &
-                                                   __builtin_amdgcn_ballot_w64(power <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
-                // Per lane only the colour terms and six moments of u = G * dL_dalpha are formed; the factors
-                // that are constant per splat (opacity, conic, 0.5*W, -0.5) are applied once per entry in the flush.
-                float dchannel_dcolor = 0.0f, u[K];
-#pragma unroll
-                for (int p = 0; p < K; p++) u[p] = 0.0f;
-                if (act) {
-                    const float keep = 1.0f - alpha;
-                    const float inv1ma = __builtin_amdgcn_rcpf(keep);
-                    T = T * inv1ma;
-                    dchannel_dcolor = alpha * T;
-                    // upstream blends (last_alpha, last_color) into accum_rec BEFORE using it; doing the same blend with
-                    // this entry's (alpha, colour) AFTER use is the identical recurrence one step early
-                    // (alpha*c + (1-alpha)*ar written as ar + alpha*(c - ar): one fma on the difference that is needed anyway)
-                    const float c0 = Bc.z - ar0, c1 = Bc.w - ar1, c2 = cbc - ar2;
-                    ar0 = fmaf(alpha, c0, ar0);
-                    ar1 = fmaf(alpha, c1, ar1);
-                    ar2 = fmaf(alpha, c2, ar2);
-                    const float GT = G * T, Gi = G * inv1ma;
-#pragma unroll
-                    for (int p = 0; p < K; p++) {
-                        float dL = c0 * dpx[p][0];
-                        dL += c1 * dpx[p][1];
-                        dL += c2 * dpx[p][2];
-                        u[p] = dL * GT + tfbg[p] * Gi;  // G * (dL_dalpha * T + tfbg / (1 - alpha)),  tfbg = -T_final * (bg . dL_dpix)
-                    }
-                }
-                if (any_act != 0ull) {
-                    // inactive lanes contribute exact zeros: dchannel_dcolor = u = 0 there
-#pragma unroll
-                    for (int p = 0; p < K; p++) {
-                        const float ux = u[p] * dx, uy = u[p] * dy;
-                        float red = wave_reduce_scatter9_rows(dchannel_dcolor * dpx[p][0], dchannel_dcolor * dpx[p][1],
-                                                              dchannel_dcolor * dpx[p][2], ux, uy, ux * dx, ux * dy, uy * dy, u[p]);
-                        red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold16, __builtin_bit_cast(int, red)));
-                        red += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fold32, __builtin_bit_cast(int, red)));
-                        if (writer) acc_lane[jj * ACC_STRIDE + p * (4 * ROUND * ACC_STRIDE)] = red;  // lane-constant base + scalar offset
-                    }
-                    touched[sb] |= 1ull << kk;
-                }
-            }
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int sb = 0; sb < (ROUND + 63) / 64; sb++) sTouched[wave][sb] = touched[sb];
-        }
-        __syncthreads();
-        if (tid < cnt) {
-            // moments -> the reference's nine sums (dx = mean2D.x - pixel.x as upstream):
-            //   dL_dmean2D.x = -0.5 W op (conA * S[u dx] + conB * S[u dy]),  .y = -0.5 H op (conC * S[u dy] + conB * S[u dx])
-            //   dL_dconic    = -0.5 op (S[u dx dx], S[u dx dy], S[u dy dy]),  dL_dopacity = S[u]
-            const float4 Af = st.A[tid], Bf = st.B[tid];
-            const float op = Bf.y, hop = -0.5f * op;
-            float conA, conB, conC;
-            unscaled_conic(Af, Bf, conA, conB, conC);
-            const uint32_t slot = sSlot[tid];
-#pragma unroll
-            for (int p = 0; p < K; p++) {
-                float sum[ACC_STRIDE];
-#pragma unroll
-                for (int q = 0; q < ACC_STRIDE; q++) sum[q] = 0.0f;
-#pragma unroll
-                for (int w = 0; w < 4; w++) {  // fixed order over the four waves; only slots written this round are read
-                    if ((sTouched[w][tid >> 6] >> (tid & 63)) & 1ull) {
-                        const float* a = &sAcc[((p * 4 + w) * ROUND + tid) * ACC_STRIDE];
-#pragma unroll
-                        for (int q = 0; q < ACC_STRIDE; q++) sum[q] += a[q];
-                    }
-                }
-                const float gmx = -ddelx_dx * op * (conA * sum[3] + conB * sum[4]);
-                const float gmy = -ddely_dy * op * (conC * sum[4] + conB * sum[3]);
-                Row3* row = reinterpret_cast<Row3*>(s.G + ((size_t)vp[p] * d.Rcap + slot) * G_STRIDE);
-                row[0] = Row3{ sum[0], sum[1], sum[2] };
-                row[1] = Row3{ gmx, gmy, hop * sum[5] };
-                row[2] = Row3{ hop * sum[6], hop * sum[7], sum[8] };
-            }
-        }
-    }
-}
-
-// Single gradient set (<F = 2>: the step's fused camera pair; <F = 1>: one pass — rasterizer seam, cameras with an odd
-// number of passes): the LDS hand-off form.  Differences from render_bwd_body besides the pixel sums:
-//   * a round is 64 entries = ONE ballot; slot s of the staging area holds entry 63 - s of the round, so walking the
-//     ballot's bits upwards (s_ff1 + s_bitset0) is the back-to-front traversal;
+// One workgroup = one tile of one camera and ONE gradient set: the sum of F passes' residual images.
+//   <F = 1>  a single pass: the rasterizer seam, and every pass of a step that needs per-pass gradients —
+//            accumulateGradients' `var += |g_loc| / S` (src/Trainer.cu:52) takes the norm of every pass's location
+//            gradient (densify steps, gs_trainer_accumulate).
+//   <F = 2>  the two passes of a camera (the reference's white / black pair) at once.  Every other output of
+//            accumulateGradients is a plain sum over the passes, and the whole backward is linear in dL/dpixel for a fixed
+//            camera, so the two residual images are added per pixel (dL/dpixel = r_white + r_black, and
+//            T_final * (bg . r) likewise) and the pair costs one single-pass backward.  `var` is not produced — the trainer
+//            takes this form on steps whose `var` nobody reads (gs_trainer_step without densify; the reference recomputes
+//            var from zero every iteration and reads it only inside the densify block, src/Trainer.cu:304-309,444,453).
+// Structure of a round (64 entries):
+//   * ONE ballot: lane l of every wave tests slot l against the wave's 8x8 block; slot s of the staging area holds entry
+//     63 - s of the round, so walking the ballot's bits upwards (s_ff1 + s_bitset0) is the back-to-front traversal;
 //   * the hit is branch-free: an inactive lane (behind the pixel's last contributor, power > 0, alpha < 1/255) continues
 //     with G = alpha = 0, which leaves T and the accumulated colour unchanged and parks exact zeros — two v_cndmask
 //     instead of an exec-masked region, and every hit is parked (no "did any lane act" test: the touched bits of the
@@ -677,8 +312,10 @@ __device__ __forceinline__ void render_bwd_body(const Dims& d, const Scratch& s,
 //   * all loop state (hit counter, packed slot indices, ballot) is wave-uniform and lives in SGPRs.
 // The scalar unit is shared by the CU's four SIMDs (4.7 cycles per SALU instruction per SIMD, tools/valu_rate.hip): the
 // first hand-off version spent 40 SALU instructions per hit on loop control, as much SIMD time as its VALU work.
+// (A two-gradient-set form that shared geometry, exp and the transmittance recurrence between the passes of a camera
+// existed through round 2; two launches of this kernel take the time it took.)
 template <int F>
-__device__ __forceinline__ void render_bwd_single(const Dims& d, const Scratch& s, const int* __restrict__ items) {
+__device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, const int* __restrict__ item) {
 #pragma clang fp contract(fast)
     constexpr int ROUND = 64;
     __shared__ StagedTile<ROUND> st;
@@ -688,15 +325,15 @@ __device__ __forceinline__ void render_bwd_single(const Dims& d, const Scratch& 
     __shared__ unsigned long long sTouched[4];
     __shared__ uint32_t sMaxLast;
     __shared__ float sLoss[F][4];
-    const int* item = items + 3 * blockIdx.y;  // {group, pass 0, pass 1}
-    const int g = item[0];                     // geometry group: lists, records, T and n_contrib live there
+    const int g = item[0];  // item = {group, pass 0[, pass 1]}; lists, records, T and n_contrib live in the geometry group
     const int tile = (int)s.tile_order[(size_t)g * d.T + blockIdx.x];
     int vin[F];  // the passes whose residual images are summed; the rows go to the slice of the first one
 #pragma unroll
     for (int q = 0; q < F; q++) vin[q] = item[1 + q];
     if (s.flags[g * 4 + 0] & 1u) return;
     const int tx = tile % d.gx, ty = tile / d.gx;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the per-wave roles below are scalar branches
     const int bx0 = tx * TILE + (wave & 1) * 8, by0 = ty * TILE + (wave >> 1) * 8;
     const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
     const bool inside = px < d.W && py < d.H;
@@ -924,26 +561,28 @@ int launch_loss_sum(const Dims& d, const Scratch& s, hipStream_t stream) {
     return GS_OK;
 }
 
-// Two entry points so that each can carry its own occupancy target: the two-pass form fits 7 waves per SIMD (72
-// VGPRs, 21.8 KB LDS; measured 3 % faster than the 6 the compiler picks by itself), the one-pass form is bounded by
-// its 25 KB of LDS at 6.
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_render_bwd2(Dims d, Scratch s, const int* __restrict__ items) {
-    render_bwd_body<2, 1>(d, s, items);
-}
-__global__ __launch_bounds__(WG) void k_render_bwd1(Dims d, Scratch s, const int* __restrict__ items) {
-    render_bwd_single<1>(d, s, items);
+// blockIdx.y enumerates passes for the per-pass form — the two passes of every pair item first, then the single items
+// (the order k_splat_bwd_view reads the rows in) — and pair items for the fused form.
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GS_BWD_PAIR_WAVES, GS_BWD_PAIR_WAVES))) void k_render_bwd1(Dims d, Scratch s, const int* __restrict__ items, int n_pairs) {
+    const int y = blockIdx.y;
+    const int* it = items + 3 * (y < 2 * n_pairs ? (y >> 1) : (y - n_pairs));
+    const int one[2] = { it[0], it[1 + (y < 2 * n_pairs ? (y & 1) : 0)] };
+    render_bwd<1>(d, s, one);
 }
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GS_BWD_PAIR_WAVES, GS_BWD_PAIR_WAVES))) void k_render_bwd_pair(Dims d, Scratch s, const int* __restrict__ items) {
-    render_bwd_single<2>(d, s, items);
+    render_bwd<2>(d, s, items + 3 * blockIdx.y);
 }
 
 // items: n2 pairs {group, pass a, pass b} followed by n1 singles {group, pass, -1} (device array of 3*(n2+n1) ints).
 // fuse_pairs: one gradient set per pair (rows in pass a's slice of G) instead of one per pass.
 int launch_render_backward(const Dims& d, const Scratch& s, const int* items, int n2, int n1, bool fuse_pairs, hipStream_t stream) {
     if (d.T == 0) return GS_OK;
-    if (n2 > 0 && fuse_pairs) hipLaunchKernelGGL(k_render_bwd_pair, dim3(d.T, n2), dim3(WG), 0, stream, d, s, items);
-    if (n2 > 0 && !fuse_pairs) hipLaunchKernelGGL(k_render_bwd2, dim3(d.T, n2), dim3(WG), 0, stream, d, s, items);
-    if (n1 > 0) hipLaunchKernelGGL(k_render_bwd1, dim3(d.T, n1), dim3(WG), 0, stream, d, s, items + 3 * n2);
+    if (n2 > 0 && fuse_pairs) {
+        hipLaunchKernelGGL(k_render_bwd_pair, dim3(d.T, n2), dim3(WG), 0, stream, d, s, items);
+        if (n1 > 0) hipLaunchKernelGGL(k_render_bwd1, dim3(d.T, n1), dim3(WG), 0, stream, d, s, items + 3 * n2, 0);
+    } else if (2 * n2 + n1 > 0) {
+        hipLaunchKernelGGL(k_render_bwd1, dim3(d.T, 2 * n2 + n1), dim3(WG), 0, stream, d, s, items, n2);
+    }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

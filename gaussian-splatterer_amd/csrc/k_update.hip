@@ -6,6 +6,8 @@
 // All HBM-bound elementwise work: plane-major SoA makes every wave access 256 contiguous bytes.
 #include <algorithm>
 
+#include <hip/hip_fp16.h>
+
 #include "gs_internal.h"
 
 namespace gs {
@@ -21,7 +23,8 @@ struct UpdateArgs {
 // under the data-parallel sharded update; blockIdx.y counts planes from the first one the range touches.
 __global__ __launch_bounds__(WG) void k_update(UpdateArgs u, int P, int Pa, float* __restrict__ params,
                                                const float* __restrict__ grads, float* __restrict__ am,
-                                               float* __restrict__ av, size_t lo, size_t hi, int first_plane) {
+                                               float* __restrict__ av, size_t lo, size_t hi, int first_plane,
+                                               __half* __restrict__ sh16) {
     const int i = blockIdx.x * WG + threadIdx.x;
     const int p = first_plane + blockIdx.y;
     if (i >= P) return;
@@ -50,10 +53,26 @@ __global__ __launch_bounds__(WG) void k_update(UpdateArgs u, int P, int Pa, floa
     if (kind == 1) x = fminf(u.scale_max, fmaxf(0.0f, x));
     else if (kind == 2) x = fminf(1.0f, fmaxf(0.0f, x));
     params[idx] = x;
+    // trainer option "sh_fp16": the projection reads the SH coefficients from a half-precision copy (BASELINE cfg5);
+    // the fp32 master above stays the optimiser's state — a learning rate of 1e-4 would vanish below half an fp16 ulp
+    if (sh16 && p >= 3 && p < pl.scale(0)) sh16[(size_t)(p - 3) * Pa + i] = __float2half_rn(x);
+}
+
+__global__ __launch_bounds__(WG) void k_sh_to_half(int P, int Pa, const float* __restrict__ planes, __half* __restrict__ sh16) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= P) return;
+    const size_t k = blockIdx.y;
+    sh16[k * Pa + i] = __float2half_rn(planes[(3 + k) * Pa + i]);
+}
+int launch_sh_to_half(int M, int P, int Pa, const float* planes, uint16_t* sh16, hipStream_t st) {
+    if (P == 0) return GS_OK;
+    hipLaunchKernelGGL(k_sh_to_half, dim3((P + WG - 1) / WG, 3 * M), dim3(WG), 0, st, P, Pa, planes, reinterpret_cast<__half*>(sh16));
+    GS_HIP(hipGetLastError());
+    return GS_OK;
 }
 
 int launch_update(const Planes& pl, int P, int Pa, float* params, float* grads, float* adam_m, float* adam_v, int adam_t,
-                  const gs_hyper& h, hipStream_t st, size_t lo, size_t hi) {
+                  const gs_hyper& h, hipStream_t st, size_t lo, size_t hi, uint16_t* sh16) {
     if (P == 0) return GS_OK;
     hi = std::min(hi, (size_t)pl.count() * Pa);
     if (lo >= hi) return GS_OK;
@@ -65,7 +84,7 @@ int launch_update(const Planes& pl, int P, int Pa, float* params, float* grads, 
     u.bc2 = 1.0f - powf(h.adam_beta2, (float)adam_t);
     u.M = pl.M;
     hipLaunchKernelGGL(k_update, dim3((P + WG - 1) / WG, last_plane - first_plane + 1), dim3(WG), 0, st, u, P, Pa, params,
-                       (const float*)grads, adam_m, adam_v, lo, hi, first_plane);
+                       (const float*)grads, adam_m, adam_v, lo, hi, first_plane, reinterpret_cast<__half*>(sh16));
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -189,6 +189,10 @@ class Trainer:
                                                 C.c_float(splatScale), C.byref(v)))
         return fb.reshape(sizeY, sizeX)
 
+    def set_option(self, name, value):
+        """gs_trainer_set_option: this trainer's switches (include/gsplat.h), e.g. "fuse_camera_passes", "sh_fp16"."""
+        capi.check(capi.lib().gs_trainer_set_option(self.handle, name.encode(), int(value)))
+
     def synchronize(self):
         capi.check(capi.lib().gs_trainer_synchronize(self.handle))
 

@@ -56,7 +56,9 @@ const char* gs_status_string(int status);
 int gs_version(int* major, int* minor, int* patch);
 /* Number of visible HIP devices (0 when none); never fails. */
 int gs_device_count(void);
-/* Process-wide diagnostic switches.  "cull" (default 1): the render kernels skip (splat, 8x8 pixel
+/* Switches.  gs_set_option edits the process-wide DEFAULTS: a trainer copies them when it is created and keeps its own
+ * set afterwards (gs_trainer_set_option, below); the rasterizer seam reads "cull" from the defaults.
+ * "cull" (default 1): the render kernels skip (splat, 8x8 pixel
  * block) pairs whose alpha >= 1/255 box misses the block; 0 evaluates every staged pair.  Results
  * are bit-identical either way (tests/test_gpu_raster.py checks exactly that).
  * "share_camera_passes" (default 1; read by gs_trainer_set_views): passes whose camera parameters are bit-identical
@@ -64,7 +66,8 @@ int gs_device_count(void);
  * forward blend; 0 recomputes them per pass like the reference.  Results are bit-identical either way.
  * "fuse_camera_passes" (default 1): gs_trainer_step WITHOUT densify runs ONE backward per camera on the sum of its
  * passes' residual images instead of one per pass (the backward is linear in dL/dpixel for a fixed camera).  All
- * averaged gradients are the same sums (re-associated: agreement ~1e-7); only `var`, which needs every pass's own
+ * averaged gradients are the same sums re-associated (measured distance from the per-pass form: <= 3e-6 of the splat's
+ * sum|term|, 99.9 % of the entries <= 4e-7; tests/test_gpu_trainer.py::test_step_sgd_matches_oracle); only `var`, which needs every pass's own
  * location gradient (src/Trainer.cu:52) and is read by the densify block alone (:444,453), is then not produced (its
  * plane of the gradient buffer is zero).  gs_trainer_accumulate and densify steps always take the per-pass form.
  * "arena_entries" (default 0 = max(2^20, 16*P)): initial capacity, in (splat, tile) entries per camera, of the binning
@@ -74,14 +77,10 @@ int gs_device_count(void);
  * "scan_single_max" (default 65536): the per-view scans of super-tile counters and tile counts run as one workgroup
  * per view up to this many items and as a three-phase scan beyond; results are identical either way. */
 int gs_set_option(const char* name, int value);
-/* Diagnostic: runs the backward kernel's 9-value wave reduce-scatter on one wave64.  in_host[q*64 + lane]
- * (q = 0..8), out_host[lane]: lane 2q of every 16-lane row holds the wave total of value q (q < 8), lane 1
- * the total of value 8. */
+/* Diagnostic: runs the backward kernel's 9-value reduce-scatter over the four 16-lane rows of one wave64 (a row = one
+ * parked hit in the kernel's contraction).  in_host[q*64 + lane] (q = 0..8), out_host[lane]: lane 2q of a row holds that
+ * row's total of value q (q < 8), lane 1 its total of value 8. */
 int gs_debug_wave_reduce9(const float* in_host, float* out_host);
-/* Diagnostic: the 8-lane-group form the single-gradient-set backward uses after its LDS hand-off.  in_host[q*64 + lane]
- * (q = 0..8), out_host[0..63]: lane 8h + r holds the total over lanes 8h..8h+7 of value (r & 4) + ((r >> 1) & 1) + 2 (r & 1);
- * out_host[64..127]: the group total of value 8 in every lane. */
-int gs_debug_group8_reduce9(const float* in_host, float* out_host);
 
 /* ------------------------------------------------------------------------------------------
  * Raw device-memory helpers (current HIP device).  They exist so that C / ctypes callers and the
@@ -201,6 +200,16 @@ int gs_trainer_step(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs_
 int gs_trainer_accumulate(gs_trainer* trainer, gs_step_stats* stats);
 int gs_trainer_grad_buffer(gs_trainer* trainer, float** device_ptr, size_t* n_floats);
 int gs_trainer_apply(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs_step_stats* stats);
+
+/* Per-trainer switches: the names gs_set_option documents (except "scan_single_max"), plus
+ * "sh_fp16" (default 0; BASELINE config 5's "fp16 SH coeffs"): the projection reads the SH coefficients from an IEEE-half
+ * READ COPY of the SH planes.  The fp32 planes stay the model (what gs_model_download returns and the optimiser updates:
+ * a learning rate of 1e-4 would vanish below half an fp16 ulp) and all gradients stay fp32; the update kernel refreshes
+ * the copy of every element it writes.  Geometry, tile lists and ranges do not depend on SH and are bit-identical with
+ * the switch on or off; colours and gradients are those of the fp32 path run on the half-rounded coefficients, bit for
+ * bit (tests/test_gpu_trainer.py::test_sh_fp16_*), i.e. within 2^-11 relative per coefficient of the fp32 result.
+ * Changing "share_camera_passes" regroups the passes already set. */
+int gs_trainer_set_option(gs_trainer* trainer, const char* name, int value);
 
 /* Optimizer state of GS_UPDATE_ADAM (build-side extension; the reference has none): device pointers to the first and
  * second moment, each [11+3M planes][plane stride] fp32 like the parameters, and the number of Adam steps taken.

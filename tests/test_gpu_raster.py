@@ -103,7 +103,7 @@ def pixel_stage_outliers(P, g, og, flip9=None):
     return bad
 
 
-def check_pixel_stage(P, g, r, dpix, max_allow_frac, assert_margin=ASSERT_MARGIN):
+def check_pixel_stage(P, g, r, dpix, max_allow_frac, assert_margin=ASSERT_MARGIN, max_allow_size=None, max_plain_outliers=None):
     """The nine sums against the oracle with NO splat excluded.  The error budget of a splat is 1e-4 of sum|term| (fp32
     summation) plus what a flipped blend decision can move: for every (pixel, splat) pair within a relative margin m
     of one of the two discrete thresholds (alpha = 1/255, T = 1e-4) the oracle re-runs the pixel with that decision
@@ -122,7 +122,15 @@ def check_pixel_stage(P, g, r, dpix, max_allow_frac, assert_margin=ASSERT_MARGIN
     print(f"pixel-stage outliers of {P} splats by flip margin: " + ", ".join(f"{m:g}: {counts[m]} (allowance on {100 * allow[m]:.2f} %)" for m in FLIP_MARGINS))
     assert counts[assert_margin] == 0, (counts, np.flatnonzero(bad_assert)[:10])
     assert allow[assert_margin] <= max_allow_frac, allow
-    assert counts[0.0] <= max(3, 0.02 * P), counts   # without any allowance only a handful of splats may be off at all
+    # how BIG the allowance is where it applies, in units of the sums' own scale sum|term|: an allowance that rivals
+    # sum|term| would bound nothing
+    size = (og_assert["flip9"] / np.maximum(og_assert["abs9"], 1e-30)).max(1)
+    size = size[og_assert["abs9"].max(1) > 0]
+    q50, q99, qmax = (float(np.quantile(size, q)) for q in (0.5, 0.99, 1.0)) if size.size else (0.0, 0.0, 0.0)
+    print(f"    flip allowance / sum|term| per splat (largest of the nine) at margin {assert_margin:g}: median {q50:.2e}, 99 % {q99:.2e}, max {qmax:.2e}")
+    if max_allow_size is not None:
+        assert q99 <= max_allow_size[0] and qmax <= max_allow_size[1], (q50, q99, qmax)
+    assert counts[0.0] <= (max(3, 0.02 * P) if max_plain_outliers is None else max_plain_outliers), counts   # without any allowance only a handful of splats may be off at all
     return og_assert
 
 
@@ -227,7 +235,10 @@ def test_long_tile_lists_take_the_spill_path(orc, P, longer_than):
     # large part of this scene (it is still a bound, not an exclusion: every splat is compared)
     # T is a running product of up to `longer_than` factors here: its fp32 rounding error grows to ~n * 2^-24 (5e-4 at
     # 8192 entries), so the T = 1e-4 decision can flip anywhere within that distance of the threshold: margin 1e-3
-    og = check_pixel_stage(P, g, r, dpix, max_allow_frac=1.0, assert_margin=1e-3)
+    # The allowance is bounded in SIZE instead: for 99 % of the splats it stays below half of sum|term| of the sum it
+    # protects (measured: median 4e-3..5e-3, 99 % 0.08..0.2; the maximum belongs to splats whose sum|term| is ~0), and
+    # without ANY allowance at most 0.2 % of the splats may leave the plain 1e-4 budget (measured: 0 and 8).
+    og = check_pixel_stage(P, g, r, dpix, max_allow_frac=1.0, assert_margin=1e-3, max_allow_size=(0.5, np.inf), max_plain_outliers=0.002 * P)
     assert_close_rel("dL_dopacity", g["dL_dopacity"], og["dL_dopacity"], rtol=1e-4, max_bad_frac=0.005)
 
 
@@ -299,27 +310,11 @@ def test_wave_reduce_scatter9_layout():
     vals = rng.integers(-50, 50, (9, 64)).astype(np.float32)
     out = np.zeros(64, np.float32)
     capi.check(capi.lib().gs_debug_wave_reduce9(vals.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
-    tot = vals.sum(1)
+    tot = vals.reshape(9, 4, 16).sum(2)   # [value][row]: a 16-lane row is one parked hit of the contraction
     for row in range(4):
         for q in range(8):
-            assert out[16 * row + 2 * q] == tot[q], (row, q, out.reshape(4, 16), tot)
-        assert out[16 * row + 1] == tot[8], (row, out.reshape(4, 16), tot)
-
-
-def test_group8_reduce_scatter9_layout():
-    """The 8-lane-group reduce-scatter behind the LDS hand-off backward: exact on integer data, documented layout."""
-    import ctypes as C
-    from gsplat_amd import capi
-    rng = np.random.default_rng(1)
-    vals = rng.integers(-50, 50, (9, 64)).astype(np.float32)
-    out = np.zeros(128, np.float32)
-    capi.check(capi.lib().gs_debug_group8_reduce9(vals.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
-    tot = vals.reshape(9, 8, 8).sum(2)   # [value][group]
-    for h in range(8):
-        for r in range(8):
-            q = (r & 4) + ((r >> 1) & 1) + 2 * (r & 1)
-            assert out[8 * h + r] == tot[q, h], (h, r, q, out[:64].reshape(8, 8), tot)
-            assert out[64 + 8 * h + r] == tot[8, h], (h, r, out[64:].reshape(8, 8), tot[8])
+            assert out[16 * row + 2 * q] == tot[q, row], (row, q, out.reshape(4, 16), tot)
+        assert out[16 * row + 1] == tot[8, row], (row, out.reshape(4, 16), tot)
 
 
 def test_rigid_motion_invariance_on_the_gpu():

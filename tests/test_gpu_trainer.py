@@ -8,7 +8,7 @@ import pytest
 
 import gsplat_amd as gs
 from gsplat_amd import capi
-from util import assert_close_rel, view_parts
+from util import assert_close_rel, step_budget, unexplained, view_parts
 
 pytestmark = pytest.mark.gpu
 
@@ -69,18 +69,41 @@ def _download(tr):
                                               (1000000, 16, 1, 2048, 2048)])  # BASELINE cfg5 size, one camera (white + black):
                                                                               # ~1100 entries per tile, long-list sort kernel
 def test_step_sgd_matches_oracle(orc, P, M, n_cams, W, H):
+    """The whole step against the oracle with every entry ACCOUNTED for: an averaged gradient may differ from the oracle's
+    by 1e-4 of sum|term| of the fp32 sums it is made of, carried through the per-splat chain and the pass average, plus the
+    decision-flip allowance (util.step_budget) — and by nothing else.  Zero unexplained entries are asserted at every
+    size, for the per-pass form (incl. `var`) and for the fused-pair step; the legacy array-scale bar is evaluated as
+    well and its outlier count PRINTED (round 2 allowed 0.2 % of the entries outside it without saying how many there were)."""
+    import time
     s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 0x5EED0001)
     proj = gs.Project()
     views = gs.camera.train_views(cams, W, H)
     truths = np.concatenate(fw + fb)
     o = orc.train_views(P, s["D"], M, W, H, s["loc"], s["sh"], s["scale"], s["opac"], s["rot"], views, truths, 2.0 * n_cams)
+    st = tr.accumulate(stats=True)
+    # T is a running product of one factor per blended entry: over n entries it carries ~n * 2^-24 of rounding error, which
+    # is how far from its threshold the T < 1e-4 decision can flip — 1e-4 covers lists up to ~1000 entries, the dense
+    # 1M-splat scene (up to ~3400 per tile) needs the wider margin the long-list seam tests use
+    flip_margin = 1e-4 if st.max_tile_list <= 1024 else 1e-3
+    t0 = time.time()
+    bud = step_budget(orc, s, s["D"], M, W, H, views, truths, 2.0 * n_cams, flip_margin=flip_margin)
+    t_budget = time.time() - t0
+
+    def legacy_outliers(got, want):
+        tol = 1e-4 * np.maximum(np.abs(want), 1e-3 * np.abs(want).max()) + 1e-30
+        return int((np.abs(got.astype(np.float64) - want) > tol).sum())
+
     # (1) the per-pass form (gs_trainer_accumulate / _apply; also what a densify step runs): every output of
     #     accumulateGradients, `var` included
-    st = tr.accumulate(stats=True)
     assert st.views == 2 * n_cams and st.num_rendered == int(o["num_rendered"].sum())
     g = _read_grads(tr, P, M)
+    report = []
+    stride = dict(loc=3, sh=3 * M, scale=3, opac=1, rot=4, var=1)
     for k in ["loc", "sh", "scale", "opac", "rot", "var"]:
-        assert_close_rel("avg_" + k, g[k], o[k], rtol=1e-4, max_bad_frac=0.002)
+        n_bad, worst = unexplained("avg_" + k, g[k], o[k], bud[k]["budget"], stride[k])
+        report.append(f"{k}: {n_bad} unexplained (worst error/budget {worst:.2f}), {legacy_outliers(g[k], o[k])} of {g[k].size} outside the array-scale bar")
+        assert n_bad == 0, (k, n_bad, worst)
+    print(f"[{P} splats, {2 * n_cams} passes @{W}x{H}] per-pass form vs oracle — " + "; ".join(report) + f"  (flip margin {flip_margin:g}, longest list {st.max_tile_list}; budget computed in {t_budget:.1f} s)")
     st = tr.apply(proj, stats=True)
     assert proj.iterations == 1 and st.count_after == P
     # the update itself is bit-exact: applyGradients on the GPU's own averaged gradients
@@ -91,16 +114,30 @@ def test_step_sgd_matches_oracle(orc, P, M, n_cams, W, H):
     for k in want:
         assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
     # (2) Trainer::train without densify (gs_trainer_step): one backward per camera on the summed residuals of its two
-    #     passes.  Same bar against the oracle for every averaged gradient; `var` has no reader on such a step and is zero.
+    #     passes.  Same accounting against the oracle (sum|term| of the per-pass sums bounds that of the fused sums, and the
+    #     passes of a camera share every blend decision); `var` has no reader on such a step and is zero.
     host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
     host.shDegree = s["D"]
     tr.model = gs.ModelSplatsDevice(host)
     st = tr.train(proj, densify=False, stats=True)
     assert proj.iterations == 2 and st.views == 2 * n_cams and st.num_rendered == int(o["num_rendered"].sum())
     gf = _read_grads(tr, P, M)
+    report, assoc = [], []
     for k in ["loc", "sh", "scale", "opac", "rot"]:
-        assert_close_rel("avg_" + k + " (fused pair)", gf[k], o[k], rtol=1e-4, max_bad_frac=0.002)
-        assert_close_rel("fused vs per-pass " + k, gf[k], g[k], rtol=1e-4, max_bad_frac=0.002)   # the same sums, re-associated
+        n_bad, worst = unexplained("avg_" + k + " (fused pair)", gf[k], o[k], bud[k]["budget"], stride[k])
+        report.append(f"{k}: {n_bad} unexplained (worst {worst:.2f}), {legacy_outliers(gf[k], o[k])} outside the array-scale bar")
+        assert n_bad == 0, (k, n_bad, worst)
+        # fused vs per-pass: the same sums re-associated; both forms share forward state and every decision, so no flip
+        # can separate them — the distance is measured in units of sum|term| and bounded by fp32 summation alone
+        # (in units of the splat's LARGEST sum|term| of that array: a component that nearly cancels carries its siblings'
+        # rounding noise, util.unexplained)
+        per_splat = np.repeat(bud[k]["sumabs"].reshape(-1, stride[k]).max(1), stride[k])
+        rel = np.abs(gf[k].astype(np.float64) - g[k]) / (per_splat + 1e-37)
+        rel = rel[per_splat > 0]
+        assoc.append((k, float(rel.max()) if rel.size else 0.0, float(np.quantile(rel, 0.999)) if rel.size else 0.0))
+        assert not rel.size or rel.max() <= 5e-6, (k, rel.max())   # measured on the MI355X: max <= 3e-6, 99.9 % <= 4e-7 at every size
+    print(f"[{P} splats, {2 * n_cams} passes @{W}x{H}] fused-pair step vs oracle — " + "; ".join(report))
+    print("    fused vs per-pass, |difference| / sum|term|: " + ", ".join(f"{k} max {a:.1e} p99.9 {b:.1e}" for k, a, b in assoc))
     assert not gf["var"].any()
     want = {k: s[k].copy() for k in ["loc", "sh", "scale", "opac", "rot"]}
     orc.apply_sgd(want["loc"], want["sh"], want["scale"], want["opac"], want["rot"], gf,
@@ -501,3 +538,106 @@ def test_non_finite_and_extreme_parameters_do_not_break_the_step(orc):
         tr.close()
     finally:
         capi.check(capi.lib().gs_set_option(b"debug_sync", 0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# trainer option "sh_fp16" (BASELINE config 5: "fp16 SH coeffs"): the projection reads a half-precision copy of the SH planes
+# ---------------------------------------------------------------------------------------------------------------------
+def _half_rounded(s):
+    r = dict(s)
+    r["sh"] = s["sh"].astype(np.float16).astype(np.float32)   # IEEE round-to-nearest-even, as v_cvt_f16_f32 does
+    return r
+
+
+def _trainer_on(s, cams, fw, fb, W, H, **options):
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = s["D"]
+    tr = gs.Trainer(W, H)
+    for k, v in options.items():
+        tr.set_option(k, v)
+    tr.model = gs.ModelSplatsDevice(host)
+    tr.captureTruths(cams, fw, fb)
+    return tr
+
+
+@pytest.mark.parametrize("M", [1, 4, 16])
+def test_sh_fp16_is_the_fp32_path_on_half_rounded_coefficients(orc, M):
+    """With "sh_fp16" the step must be, BIT FOR BIT, the fp32 step of a model whose SH coefficients were rounded to half
+    precision: same images, same statistics, same averaged gradients (every plane) — the fp32 master, the gradients and
+    everything that does not read SH (projection geometry, tile lists) are untouched.  Against the fp32 step on the
+    unrounded model: identical lists, colours within the half-precision rounding of the coefficients (printed)."""
+    P, n_cams, W, H = 3000, 3, 160, 128
+    s, cams, fw, fb, tr32 = _setup(orc, P, M, n_cams, W, H, 777)
+    st32 = tr32.accumulate(stats=True)
+    g32 = _read_grads(tr32, P, M)
+    img32 = [tr32.read_image(v) for v in range(2 * n_cams)]
+    tr32.close()
+    tr16 = _trainer_on(s, cams, fw, fb, W, H, sh_fp16=1)
+    st16 = tr16.accumulate(stats=True)
+    g16 = _read_grads(tr16, P, M)
+    img16 = [tr16.read_image(v) for v in range(2 * n_cams)]
+    kept = _download(tr16)
+    assert np.array_equal(kept["sh"].view(np.uint32), s["sh"].view(np.uint32))   # the fp32 master is what the model IS
+    tr16.close()
+    trr = _trainer_on(_half_rounded(s), cams, fw, fb, W, H)
+    str_ = trr.accumulate(stats=True)
+    gr = _read_grads(trr, P, M)
+    imgr = [trr.read_image(v) for v in range(2 * n_cams)]
+    trr.close()
+    assert (st16.num_rendered, st16.max_tile_list, st16.loss) == (str_.num_rendered, str_.max_tile_list, str_.loss)
+    for a, b in zip(img16, imgr):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for k in g16:
+        assert np.array_equal(g16[k].view(np.uint32), gr[k].view(np.uint32)), k
+    # against full precision: the lists do not depend on SH at all
+    assert (st16.num_rendered, st16.max_tile_list) == (st32.num_rendered, st32.max_tile_list)
+    err = max(float(np.abs(a - b).max()) for a, b in zip(img16, img32))
+    gerr = {k: float(np.abs(g16[k] - g32[k]).max() / max(np.abs(g32[k]).max(), 1e-30)) for k in g16}
+    print(f"sh_fp16 vs fp32, M={M}: max |colour difference| {err:.3e}; max gradient difference / max|gradient|: "
+          + ", ".join(f"{k} {v:.2e}" for k, v in gerr.items()))
+    # a coefficient moves by <= 2^-11 relative, a colour is a sum of M basis(<= ~1.8) x coefficient(<= 1.5) terms
+    assert 0 < err <= M * 1.8 * 1.5 * 2.0 ** -11
+    assert all(v < 5e-3 for v in gerr.values())
+
+
+def test_sh_fp16_copy_follows_the_update_and_densify(orc):
+    """The update kernel refreshes the half copy of every SH element it writes: after Adam steps (and a densify) the copy
+    equals a fresh conversion of the fp32 planes — a step taken with the incrementally maintained copy is bit-identical to
+    one taken right after the copy was rebuilt from scratch."""
+    P, M, n_cams, W, H = 2000, 4, 2, 128, 96
+    outs = []
+    for rebuild in (0, 1):
+        s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 4711)
+        tr.set_option("sh_fp16", 1)
+        proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrSh=0.02)   # large enough to move coefficients across half ulps
+        for _ in range(4):
+            tr.train(proj)
+        st = tr.train(proj, densify=True, stats=True)
+        tr.train(proj)
+        if rebuild:
+            tr.set_option("sh_fp16", 1)   # drops the copy: the next projection converts the planes afresh
+        st2 = tr.accumulate(stats=True)
+        outs.append((st.count_after, st2.num_rendered, st2.loss, _read_grads(tr, st.count_after, M), _download(tr)))
+        tr.close()
+    assert outs[0][:3] == outs[1][:3]
+    for k in outs[0][3]:
+        assert np.array_equal(outs[0][3][k].view(np.uint32), outs[1][3][k].view(np.uint32)), k
+    for k in ("loc", "sh", "scale", "opac", "rot"):
+        assert np.array_equal(outs[0][4][k].view(np.uint32), outs[1][4][k].view(np.uint32)), k
+    # and the copy did change along the way: the coefficients moved by more than a half ulp
+    s0 = gs.synth.random_splats(P, M, 4711)
+    assert np.abs(outs[0][4]["sh"][:8] - s0["sh"][:8]).max() > 1e-3
+
+
+def test_trainer_options_are_per_trainer(orc):
+    """gs_set_option edits the defaults new trainers copy; gs_trainer_set_option changes one trainer and no other."""
+    P, M, n_cams, W, H = 800, 4, 2, 96, 96
+    s, cams, fw, fb, a = _setup(orc, P, M, n_cams, W, H, 5)
+    b = _trainer_on(s, cams, fw, fb, W, H)
+    a.set_option("fuse_camera_passes", 0)
+    a.train(gs.Project())
+    b.train(gs.Project())
+    assert _read_grads(a, P, M)["var"].any() and not _read_grads(b, P, M)["var"].any()   # only `a` took the per-pass form
+    with pytest.raises(RuntimeError, match="unknown option"):
+        a.set_option("no_such_switch", 1)
+    a.close(); b.close()

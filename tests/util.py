@@ -109,3 +109,57 @@ def assert_close_rel(name, got, want, rtol=1e-4, floor=None, max_bad_frac=0.0):
     if frac > max_bad_frac:
         i = int(np.argmax(np.abs(got - want) / tol))
         raise AssertionError(f"{name}: {bad.sum()}/{bad.size} outside rtol={rtol} (worst idx {i}: got {got[i]!r} want {want[i]!r}, scale {scale!r})")
+
+
+def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4):
+    """What the averaged gradients of one iteration may differ from the oracle's by, per entry, with every part of it
+    accounted for.  For every pass the oracle reports, per splat and pixel-stage sum q, sum|term| of the fp32 summation
+    (abs9) and the decision-flip allowance (flip9: |term change| of every blend decision within `flip_margin` of its
+    threshold, see tests/test_gpu_raster.py::check_pixel_stage).  The per-splat chain is linear in the nine sums and the
+    HIP chain repeats the oracle's fp32 operations, so an output's budget is the sums' budget carried through the chain,
+        |d out_k| <= sum_q |A_kq| * (1e-4 * abs9_q + flip9_q),    A = the chain evaluated on the nine unit inputs,
+    and accumulateGradients (src/Trainer.cu:47-77) adds the passes' gradients divided by S: the budgets add the same way
+    (`var` = sum of |g_loc| / S: | |a| - |b| | <= |a - b|).
+    Returns {array: {"budget": with flips, "sumabs": sum|term| carried through the chain, without the 1e-4 and flips}}."""
+    P = s["opac"].size
+    V = views40.shape[0]
+    N = W * H
+    chain_names = {"loc": ("dL_dmean3D", 3), "sh": ("dL_dsh", 3 * M), "scale": ("dL_dscale", 3), "rot": ("dL_drot", 4)}
+    out = {k: {"budget": np.zeros((P, st)), "sumabs": np.zeros((P, st))} for k, (_, st) in chain_names.items()}
+    out["opac"] = {"budget": np.zeros((P, 1)), "sumabs": np.zeros((P, 1))}
+    out["var"] = {"budget": np.zeros((P, 1)), "sumabs": np.zeros((P, 1))}
+    truths = np.asarray(truths, np.uint32).reshape(V, N)
+    for v in range(V):
+        vp = view_parts(views40[v])
+        r, img, _ = oracle_forward(orc, s, D, M, vp, W, H)
+        dpix = orc.image_int_to_loss(truths[v], img, W, H)
+        og = r.backward(dpix, want_abs=True, flip_margin=flip_margin)
+        abs9, tol9 = og["abs9"], 1e-4 * og["abs9"] + og["flip9"]
+        loc_b, loc_a = np.zeros((P, 3)), np.zeros((P, 3))
+        for q in range(9):
+            unit = np.zeros((P, 9), np.float32); unit[:, q] = 1.0
+            col = orc.chain(r, unit)
+            for k, (n, st) in chain_names.items():
+                A = np.abs(col[n].reshape(P, st).astype(np.float64))
+                out[k]["budget"] += A * tol9[:, q, None] / samples
+                out[k]["sumabs"] += A * abs9[:, q, None] / samples
+                if k == "loc":
+                    loc_b += A * tol9[:, q, None]; loc_a += A * abs9[:, q, None]
+        out["opac"]["budget"] += tol9[:, 8:9] / samples
+        out["opac"]["sumabs"] += abs9[:, 8:9] / samples
+        out["var"]["budget"] += np.linalg.norm(loc_b, axis=1, keepdims=True) / samples
+        out["var"]["sumabs"] += np.linalg.norm(loc_a, axis=1, keepdims=True) / samples
+    return {k: {a: b.reshape(-1) for a, b in d.items()} for k, d in out.items()}
+
+
+def unexplained(name, got, want, budget, stride=1, eps_rel=4e-6):
+    """Entries of `got` outside  budget + eps_rel * max|want of the same splat|.  The second term is the fp32 rounding of the
+    per-splat chain itself and of the division / accumulation over the passes: the components of one splat's gradient
+    (`stride` per splat) come out of shared intermediates, so a component that nearly cancels — e.g. one scale axis four
+    orders of magnitude below its siblings — carries rounding noise of the siblings' size, not of its own.
+    Returns (count, worst ratio |error| / tolerance)."""
+    got = np.asarray(got, np.float64).reshape(-1); want = np.asarray(want, np.float64).reshape(-1)
+    per_splat = np.repeat(np.abs(want).reshape(-1, stride).max(1), stride)
+    tol = budget + eps_rel * per_splat + 1e-37
+    ratio = np.abs(got - want) / tol
+    return int((ratio > 1.0).sum()), float(ratio.max()) if ratio.size else 0.0
