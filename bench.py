@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--cpu-views", type=int, default=16, help="views of the workload the CPU baseline leg times")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and the collective hook even with one rank (plumbing test)")
     ap.add_argument("--no-stage-events", action="store_true", help="diagnostic only: time the steps without the per-stage HIP events (no roofline object)")
+    ap.add_argument("--sh-fp16", action="store_true", help="trainer option sh_fp16: the projection reads a half-precision copy of the SH planes (BASELINE config 5)")
     ap.add_argument("--views", type=int, default=0, help="diagnostic only: override the number of views per step (not the metric's config)")
     args = ap.parse_args()
 
@@ -138,6 +139,8 @@ def main():
     host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
     host.shDegree = D
     tr.model = gs.ModelSplatsDevice(host)
+    if args.sh_fp16:
+        tr.set_option("sh_fp16", 1)
     tr.captureTruths(cams, framesW, framesB)
     tr.shard(rank, world)
     proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM if args.update == "adam" else capi.GS_UPDATE_SGD_CLAMP)
@@ -291,6 +294,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[args.config] + (f" [DIAGNOSTIC: views overridden to {V_total}]" if args.views else ""), "splats": P, "sh_coeffs": M, "views_per_step": V_total,
                        "views_per_gpu": V_local, "width": W, "height": H, "update": args.update,
+                       "sh_storage": "fp16 read copy (trainer option sh_fp16; fp32 master and gradients)" if args.sh_fp16 else "fp32",
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "collective": (args.collective + (" reduce-scatter + all-gather" if args.collective.endswith("sharded") else " all-reduce")
                                       + " of %d fp32" % ((12 + 3 * M) * P)) if use_dist else "none",

@@ -18,7 +18,7 @@ import pytest
 
 import gsplat_amd as gs
 from gsplat_amd import capi
-from util import REC_DTYPE, SeamRaster, make_scene, view_parts
+from util import REC_DTYPE, SeamRaster, make_scene, step_budget, unexplained, view_parts
 
 pytestmark = pytest.mark.gpu
 
@@ -203,3 +203,65 @@ def test_model_round_trip_full_size(idx):
         for name, want in [("locations", s["loc"]), ("shs", s["sh"]), ("scales", s["scale"]), ("opacities", s["opac"]), ("rotations", s["rot"])]:
             got = getattr(back, name)[:want.size]
             assert np.array_equal(np.asarray(got).view(np.uint32), np.asarray(want, np.float32).reshape(-1).view(np.uint32)), name
+
+
+def test_cfg5_per_rank_load_with_fp16_sh(orc):
+    """BASELINE config 5 as it is written — 1M splats @2048^2, SH degree 3 with fp16 SH storage (trainer option "sh_fp16"),
+    LDS long-list / spill sort path — at the load ONE rank of its 8-GPU run carries: 4 of the 32 cameras = 8 passes
+    (scale anchor /root/reference/src/Config.h:17, SPLATS_LIMIT 1000000).
+      * the step against the oracle on the half-rounded coefficients, every entry of every averaged gradient accounted for
+        (util.step_budget; the long lists take the wide flip margin), in the per-pass form incl. `var`;
+      * the fused-pair step: same accounting; bit-reproducible; `var` zero;
+      * geometry, tile lists and statistics bit-identical with the fp32 mode (SH does not enter them)."""
+    import time
+    P, M, D, V, W, H, s, cams32 = _cfg(5)
+    n_cams = 4
+    cams = cams32[:n_cams]   # rank 0's share under camera sharding (camera c -> rank c % 8 holds c = 0, 8, 16, 24: any four do)
+    t = gs.synth.random_splats(P // 2, M, gs.synth.seed_for(5) + 1000)
+    fw, fb = _product_truths(t, D, cams, W, H)
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = D
+    tr = gs.Trainer(W, H)
+    tr.set_option("sh_fp16", 1)
+    tr.model = gs.ModelSplatsDevice(host)
+    tr.captureTruths(cams, fw, fb)
+    views = gs.camera.train_views(cams, W, H)
+    truths = np.concatenate(fw + fb)
+    rounded = dict(s, sh=s["sh"].astype(np.float16).astype(np.float32))
+    t0 = time.time()
+    o = orc.train_views(P, D, M, W, H, rounded["loc"], rounded["sh"], rounded["scale"], rounded["opac"], rounded["rot"], views, truths, 2.0 * n_cams)
+    t_oracle = time.time() - t0
+    st = tr.accumulate(stats=True)
+    assert st.views == 2 * n_cams and st.num_rendered == int(o["num_rendered"].sum()) and st.max_tile_list > 2048
+    from test_gpu_trainer import _read_grads
+    g = _read_grads(tr, P, M)
+    t0 = time.time()
+    bud = step_budget(orc, rounded, D, M, W, H, views, truths, 2.0 * n_cams, flip_margin=1e-3)
+    t_budget = time.time() - t0
+    stride = dict(loc=3, sh=3 * M, scale=3, opac=1, rot=4, var=1)
+    report = []
+    for k in ["loc", "sh", "scale", "opac", "rot", "var"]:
+        n_bad, worst = unexplained(k, g[k], o[k], bud[k]["budget"], stride[k])
+        report.append(f"{k} {n_bad} (worst {worst:.2f})")
+        assert n_bad == 0, (k, n_bad, worst)
+    print(f"[cfg5 per-rank load: {P} splats, fp16 SH, {2 * n_cams} passes @{W}x{H}, {st.num_rendered / (2 * n_cams):.3g} entries per pass, longest list "
+          f"{st.max_tile_list}] unexplained entries per-pass form: " + ", ".join(report) + f"  (oracle {t_oracle:.0f} s, budget {t_budget:.0f} s)")
+    # the step (fused pairs): same accounting, reproducible
+    res = []
+    for _ in range(2):
+        stf = tr.train(gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0), stats=True)   # gradients only
+        res.append(_read_grads(tr, P, M))
+    assert stf.num_rendered == st.num_rendered
+    for k in ["loc", "sh", "scale", "opac", "rot"]:
+        assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
+        n_bad, worst = unexplained(k + " (fused pair)", res[0][k], o[k], bud[k]["budget"], stride[k])
+        assert n_bad == 0, (k, n_bad, worst)
+    assert not res[0]["var"].any()
+    tr.close()
+    # fp32 mode: identical lists and statistics (SH never enters geometry)
+    tr32 = gs.Trainer(W, H)
+    tr32.model = gs.ModelSplatsDevice(host)
+    tr32.captureTruths(cams, fw, fb)
+    st32 = tr32.accumulate(stats=True)
+    assert (st32.num_rendered, st32.max_tile_list) == (st.num_rendered, st.max_tile_list)
+    tr32.close()
