@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and the collective hook even with one rank (plumbing test)")
     ap.add_argument("--no-stage-events", action="store_true", help="diagnostic only: time the steps without the per-stage HIP events (no roofline object)")
     ap.add_argument("--sh-fp16", action="store_true", help="trainer option sh_fp16: the projection reads a half-precision copy of the SH planes (BASELINE config 5)")
+    ap.add_argument("--long-steps", type=int, default=500, help="steps of the untimed-by-the-metric long run reported as `long_run` (0: skip)")
     ap.add_argument("--views", type=int, default=0, help="diagnostic only: override the number of views per step (not the metric's config)")
     args = ap.parse_args()
 
@@ -178,6 +179,24 @@ def main():
     launches = (C.c_longlong * capi.GS_STAGE_COUNT)()
     capi.check(L.gs_trainer_stage_times(tr.handle, ms, launches))
     dom_timed = (ms[DOM_STAGE], launches[DOM_STAGE])
+    # not the metric: a LONG run of the same steps (no events, no statistics), so that the 20-50-step timed window is not the
+    # only figure on record — clocks, caches and the run-ahead host queue have all settled by then
+    capi.check(L.gs_trainer_set_profiling(tr.handle, 0))
+    n_long = args.long_steps
+    long_run = None
+    if n_long > 0:
+        sync_all()
+        t_l = time.perf_counter()
+        for _ in range(n_long):
+            tr.train(proj, densify=False)
+        sync_all()
+        long_s = time.perf_counter() - t_l
+        if use_dist:
+            tl = torch.tensor([long_s], dtype=torch.float64)
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            long_s = float(tl[0])
+        long_run = {"value": n_long / long_s, "unit": "steps/s", "steps": n_long, "ms_per_step": long_s / n_long * 1e3,
+                    "note": "the same steps run after the timed region, no HIP events; not the metric"}
     # untimed: every stage, a few steps
     capi.check(L.gs_trainer_set_profiling(tr.handle, 1))
     for _ in range(min(args.steps, 10)):
@@ -246,6 +265,11 @@ def main():
             dom_ms, dom_src = dom_timed[0] / dom_timed[1], f"HIP events on the trainer's stream around every launch of the timed region ({int(dom_timed[1])} launches)"
         dom_bytes = stage_bytes(dom, P, M, N, R_mean, V_local)
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # the bytes the form that actually RAN must move: the fused backward walks one list and writes one row set per CAMERA
+        # (its two passes share them) and reads truth + colour per pass — fewer than SURVEY's per-view figure x views
+        n_groups = max(V_local // 2, 1)
+        form_bytes = {"render_backward": n_groups * (40 * R_mean + 44 * P) + V_local * 24 * N,
+                      "render_forward": n_groups * 40 * R_mean + V_local * 12 * N + n_groups * 8 * N}.get(dom, dom_bytes)
         step_bytes = sum(stage_bytes(k, P, M, N, R_mean, V_local) for k in kern) + (48 + 12 * M) * P
         ms_per_step = elapsed / args.steps * 1e3
         # Counters of the dominant kernel (rocprofv3 --pmc passes of the same command, tools/pmc_pass.sh, committed as
@@ -309,11 +333,15 @@ def main():
                          "bound_note": "achieved/peak/frac are the HBM roofline of the dominant kernel (algorithmic bytes / measured time); "
                                        "`valu` is its vector-issue roofline; `bound` names the larger fraction (no dense contraction here: MFMA is not used)",
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms, "measured": dom_src,
+                         "form_bytes_per_launch": form_bytes, "frac_form": form_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "form_note": "frac prices SURVEY 8d's per-view bytes x the views the launch serves; frac_form prices the compulsory bytes of the form "
+                                      "that ran (camera passes share lists and rows): the smaller, stricter figure",
                          "step_algorithmic_GB": step_bytes / 1e9,
                          "step_achieved_GBs": step_bytes / (ms_per_step * 1e-3) / 1e9,
                          "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
             "stages_note": "all-stage table: HIP events over %d extra steps run after the timed region (timing every stage costs ~3 us of stream time per event)" % min(args.steps, 10),
+            "long_run": long_run,
             "per_pass_form": per_pass,
             "densify_step": None if densify_ms is None else {"ms": round(densify_ms, 3), "count_before": st_d.count_before, "count_after": st_d.count_after,
                              "note": "one extra step with densify/prune after the timed region (the driver loop does this every 200th iteration); includes the step itself"},
@@ -353,4 +381,14 @@ def cpu_baseline(gs, s, cams, framesW, framesB, P, M, D, W, H, n_cams, n_views):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:  # noqa: BLE001
+        if isinstance(e, SystemExit):
+            raise
+        # A failed step on one rank (e.g. GS_ERR_COLLECTIVE) leaves the peers blocked in the collective: end THIS process at
+        # once and non-zero, without the process-group teardown that would wait for them; the launcher then ends the peers.
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

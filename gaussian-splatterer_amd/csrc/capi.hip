@@ -256,6 +256,7 @@ extern "C" const char* gs_status_string(int s) {
         case GS_ERR_OUT_OF_MEMORY: return "out of device memory";
         case GS_ERR_NO_MODEL: return "trainer has no model";
         case GS_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+        case GS_ERR_COLLECTIVE: return "a data-parallel collective failed on this rank: end the process so that the launcher ends the peers";
         default: return "internal error";
     }
 }
@@ -328,7 +329,8 @@ extern "C" int gs_hyper_defaults(gs_hyper* h) {
 // =============================================================================================
 // model
 // =============================================================================================
-static int model_alloc(int capacity, int sh_degree, int sh_coeffs, int count, gs_model** out) {
+// clear_on != nullptr: the planes are cleared on that stream (asynchronously) instead of the null stream
+static int model_alloc(int capacity, int sh_degree, int sh_coeffs, int count, gs_model** out, hipStream_t* clear_on = nullptr) {
     gs_model* m = new gs_model();
     m->capacity = capacity; m->sh_degree = sh_degree; m->sh_coeffs = sh_coeffs; m->count = count;
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; set_error("hipGetDevice failed"); return GS_ERR_HIP; }
@@ -336,7 +338,7 @@ static int model_alloc(int capacity, int sh_degree, int sh_coeffs, int count, gs
     const size_t bytes = plane_buffer_floats(sh_coeffs, m->Pa) * sizeof(float);  // parameter planes + spare plane + chunk padding
     hipError_t e = hipMalloc((void**)&m->planes, bytes);
     if (e != hipSuccess) { delete m; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GS_ERR_OUT_OF_MEMORY; }
-    e = hipMemset(m->planes, 0, bytes);
+    e = clear_on ? hipMemsetAsync(m->planes, 0, bytes, *clear_on) : hipMemset(m->planes, 0, bytes);
     if (e != hipSuccess) { (void)hipFree(m->planes); delete m; set_error("hipMemset failed: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
     *out = m;
     return GS_OK;
@@ -427,6 +429,7 @@ extern "C" int gs_model_destroy(gs_model* m) {
 // =============================================================================================
 struct gs_trainer {
     Options opt;                  // copied from the process defaults at creation; gs_trainer_set_option edits them
+    DevBuf densify_work;          // classification flags, ranks and scan partials of densify / prune
     DevBuf sh16;                  // [3M][Pa] half: read copy of the SH planes (option "sh_fp16")
     const void* sh16_of = nullptr;  // the parameter planes the copy was made from and kept current with (null: stale)
     int device = 0, W = 0, H = 0;
@@ -549,7 +552,7 @@ extern "C" int gs_trainer_destroy(gs_trainer* t) {
     if (!t) return GS_OK;
     (void)hipStreamSynchronize(t->stream);
     gs_model_destroy(t->model);
-    t->truth.release(); t->grad.release(); t->adam_m.release(); t->adam_v.release(); t->sh16.release();
+    t->truth.release(); t->grad.release(); t->adam_m.release(); t->adam_v.release(); t->sh16.release(); t->densify_work.release();
     t->train.release(); t->preview.release();
     if (t->h_flags) (void)hipHostFree(t->h_flags);
     if (t->ev_flags) (void)hipEventDestroy(t->ev_flags);
@@ -650,7 +653,7 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
         // averaged gradients is zero, and it still joins the collective and applies the common update.
         GS_TRY(t->grad.ensure(plane_buffer_floats(M, m->Pa) * 4));
         t->grad_Pa = m->Pa; t->grad_M = M;
-        GS_HIP(hipMemsetAsync(t->grad.p, 0, (size_t)(pl.count() + 1) * m->Pa * 4, t->stream));
+        GS_HIP(hipMemsetAsync(t->grad.p, 0, plane_buffer_floats(M, m->Pa) * 4, t->stream));  // the chunk padding behind the planes too: it takes part in the collectives
         gs_step_stats st0{};
         st0.count_before = st0.count_after = P;
         t->last = st0; t->stats_stale = false; t->accumulated = true;
@@ -777,7 +780,7 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
     st->count_after = count;
     if (count == 0) return GS_OK;
     const int fs = round_up(count, 64);
-    DevBuf work;  // flags[3][fs] | ranks[3][fs] | scan partials
+    DevBuf& work = t->densify_work;  // flags[3][fs] | ranks[3][fs] | scan partials (kept between densify steps, grow-only)
     const size_t npart = scan_partials_count(count, 3) + 64;
     GS_TRY(work.ensure(((size_t)6 * fs + npart) * 4));
     uint32_t* flags = work.as<uint32_t>();
@@ -788,14 +791,13 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
     for (int k = 0; k < 3 && rc == GS_OK; k++)
         if (hipMemcpyAsync(&totals[k], ranks + (size_t)k * fs + (count - 1), 4, hipMemcpyDeviceToHost, t->stream) != hipSuccess) rc = GS_ERR_HIP;
     if (rc == GS_OK && hipStreamSynchronize(t->stream) != hipSuccess) rc = GS_ERR_HIP;
-    if (rc != GS_OK) { work.release(); if (rc == GS_ERR_HIP) set_error("densify failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
+    if (rc != GS_OK) { if (rc == GS_ERR_HIP) set_error("densify failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
     const int n_split = (int)totals[0], n_clone = (int)totals[1], kept = (int)totals[2];
     const int splits_done = std::min(n_split, std::max(0, cap - count));
     const int clones_done = std::min(n_clone, std::max(0, cap - count - splits_done));
     const int n2 = kept + splits_done + clones_done;
     gs_model* fresh = nullptr;
-    rc = model_alloc(cap, m->sh_degree, M, n2, &fresh);
-    if (rc == GS_OK && hipDeviceSynchronize() != hipSuccess) rc = GS_ERR_HIP;  // model_alloc clears the planes on the null stream; ours does not wait for it
+    rc = model_alloc(cap, m->sh_degree, M, n2, &fresh, &t->stream);  // cleared on the trainer's stream, in order with the emit pass
     if (rc == GS_OK) rc = launch_densify_emit(count, m->Pa, M, m->planes, t->grad.as<float>(), *h, flags, ranks, fs, splits_done, clones_done, kept,
                                               fresh->Pa, fresh->planes, t->stream);
     // Adam moments follow their splats (twins inherit the parent's); the step counter keeps running
@@ -808,8 +810,8 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
         if (rc == GS_OK) rc = launch_densify_carry(count, m->Pa, M, *h, flags, ranks, fs, splits_done, clones_done, kept, fresh->Pa,
                                                    t->adam_m.as<float>(), new_m.as<float>(), t->adam_v.as<float>(), new_v.as<float>(), t->stream);
     }
+    // the old planes (and moments) are freed below: wait for the kernels that read them
     if (rc == GS_OK && hipStreamSynchronize(t->stream) != hipSuccess) { rc = GS_ERR_HIP; set_error("densify failed: %s", hipGetErrorString(hipGetLastError())); }
-    work.release();
     if (rc != GS_OK) { if (fresh) gs_model_destroy(fresh); new_m.release(); new_v.release(); return rc; }
     std::swap(m->planes, fresh->planes);
     m->Pa = fresh->Pa; m->count = fresh->count;
@@ -868,10 +870,14 @@ extern "C" int gs_trainer_apply(gs_trainer* t, const gs_hyper* h, int densify, g
     return GS_OK;
 }
 
-// One collective of the sharded update, timed as part of the "collective" stage.
-static int shard_call(gs_trainer* t, gs_collective_fn fn, float* buf, size_t n, const char* what) {
+// One collective of the sharded update, timed as part of the "collective" stage (stage_before: the stage that ran last).
+// A hook that fails has failed on THIS rank only: the error goes back to the caller, who must end the process (bench.py
+// exits non-zero, which makes the launcher end the peers) — the library's own communicator is aborted by its hooks.
+static int shard_call(gs_trainer* t, gs_collective_fn fn, float* buf, size_t n, const char* what, int stage_before) {
+    prof_stage_begin(t, 8, stage_before);
     const int rc = fn(buf, n, (void*)t->stream, t->shard_user);
-    if (rc != 0) { set_error("%s hook failed with %d", what, rc); return GS_ERR_INTERNAL; }
+    prof_stage_end(t, 8);
+    if (rc != 0) { set_error("%s hook failed with %d", what, rc); return GS_ERR_COLLECTIVE; }
     return GS_OK;
 }
 
@@ -888,19 +894,17 @@ extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs
         gs_model* m = t->model;
         const size_t n = shard_total_floats(m->sh_coeffs, m->Pa, t->shard_world), chunk = n / (size_t)t->shard_world;
         const size_t lo = chunk * (size_t)t->shard_rank, hi = lo + chunk;
-        prof_stage_begin(t, 8, 6);
-        GS_TRY(shard_call(t, t->shard_rs, t->grad.as<float>(), n, "reduce-scatter"));
-        prof_stage_end(t, 8);
+        GS_TRY(shard_call(t, t->shard_rs, t->grad.as<float>(), n, "reduce-scatter", 6));
         GS_TRY(debug_check(t, 8));
         GS_TRY(apply_update(t, h, 8, lo, hi));
-        GS_TRY(shard_call(t, t->shard_ag, m->planes, n, "all-gather (parameters)"));
+        GS_TRY(shard_call(t, t->shard_ag, m->planes, n, "all-gather (parameters)", 7));
         if (densify) {
             // densify reads var and the averaged location gradient of EVERY splat, and re-indexes the Adam moments:
             // complete the three buffers on every rank first (every intervalDensify-th step only)
-            GS_TRY(shard_call(t, t->shard_ag, t->grad.as<float>(), n, "all-gather (gradients)"));
+            GS_TRY(shard_call(t, t->shard_ag, t->grad.as<float>(), n, "all-gather (gradients)", 8));
             if (t->adam_valid) {
-                GS_TRY(shard_call(t, t->shard_ag, t->adam_m.as<float>(), n, "all-gather (Adam m)"));
-                GS_TRY(shard_call(t, t->shard_ag, t->adam_v.as<float>(), n, "all-gather (Adam v)"));
+                GS_TRY(shard_call(t, t->shard_ag, t->adam_m.as<float>(), n, "all-gather (Adam m)", 8));
+                GS_TRY(shard_call(t, t->shard_ag, t->adam_v.as<float>(), n, "all-gather (Adam v)", 8));
             }
             GS_TRY(resolve_stats(t));
             GS_TRY(trainer_densify(t, h, &t->last));
@@ -916,7 +920,7 @@ extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs
         rc = t->allreduce(buf, n, (void*)t->stream, t->allreduce_user);
         prof_stage_end(t, 8);
         GS_TRY(debug_check(t, 8));
-        if (rc != 0) { set_error("all-reduce hook failed with %d", rc); return GS_ERR_INTERNAL; }
+        if (rc != 0) { set_error("all-reduce hook failed with %d", rc); return GS_ERR_COLLECTIVE; }
     }
     return gs_trainer_apply(t, h, densify, stats);
 }
@@ -1280,12 +1284,14 @@ typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStre
 typedef int (*fn_reduce_scatter)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*fn_destroy)(void*);
+typedef int (*fn_abort)(void*);
 typedef const char* (*fn_errstr)(int);
 struct Rccl {
     void* lib = nullptr;
     fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_allreduce allreduce = nullptr; fn_destroy destroy = nullptr;
     fn_reduce_scatter reduce_scatter = nullptr; fn_all_gather all_gather = nullptr;
     fn_errstr errstr = nullptr;
+    fn_abort abort = nullptr;
 } g_rccl;
 int rccl_load() {
     if (g_rccl.lib) return GS_OK;
@@ -1300,6 +1306,7 @@ int rccl_load() {
     g_rccl.reduce_scatter = (fn_reduce_scatter)dlsym(lib, "ncclReduceScatter");
     g_rccl.all_gather = (fn_all_gather)dlsym(lib, "ncclAllGather");
     g_rccl.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
+    g_rccl.abort = (fn_abort)dlsym(lib, "ncclCommAbort");
     if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.allreduce || !g_rccl.destroy) { set_error("librccl lacks expected symbols"); return GS_ERR_INTERNAL; }
     g_rccl.lib = lib;
     return GS_OK;
@@ -1335,10 +1342,19 @@ extern "C" int gs_comm_destroy(gs_comm* c) {
     delete c;
     return GS_OK;
 }
+// A collective that fails on this rank aborts the communicator (ncclCommAbort): the peers' pending collectives then end with
+// an error instead of waiting for this rank for ever.
+static int rccl_result(gs_comm* c, int rc, const char* what) {
+    if (rc == 0) return 0;
+    set_error("%s failed: %s; communicator aborted", what, g_rccl.errstr ? g_rccl.errstr(rc) : "?");
+    if (c->comm && g_rccl.abort) { g_rccl.abort(c->comm); c->comm = nullptr; }
+    return rc;
+}
 static int rccl_hook(float* buf, size_t n, void* stream, void* user) {
     gs_comm* c = static_cast<gs_comm*>(user);
+    if (!c->comm) return -1;
     // ncclFloat32 = 7, ncclSum = 0
-    return g_rccl.allreduce(buf, buf, n, 7, 0, c->comm, (hipStream_t)stream);
+    return rccl_result(c, g_rccl.allreduce(buf, buf, n, 7, 0, c->comm, (hipStream_t)stream), "ncclAllReduce");
 }
 extern "C" int gs_trainer_attach_comm(gs_trainer* t, gs_comm* c) {
     if (!t) return GS_ERR_INVALID_ARGUMENT;
@@ -1348,13 +1364,15 @@ extern "C" int gs_trainer_attach_comm(gs_trainer* t, gs_comm* c) {
 // in-place forms: the rank's chunk of the buffer is both the reduce-scatter's output and the all-gather's input
 static int rccl_rs_hook(float* buf, size_t n, void* stream, void* user) {
     gs_comm* c = static_cast<gs_comm*>(user);
+    if (!c->comm) return -1;
     const size_t chunk = n / (size_t)c->n_ranks;
-    return g_rccl.reduce_scatter(buf, buf + chunk * (size_t)c->rank, chunk, 7, 0, c->comm, (hipStream_t)stream);
+    return rccl_result(c, g_rccl.reduce_scatter(buf, buf + chunk * (size_t)c->rank, chunk, 7, 0, c->comm, (hipStream_t)stream), "ncclReduceScatter");
 }
 static int rccl_ag_hook(float* buf, size_t n, void* stream, void* user) {
     gs_comm* c = static_cast<gs_comm*>(user);
+    if (!c->comm) return -1;
     const size_t chunk = n / (size_t)c->n_ranks;
-    return g_rccl.all_gather(buf + chunk * (size_t)c->rank, buf, chunk, 7, c->comm, (hipStream_t)stream);
+    return rccl_result(c, g_rccl.all_gather(buf + chunk * (size_t)c->rank, buf, chunk, 7, c->comm, (hipStream_t)stream), "ncclAllGather");
 }
 extern "C" int gs_trainer_attach_comm_sharded(gs_trainer* t, gs_comm* c) {
     if (!t) return GS_ERR_INVALID_ARGUMENT;

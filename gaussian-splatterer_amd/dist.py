@@ -82,8 +82,11 @@ class TorchShardedUpdate:
     """gs_trainer_set_sharded_update with torch.distributed: reduce_scatter_tensor / all_gather_into_tensor IN PLACE on
     tensors that alias the library's plane-major buffers (the rank's chunk is a view of the whole buffer), enqueued
     behind the trainer's HIP stream.  Each rank then updates 1/world of the parameters and keeps 1/world of the Adam
-    moments current; the bytes on the wire equal an all-reduce's.  Backends without reduce-scatter (gloo, used by the
-    two-processes-on-one-GPU test) fall back to an all-reduce, which leaves the same sums in the rank's chunk."""
+    moments current; the bytes on the wire equal an all-reduce's.  The reduce-scatter's form is chosen ONCE, from the
+    backend that serves device tensors: nccl (= RCCL) runs reduce_scatter_tensor; gloo (the two-processes-on-one-GPU
+    test) has none and runs an all-reduce, which leaves the same sums in the rank's chunk.  A failing collective returns
+    non-zero to the library on this rank — it is never retried in another form, which would pair a different collective
+    with the peers' and hang them."""
 
     def __init__(self, trainer, rank, world):
         import torch
@@ -95,6 +98,11 @@ class TorchShardedUpdate:
         self.stream = torch.cuda.ExternalStream(st.value)
         self._alias = {}
         self.calls = {"reduce_scatter": 0, "all_gather": 0}
+        try:   # the backend object that will serve device tensors ("cpu:gloo,cuda:nccl" groups carry two)
+            backend = dist.distributed_c10d._get_default_group()._get_backend(torch.device("cuda")).__class__.__name__
+        except Exception:
+            backend = str(dist.get_backend())
+        self.native_reduce_scatter = "nccl" in backend.lower()
 
         def alias(buf, n):
             t = self._alias.get((buf, n))
@@ -110,9 +118,9 @@ class TorchShardedUpdate:
                 t = alias(buf, n)
                 c = n // self.world
                 with torch.cuda.stream(self.stream):
-                    try:
+                    if self.native_reduce_scatter:
                         dist.reduce_scatter_tensor(t[self.rank * c:(self.rank + 1) * c], t, op=dist.ReduceOp.SUM)
-                    except (RuntimeError, NotImplementedError):
+                    else:
                         dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 self.calls["reduce_scatter"] += 1
                 return 0

@@ -29,6 +29,29 @@ def saveSplats(path, model):
             f.write("r " + " ".join(_g(v) for v in model.rotations[4 * i:4 * i + 4]) + "\n")
 
 
+_STREAM_FLOAT = None
+
+
+def _stream_floats(text, width=None):
+    """Numbers the way successive `iss >> x` (float) read them: decimal forms only ("nan", "inf", hex are not numbers to a
+    stream), stopping at the first token that is none.  width: exactly that many values, 0.0 once extraction has failed
+    (the reference pushes 3 / 1 / 4 values per v, s / a / r line whatever the line holds, src/ui/UiFrame.cpp:404-434)."""
+    global _STREAM_FLOAT
+    import re
+    if _STREAM_FLOAT is None:
+        _STREAM_FLOAT = re.compile(r"\s*([+-]?(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?)")
+    out, pos = [], 0
+    while width is None or len(out) < width:
+        m = _STREAM_FLOAT.match(text, pos)
+        if not m:
+            break
+        out.append(float(np.float32(m.group(1))))
+        pos = m.end()
+    if width is not None:
+        out += [0.0] * (width - len(out))
+    return out
+
+
 def loadSplats(path):
     """UiFrame::loadSplats, src/ui/UiFrame.cpp:373-450 -> ModelSplatsHost (five-vector constructor semantics:
     capacity 1e6 grown x10, shDegree = (M-1)/3; inconsistent SH counts raise "Inconsistent SH degree!")."""
@@ -36,30 +59,25 @@ def loadSplats(path):
     sh_coeffs = None
     with open(path) as f:
         for line in f:
-            parts = line.split()
+            parts = line.split(None, 1)
             if not parts:
                 continue
-            p, vals = parts[0], parts[1:]
+            p, rest = parts[0], (parts[1] if len(parts) > 1 else "")
             if p == "v":
-                loc += [float(x) for x in vals[:3]]
+                loc += _stream_floats(rest, 3)
             elif p == "sh":
-                got = []
-                for x in vals:           # `while (iss >> x)`: stops at the first token that is not a number
-                    try:
-                        got.append(float(x))
-                    except ValueError:
-                        break
+                got = _stream_floats(rest)   # `while (iss >> x)`: stops at the first token that is not a number
                 shs += got
                 if sh_coeffs is None:
                     sh_coeffs = len(got)
                 elif sh_coeffs != len(got):
                     raise RuntimeError("Inconsistent SH degree!")
             elif p == "s":
-                sc += [float(x) for x in vals[:3]]
+                sc += _stream_floats(rest, 3)
             elif p == "a":
-                op.append(float(vals[0]))
+                op += _stream_floats(rest, 1)
             elif p == "r":
-                rot += [float(x) for x in vals[:4]]
+                rot += _stream_floats(rest, 4)
     return ModelSplatsHost.fromVectors(loc, shs, sc, op, rot)
 
 

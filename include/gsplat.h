@@ -48,7 +48,9 @@ typedef enum gs_status {
     GS_ERR_OUT_OF_MEMORY = -7,
     GS_ERR_NO_MODEL = -8,
     GS_ERR_NO_DEVICE = -9,    /* no gfx950 device / HIP runtime unusable: there is no CPU fallback */
-    GS_ERR_INTERNAL = -10
+    GS_ERR_INTERNAL = -10,
+    GS_ERR_COLLECTIVE = -11   /* a data-parallel collective hook failed on this rank: the caller must end the process (peers are
+                                 blocked in the same collective); the library's own communicator has been aborted */
 } gs_status;
 
 const char* gs_last_error(void);

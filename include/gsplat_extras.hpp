@@ -15,6 +15,7 @@
 #include <array>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <functional>
 #include <istream>
@@ -79,6 +80,23 @@ inline void saveSplats(const std::string& path, const ModelSplatsHost& model) {
 // variable-width `sh` record takes every number on the line and all `sh` lines must agree), unknown tags and blank
 // lines are skipped, as the reference's prefix chain does.  The columns then go through the five-vector constructor,
 // which owns the dimension checks.
+// One number the way `iss >> x` (float) reads it: leading blanks skipped, then the longest run of decimal-float characters;
+// "nan", "inf" and hexadecimal forms are not numbers to a stream.  Returns false (q unchanged) when there is none.
+inline bool streamFloat(const char*& q, float& v) {
+    const char* p = q;
+    while (*p == ' ' || *p == '\t' || *p == '\r') p++;
+    char buf[64];
+    size_t n = 0;
+    while (n + 1 < sizeof(buf) && *p && std::strchr("+-0123456789.eE", *p)) buf[n++] = *p++;
+    buf[n] = 0;
+    if (n == 0) return false;
+    char* end = nullptr;
+    v = std::strtof(buf, &end);
+    if (end == buf) return false;
+    q += (p - n - q) + (end - buf);
+    return true;
+}
+
 inline std::unique_ptr<ModelSplatsHost> readSplats(std::istream& is) {
     const auto& schema = gobjSchema();
     std::array<std::vector<float>, 5> column;
@@ -92,18 +110,20 @@ inline std::unique_ptr<ModelSplatsHost> readSplats(std::istream& is) {
         const std::string tag(p, tagEnd);
         for (size_t k = 0; k < schema.size(); k++) {
             if (tag != schema[k].tag) continue;
-            const int limit = schema[k].fixedWidth ? schema[k].fixedWidth : -1;
-            int got = 0;
             const char* q = tagEnd;
-            while (limit < 0 || got < limit) {
-                char* end = nullptr;
-                const float v = std::strtof(q, &end);
-                if (end == q) break;  // no further number on this line
-                column[k].push_back(v);
-                q = end;
-                got++;
-            }
-            if (!schema[k].fixedWidth) {
+            if (schema[k].fixedWidth) {
+                // the reference pushes exactly 3 / 1 / 4 values per v, s / a / r line whatever the line holds
+                // (src/ui/UiFrame.cpp:404-434: `float x; iss >> x; push_back(x)`; a failed extraction stores 0)
+                bool ok = true;
+                for (int f = 0; f < schema[k].fixedWidth; f++) {
+                    float v = 0.0f;
+                    ok = ok && streamFloat(q, v);
+                    column[k].push_back(ok ? v : 0.0f);
+                }
+            } else {
+                int got = 0;
+                float v;
+                while (streamFloat(q, v)) { column[k].push_back(v); got++; }   // `while (iss >> x)`
                 if (shPerSplat < 0) shPerSplat = got;
                 else if (shPerSplat != got) throw std::runtime_error("Inconsistent SH degree!");
             }

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "gsplat.h"
@@ -291,7 +292,10 @@ public:
     // Trainer::train(Project&, bool densify), src/Trainer.cu:252-543: reads the learning rates and densify
     // parameters from the project on every call and counts the iteration (:255).  Like the reference it returns
     // with the device still working unless densify is set.
-    template <class ProjectT> void train(ProjectT& project, bool densify) {
+    // (only types that look like the reference's Project take this overload: a non-const gs_hyper lvalue must still reach the
+    // gs_hyper form below)
+    template <class ProjectT, class = decltype(std::declval<ProjectT&>().lrLocation), class = decltype(std::declval<ProjectT&>().iterations)>
+    void train(ProjectT& project, bool densify) {
         if (truthFrameBuffersW.empty()) throw std::runtime_error("Can't run training iteration, no truth data available!");
         project.iterations++;
         const gs_hyper hyper = hyperOf(project);

@@ -41,6 +41,12 @@ int main(int argc, char** argv) {
     } catch (const std::runtime_error& e) { if (std::string(e.what()).rfind("Unexpected vertex count in face list!", 0) == 0) threw++; }
     try { loadSplats(dir + "/does_not_exist.gobj"); } catch (const std::runtime_error&) { threw++; }
     if (threw != 4) return 7;
+    {   // a short / malformed fixed-width line still yields its 3 / 1 / 4 values, zero from the first failed extraction on
+        std::istringstream shortLine("v 1 2\nsh 1 2 3\ns 1 nan 3\na\nr 1 0 0 0 9\n");
+        auto m = readSplats(shortLine);
+        if (m->count != 1 || m->locations[0] != 1.0f || m->locations[1] != 2.0f || m->locations[2] != 0.0f) return 8;
+        if (m->scales[0] != 1.0f || m->scales[1] != 0.0f || m->scales[2] != 0.0f || m->opacities[0] != 0.0f || m->rotations[0] != 1.0f) return 8;
+    }
     printf("extras ok\n");
     return 0;
 }

@@ -1,4 +1,5 @@
-"""Multi-process data-parallel path on CPU (gloo, world_size 2 and 3): the passes of one iteration are sharded by
+"""Multi-process data-parallel path on CPU (gloo, world_size 2, 3 and 8 — the 8-rank cases are BASELINE cfg3's and cfg4's camera
+splits at toy size): the passes of one iteration are sharded by
 camera (both passes of a camera on one rank; pass by pass only when there are fewer cameras than ranks, and a rank
 may then own nothing), every rank accumulates its own passes with the GLOBAL divisor S, one sum all-reduce of the
 gradient buffer follows, and every rank applies the identical update.  The compute
@@ -24,7 +25,7 @@ def _free_port():
 
 def _worker(rank, world, port, q, n_cams=3):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OMP_NUM_THREADS="2" if world <= 3 else "1")
     import torch.distributed as dist
 
     import gsplat_amd as gs
@@ -94,8 +95,10 @@ def _single(n_cams):
     return np.concatenate([o[k] for k in ("loc", "sh", "scale", "opac", "rot", "var")])
 
 
-@pytest.mark.parametrize("world,n_cams", [(2, 3),   # cameras % world != 0: rank 0 owns two cameras, rank 1 one
-                                           (3, 1)])  # more ranks than passes: rank 2 owns nothing
+@pytest.mark.parametrize("world,n_cams", [(2, 3),    # cameras % world != 0: rank 0 owns two cameras, rank 1 one
+                                           (3, 1),    # more ranks than passes: rank 2 owns nothing
+                                           (8, 8),    # BASELINE cfg3's 16 passes on 8 ranks: one camera (2 passes) per rank
+                                           (8, 16)])  # BASELINE cfg4's 32 passes on 8 ranks: two cameras (4 passes) per rank
 def test_uneven_and_empty_shards(world, n_cams):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -110,9 +113,11 @@ def test_uneven_and_empty_shards(world, n_cams):
         assert p.exitcode == 0
     owned = [r[1] for r in res]
     assert sorted(v for m in owned for v in m) == list(range(2 * n_cams))
-    if n_cams >= world:   # twins stay together
+    if n_cams >= world:   # twins stay together, cameras are dealt evenly
         for m in owned:
             assert sorted(v % n_cams for v in m) == sorted(2 * [c for c in set(v % n_cams for v in m)])
+        if n_cams % world == 0:
+            assert all(len(m) == 2 * n_cams // world for m in owned)
     else:
         assert any(len(m) == 0 for m in owned)
     for r in res[1:]:

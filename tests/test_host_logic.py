@@ -127,6 +127,6 @@ def test_cpp_shim_and_its_reference_call_sites_compile():
     `delete trainer->model; trainer->model = new ...`, `train(project, densify)`, `render(fb, w, h, scale, camera)`,
     `truthCameras`) compile with a plain host compiler (the run itself needs the GPU: tests/test_gpu_shim.py)."""
     import subprocess
-    for src in ("shim_step.cpp", "extras_cpu.cpp"):
+    for src in ("shim_step.cpp", "extras_cpu.cpp", "shim_hyper_overload.cpp"):
         subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                                os.path.join(ROOT, "tests", "cpp", src)])

@@ -128,6 +128,18 @@ def test_auto_train_driver_loop():
     assert drv2.update() is False
 
 
+def test_gobj_short_and_malformed_lines_follow_the_stream_reader(tmp_path):
+    """The reference reads `v`, `s`, `a`, `r` lines with a fixed number of `iss >> x` extractions and pushes every one
+    (src/ui/UiFrame.cpp:404-434): a short line, or one holding something a stream does not read as a number, still yields
+    3 / 1 / 4 values — zero from the first failed extraction on."""
+    path = tmp_path / "short.gobj"
+    path.write_text("v 1 2\nsh 1 2 3\ns 1 nan 3\na\nr 1 0 0 0 9\n")
+    m = gs.io.loadSplats(path)
+    assert m.count == 1
+    assert list(m.locations[:3]) == [1.0, 2.0, 0.0] and list(m.scales[:3]) == [1.0, 0.0, 0.0]
+    assert m.opacities[0] == 0.0 and list(m.rotations[:4]) == [1.0, 0.0, 0.0, 0.0]
+
+
 def test_cpp_extras_header_and_gobj_interop(tmp_path):
     """include/gsplat_extras.hpp (C++) against the Python mirror: a .gobj written by Python and copied by C++ equals
     Python's own copy byte for byte; the C++ grid and one-splat-per-triangle fields equal fields.py's."""
