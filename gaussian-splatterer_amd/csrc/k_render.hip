@@ -119,8 +119,8 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
             }
             unsigned long long mask = __ballot(hit);
             while (mask) {
-                const int k = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
+                const int k = __builtin_ctzll(mask);
+                asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(k));  // one SALU instruction instead of the add / addc / and of mask &= mask - 1
                 const int jj = sub + k;
                 const float4 A = st.A[jj], B = st.B[jj];
                 const float cb = st.C[jj].x;
@@ -511,31 +511,40 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
         }
         if (lane == 0) sTouched[wave] = touched;
         __syncthreads();
-        if (tid < ROUND && ROUND - 1 - tid < cnt) {
+        if (wave < 3 && ROUND - 1 - lane < cnt) {
             // moments -> the reference's nine sums (dx = mean2D.x - pixel.x as upstream):
             //   dL_dmean2D.x = -0.5 W op (conA * S[u dx] + conB * S[u dy]),  .y = -0.5 H op (conC * S[u dy] + conB * S[u dx])
             //   dL_dconic    = -0.5 op (S[u dx dx], S[u dx dy], S[u dy dy]),  dL_dopacity = S[u]
-            const float4 Af = st.A[tid], Bf = st.B[tid];
-            const float op = Bf.y, hop = -0.5f * op;
-            float conA, conB, conC;
-            unscaled_conic(Af, Bf, conA, conB, conC);
-            float sum[ACC_STRIDE];
-#pragma unroll
-            for (int q = 0; q < ACC_STRIDE; q++) sum[q] = 0.0f;
+            // Wave w < 3 finishes 12-byte group w of every slot's row (colour | mean2D + conic.x | conic.y, conic.z, opacity):
+            // a third of the LDS reads and one store per thread instead of the whole row on wave 0 while three waves wait.
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
             for (int w = 0; w < 4; w++) {  // fixed order over the four waves; only slots written this round are read
-                if ((sTouched[w] >> tid) & 1ull) {
-                    const float* a = &sAcc[(w * ROUND + tid) * ACC_STRIDE];
-#pragma unroll
-                    for (int q = 0; q < ACC_STRIDE; q++) sum[q] += a[q];
+                if ((sTouched[w] >> lane) & 1ull) {
+                    const float* a = &sAcc[(w * ROUND + lane) * ACC_STRIDE + 3 * wave];
+                    s0 += a[0]; s1 += a[1]; s2 += a[2];
                 }
             }
-            const float gmx = -ddelx_dx * op * (conA * sum[3] + conB * sum[4]);
-            const float gmy = -ddely_dy * op * (conC * sum[4] + conB * sum[3]);
-            Row3* row = reinterpret_cast<Row3*>(Gout + (size_t)sSlot[tid] * G_STRIDE);
-            row[0] = Row3{ sum[0], sum[1], sum[2] };
-            row[1] = Row3{ gmx, gmy, hop * sum[5] };
-            row[2] = Row3{ hop * sum[6], hop * sum[7], sum[8] };
+            Row3 out{ s0, s1, s2 };
+            if (wave != 0) {
+                const float4 Af = st.A[lane], Bf = st.B[lane];
+                const float op = Bf.y, hop = -0.5f * op;
+                if (wave == 1) {
+                    float conA, conB, conC;
+                    unscaled_conic(Af, Bf, conA, conB, conC);
+                    out = Row3{ -ddelx_dx * op * (conA * s0 + conB * s1), -ddely_dy * op * (conC * s1 + conB * s0), hop * s2 };
+                } else {
+                    out = Row3{ hop * s0, hop * s1, s2 };
+                }
+            }
+#ifdef GS_DIAG_ROWS_IN_TILE_ORDER  // timing experiment: rows at the entry's list position (coalesced 2304-byte runs) instead of its slot
+            Row3* row = reinterpret_cast<Row3*>(Gout + ((size_t)start + base + (ROUND - 1 - lane)) * G_STRIDE);
+#else
+            Row3* row = reinterpret_cast<Row3*>(Gout + (size_t)sSlot[lane] * G_STRIDE);
+#endif
+#ifndef GS_DIAG_NO_ROWS  // timing experiment: the kernel without its gradient-row stores
+            row[wave] = out;
+#endif
         }
     }
 }
