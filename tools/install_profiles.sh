@@ -1,0 +1,16 @@
+#!/bin/bash
+# Copies a tools/collect_profiles.sh output directory into profiles/<round>/ under stable names and refreshes profiles/pmc_latest.json.
+#   tools/install_profiles.sh gpurun_out/<tag> profiles/r03 <prefix>
+set -e
+src=$1; dst=$2; p=$3
+mkdir -p $dst
+cp $src/bench_default.json $dst/${p}_bench_default.json
+cp $src/stats50/kernel_stats.csv $dst/${p}_kernel_stats_bench_steps50.csv
+cp $src/stats50/bench_under_rocprof.json $dst/${p}_bench_under_rocprof.json
+cp $src/stats_views2/kernel_stats.csv $dst/${p}_kernel_stats_views2_steps300.csv
+cp $src/stats_dense/kernel_stats.csv $dst/${p}_kernel_stats_config5views8_steps20.csv
+cp $src/pmc/summary.json $dst/${p}_pmc_per_kernel.json
+cp $src/pmc_dense/summary.json $dst/${p}_pmc_per_kernel_config5views8.json
+for f in $src/diag_*.json; do tail -1 $f > $dst/${p}_$(basename $f); done
+python3 tools/pmc_to_latest.py $src/pmc/summary.json profiles/pmc_latest.json > /dev/null
+echo installed into $dst
