@@ -30,6 +30,7 @@ struct Options {
     int fuse = 1;        // gs_trainer_step without densify: one backward per camera pair (the step's `var` has no reader)
     int debug_sync = 0;  // wait and check for errors after every stage, like the reference's debug=true rasterizer calls
     int sh_fp16 = 0;     // the projection reads SH coefficients from a half-precision copy (BASELINE cfg5); fp32 master and gradients
+    int long_sort = -1;  // k_tile_sort_long launch: -1 by the longest-list hint (default), 0 never (lists take the global-scratch path), 1 always
 };
 static Options g_defaults;
 // returns false for an unknown name
@@ -40,6 +41,7 @@ static bool set_option(Options& o, const char* name, int value) {
     if (strcmp(name, "arena_entries") == 0) { o.arena = value > 0 ? value : 0; return true; }
     if (strcmp(name, "debug_sync") == 0) { o.debug_sync = value != 0; return true; }
     if (strcmp(name, "sh_fp16") == 0) { o.sh_fp16 = value != 0; return true; }
+    if (strcmp(name, "long_list_sort_launch") == 0) { o.long_sort = value < 0 ? -1 : (value != 0); return true; }
     return false;
 }
 
@@ -75,7 +77,7 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
     d.P = P; d.Pa = Pa; d.D = D; d.M = M; d.W = W; d.H = H; d.N = W * H;
     d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
     d.sgx = (d.gx + STILE - 1) / STILE; d.sgy = (d.gy + STILE - 1) / STILE; d.NST = d.sgx * d.sgy;
-    d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = cull < 0 ? g_defaults.cull : cull;
+    d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = cull < 0 ? g_defaults.cull : cull; d.long_sort = 1;
     return d;
 }
 
@@ -429,6 +431,8 @@ extern "C" int gs_model_destroy(gs_model* m) {
 // =============================================================================================
 struct gs_trainer {
     Options opt;                  // copied from the process defaults at creation; gs_trainer_set_option edits them
+    int steps_on_these_lists = 0;  // accumulate calls since the model / views / arena last changed: the longest-list hint below is
+                                  // what the device wrote two calls ago and the early flag copy of the last call brought back
     DevBuf densify_work;          // classification flags, ranks and scan partials of densify / prune
     DevBuf sh16;                  // [3M][Pa] half: read copy of the SH planes (option "sh_fp16")
     const void* sh16_of = nullptr;  // the parameter planes the copy was made from and kept current with (null: stale)
@@ -570,7 +574,7 @@ extern "C" int gs_trainer_set_model(gs_trainer* t, gs_model* m) {
     if (t->model != m) gs_model_destroy(t->model);
     t->model = m;
     t->adam_valid = false; t->adam_t = 0; t->accumulated = false;
-    t->sh16_of = nullptr;
+    t->sh16_of = nullptr; t->steps_on_these_lists = 0;
     return GS_OK;
 }
 extern "C" gs_model* gs_trainer_get_model(gs_trainer* t) { return t ? t->model : nullptr; }
@@ -600,6 +604,7 @@ extern "C" int gs_trainer_set_views(gs_trainer* t, int n_views, const gs_view* v
     t->accumulated = false;
     t->views_on_device = nullptr;
     t->stats_stale = false;
+    t->steps_on_these_lists = 0;
     return GS_OK;
 }
 
@@ -684,6 +689,17 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
         GS_TRY(trainer_dims(t, &d));
         GS_TRY(t->train.ensure(P, V, t->W, t->H, t->Rcap, true));
         d.Rcap = t->train.Rcap;
+        // The long-list sort launch is empty in most scenes (no tile list reaches SORT_SMALL_CAP entries) and still costs a
+        // dependent launch — 7 us of a 255 us step at the 8-GPU load.  The host knows the longest list of two steps ago (the
+        // device writes it after the early flag copy, which therefore carries the previous step's value): with a quarter of
+        // headroom the launch is skipped; a list that outgrows the hint anyway is sorted by k_tile_build_sort's global-scratch
+        // path — slower, never wrong.
+        if (t->opt.long_sort >= 0) d.long_sort = t->opt.long_sort;
+        else if (t->steps_on_these_lists >= 2) {
+            uint32_t longest = 0;
+            for (int g = 0; g < t->VG; g++) longest = std::max(longest, t->h_flags[g * 4 + 1]);
+            d.long_sort = longest >= (uint32_t)(SORT_SMALL_CAP - SORT_SMALL_CAP / 4) ? 1 : 0;
+        }
         Scratch s = t->train.s;
         s.truth = t->truth.as<uint32_t>();
         if (t->opt.sh_fp16 && P > 0) {
@@ -746,12 +762,14 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
         GS_HIP(hipStreamSynchronize(t->stream));  // the overflowed groups' later stages are no-ops; drain them before regrowing
         prof_resolve(t);
         t->Rcap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)need + need / 4 + 1024);
+        t->steps_on_these_lists = 0;
         st.arena_regrows++;
         if (st.arena_regrows > 8) { set_error("binning arena failed to converge"); return GS_ERR_INTERNAL; }
     }
     t->last = st;
     t->stats_stale = true;
     t->accumulated = true;
+    t->steps_on_these_lists++;
     return GS_OK;
 }
 
@@ -815,7 +833,7 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
     if (rc != GS_OK) { if (fresh) gs_model_destroy(fresh); new_m.release(); new_v.release(); return rc; }
     std::swap(m->planes, fresh->planes);
     m->Pa = fresh->Pa; m->count = fresh->count;
-    t->sh16_of = nullptr;
+    t->sh16_of = nullptr; t->steps_on_these_lists = 0;
     gs_model_destroy(fresh);
     if (t->adam_valid) {
         t->adam_m.release(); t->adam_v.release();

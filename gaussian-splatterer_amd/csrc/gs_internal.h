@@ -80,6 +80,8 @@ struct Dims {
     uint32_t Rcap;  // entries per view the binning arena holds
     float mod;    // scale modifier
     int cull;     // 1: sub-tile alpha>=1/255 box culling on (default); 0: evaluate every staged pair
+    int long_sort;  // 1: k_tile_sort_long follows k_tile_build_sort (default); 0: the launch is skipped and lists of SORT_SMALL_CAP
+                    //    entries and more take the global-scratch sort inside k_tile_build_sort (the trainer's hint, capi.hip)
 };
 
 // Device pointers of the scratch.  Arrays marked [G] are per geometry group (camera), [V] per pass.

@@ -390,7 +390,9 @@ __global__ __launch_bounds__(WG) void k_tile_scatter(Dims d, Scratch s) {
                 f = s.tile_end[(size_t)v * d.T + ty * d.gx + tx] - n;
             }
         }
-        cur[threadIdx.x] = 0; first[threadIdx.x] = f; big[threadIdx.x] = n > (uint32_t)SORT_LDS_CAP;  // only these take the global-scratch sort, which needs ids by slot
+        // only lists that take the global-scratch sort need ids by slot: those beyond the long-list kernel's LDS, or — when the
+        // trainer skips that launch — beyond the per-tile kernel's
+        cur[threadIdx.x] = 0; first[threadIdx.x] = f; big[threadIdx.x] = n > (uint32_t)(d.long_sort ? SORT_LDS_CAP : SORT_SMALL_CAP);
     }
     __syncthreads();
     const size_t c0 = (size_t)v * d.NST + st;
@@ -620,7 +622,8 @@ __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
     const int tile = (int)s.tile_order[(size_t)v * d.T + blockIdx.x];
     if (s.flags[v * 4 + 0] & 1u) return;  // overflowed view: nothing was scattered
     const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
-    if (n == 0 || n >= (uint32_t)SORT_SMALL_CAP) return;  // long lists: k_tile_sort_long
+    if (n == 0 || (n >= (uint32_t)SORT_SMALL_CAP && d.long_sort)) return;  // long lists: k_tile_sort_long, when it was launched
+    // (without it a list of SORT_SMALL_CAP entries is still sorted in LDS here and longer ones in global scratch: slow, correct)
     sort_tile<WG, SORT_SMALL_CAP, 256>(d, s, v, tile, n, sk, sid);
 }
 
@@ -645,9 +648,11 @@ __global__ __launch_bounds__(LONG_NT) void k_tile_sort_long(Dims d, Scratch s) {
 int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.T == 0 || d.VG == 0) return GS_OK;
     hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T, d.VG), dim3(WG), 0, st, d, s);
-    // one long-list workgroup fills a CU (96 KB LDS): about one per CU over all cameras
-    const int per_cam = std::min(d.T, std::max(16, std::min(256, 256 / std::max(d.VG, 1))));
-    hipLaunchKernelGGL(k_tile_sort_long, dim3(per_cam, d.VG), dim3(LONG_NT), 0, st, d, s);
+    if (d.long_sort) {
+        // one long-list workgroup fills a CU (96 KB LDS): about one per CU over all cameras
+        const int per_cam = std::min(d.T, std::max(16, std::min(256, 256 / std::max(d.VG, 1))));
+        hipLaunchKernelGGL(k_tile_sort_long, dim3(per_cam, d.VG), dim3(LONG_NT), 0, st, d, s);
+    }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -641,3 +641,36 @@ def test_trainer_options_are_per_trainer(orc):
     with pytest.raises(RuntimeError, match="unknown option"):
         a.set_option("no_such_switch", 1)
     a.close(); b.close()
+
+
+def test_long_list_sort_launch_hint_never_changes_a_bit(orc):
+    """The long-list sort launch is skipped when the longest list of two steps ago was short ("long_list_sort_launch" = -1,
+    the default).  Whatever the switch says — never launch (every long list takes the per-tile kernel's global-scratch path),
+    always launch, or the hint — lists, statistics and gradients are the same bits, over several steps of a scene whose tile
+    lists exceed 4096 entries."""
+    P, M, W, H = 6000, 1, 32, 32
+    s = gs.synth.random_splats(P, M, 99)
+    s["loc"] = (s["loc"] * 0.05).astype(np.float32)   # everything projects into the same few tiles
+    s["opac"] = (s["opac"] * 0.02).astype(np.float32)
+    cams = gs.camera.get_cameras(2, 10.0, 20.0)
+    rng = np.random.default_rng(3)
+    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+    res = []
+    for mode in (1, 0, -1):
+        tr = _trainer_on(s, cams, fw, fb, W, H, long_list_sort_launch=mode)
+        out = []
+        for _ in range(4):
+            st = tr.train(gs.Project(), stats=True)
+            out.append((st.num_rendered, st.max_tile_list, st.loss, _read_grads(tr, P, M)))
+        out.append(_download(tr))
+        res.append(out)
+        tr.close()
+    assert res[0][0][1] > 4096
+    for other in res[1:]:
+        for a, b in zip(res[0][:4], other[:4]):
+            assert a[:3] == b[:3]
+            for k in a[3]:
+                assert np.array_equal(a[3][k].view(np.uint32), b[3][k].view(np.uint32)), k
+        for k in ("loc", "sh", "scale", "opac", "rot"):
+            assert np.array_equal(res[0][4][k].view(np.uint32), other[4][k].view(np.uint32)), k
