@@ -236,7 +236,7 @@ template <int D> __device__ inline void sh_basis(float X, float Y, float Z, floa
 // runs the per-splat chain; the result is ONE 64-byte record per (pass, splat):
 //   mean(3) scale(3) rot(4) opacity(1) dL_dRGB(3, clamp-masked) pad(2).   Culled splats write zeros.
 // (Fusing the two passes of a camera into one thread was measured slower: 175 VGPRs, 2 waves/SIMD.)
-// Work items are the backward's {group, pass a, pass b}.  With fused pairs (render_bwd_body<1, 2>) there is one
+// Work items are the backward's {group, pass a, pass b}.  With fused pairs (render_bwd<2>) there is one
 // gradient set per item, in pass a's slice: blockIdx.y then enumerates items and the record is pass a's.
 template <int D>
 __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __restrict__ params, Scratch s, float4* __restrict__ rec_out,
