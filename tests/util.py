@@ -113,43 +113,62 @@ def assert_close_rel(name, got, want, rtol=1e-4, floor=None, max_bad_frac=0.0):
 
 def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4):
     """What the averaged gradients of one iteration may differ from the oracle's by, per entry, with every part of it
-    accounted for.  For every pass the oracle reports, per splat and pixel-stage sum q, sum|term| of the fp32 summation
+    accounted for — and the oracle's averaged gradients themselves (one forward + backward per pass serves both).
+    For every pass the oracle reports, per splat and pixel-stage sum q, sum|term| of the fp32 summation
     (abs9) and the decision-flip allowance (flip9: |term change| of every blend decision within `flip_margin` of its
     threshold, see tests/test_gpu_raster.py::check_pixel_stage).  The per-splat chain is linear in the nine sums and the
     HIP chain repeats the oracle's fp32 operations, so an output's budget is the sums' budget carried through the chain,
         |d out_k| <= sum_q |A_kq| * (1e-4 * abs9_q + flip9_q),    A = the chain evaluated on the nine unit inputs,
     and accumulateGradients (src/Trainer.cu:47-77) adds the passes' gradients divided by S: the budgets add the same way
     (`var` = sum of |g_loc| / S: | |a| - |b| | <= |a - b|).
-    Returns {array: {"budget": with flips, "sumabs": sum|term| carried through the chain, without the 1e-4 and flips}}."""
+    Returns {array: {"budget": with flips, "sumabs": sum|term| carried through the chain, without the 1e-4 and flips,
+    "want": the oracle's averaged gradient — accumulateGradients restated in fp32 numpy, bit-identical to orc.train_views
+    (tests/test_gpu_trainer.py::test_step_budget_restates_accumulate_gradients)}, "num_rendered": [per pass]}."""
     P = s["opac"].size
     V = views40.shape[0]
     N = W * H
+    f32 = np.float32
+    S = f32(samples)
     chain_names = {"loc": ("dL_dmean3D", 3), "sh": ("dL_dsh", 3 * M), "scale": ("dL_dscale", 3), "rot": ("dL_drot", 4)}
-    out = {k: {"budget": np.zeros((P, st)), "sumabs": np.zeros((P, st))} for k, (_, st) in chain_names.items()}
-    out["opac"] = {"budget": np.zeros((P, 1)), "sumabs": np.zeros((P, 1))}
-    out["var"] = {"budget": np.zeros((P, 1)), "sumabs": np.zeros((P, 1))}
+    strides = dict(loc=3, sh=3 * M, scale=3, rot=4, opac=1, var=1)
+    out = {k: {"budget": np.zeros((P, st)), "sumabs": np.zeros((P, st)), "want": np.zeros((P, st), f32)} for k, st in strides.items()}
+    num_rendered = []
     truths = np.asarray(truths, np.uint32).reshape(V, N)
     for v in range(V):
         vp = view_parts(views40[v])
-        r, img, _ = oracle_forward(orc, s, D, M, vp, W, H)
+        r, img, R = oracle_forward(orc, s, D, M, vp, W, H)
+        num_rendered.append(R)
         dpix = orc.image_int_to_loss(truths[v], img, W, H)
         og = r.backward(dpix, want_abs=True, flip_margin=flip_margin)
-        abs9, tol9 = og["abs9"], 1e-4 * og["abs9"] + og["flip9"]
+        # accumulateGradients, src/Trainer.cu:47-77 (same fp32 operations in the same order as oracle/gs_oracle.cpp)
+        gm = og["dL_dmean3D"].reshape(P, 3)
+        out["var"]["want"][:, 0] += np.sqrt((gm[:, 0] * gm[:, 0] + gm[:, 1] * gm[:, 1]) + gm[:, 2] * gm[:, 2]) / S
+        for k, (n, st) in chain_names.items():
+            out[k]["want"] += og[n].reshape(P, st) / S
+        out["opac"]["want"][:, 0] += og["dL_dopacity"] / S
+        abs9 = og["abs9"].astype(f32)
+        tol9 = (1e-4 * og["abs9"] + og["flip9"]).astype(f32)
         loc_b, loc_a = np.zeros((P, 3)), np.zeros((P, 3))
-        for q in range(9):
-            unit = np.zeros((P, 9), np.float32); unit[:, q] = 1.0
+        for q in range(8):   # (sum 8, dL_dopacity, does not enter the chain)
+            unit = np.zeros((P, 9), f32); unit[:, q] = 1.0
             col = orc.chain(r, unit)
             for k, (n, st) in chain_names.items():
-                A = np.abs(col[n].reshape(P, st).astype(np.float64))
-                out[k]["budget"] += A * tol9[:, q, None] / samples
-                out[k]["sumabs"] += A * abs9[:, q, None] / samples
+                # which sums reach which output (tests/test_step_budget.py checks the zero blocks): the SH gradient is
+                # basis x dL_dcolour (sums 0-2); scale and rotation come from the conic sums (5-7) alone
+                if (k == "sh" and q >= 3) or (k in ("scale", "rot") and q not in (5, 6, 7)):
+                    continue
+                A = np.abs(col[n].reshape(P, st))
+                out[k]["budget"] += A * (tol9[:, q, None] / S)
+                out[k]["sumabs"] += A * (abs9[:, q, None] / S)
                 if k == "loc":
                     loc_b += A * tol9[:, q, None]; loc_a += A * abs9[:, q, None]
-        out["opac"]["budget"] += tol9[:, 8:9] / samples
-        out["opac"]["sumabs"] += abs9[:, 8:9] / samples
-        out["var"]["budget"] += np.linalg.norm(loc_b, axis=1, keepdims=True) / samples
-        out["var"]["sumabs"] += np.linalg.norm(loc_a, axis=1, keepdims=True) / samples
-    return {k: {a: b.reshape(-1) for a, b in d.items()} for k, d in out.items()}
+        out["opac"]["budget"] += tol9[:, 8:9] / S
+        out["opac"]["sumabs"] += abs9[:, 8:9] / S
+        out["var"]["budget"] += np.linalg.norm(loc_b, axis=1, keepdims=True) / S
+        out["var"]["sumabs"] += np.linalg.norm(loc_a, axis=1, keepdims=True) / S
+    res = {k: {a: b.reshape(-1) for a, b in d.items()} for k, d in out.items()}
+    res["num_rendered"] = np.asarray(num_rendered, np.int64)
+    return res
 
 
 def unexplained(name, got, want, budget, stride=1, eps_rel=4e-6):
