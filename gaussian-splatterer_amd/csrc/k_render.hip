@@ -467,46 +467,45 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
 #endif
         const unsigned long long touched = mask;
         const uint32_t pos_slot0 = (uint32_t)(base + ROUND - 1);  // upstream's `contributor` (after its decrement) of slot 0
-        int nb = 0;          // hits parked and not yet contracted
-        uint32_t blo = 0;    // their slots, 8 bits apiece, newest in the low byte
+        // Hits are taken PARK_BATCH at a time: the inner loop is unrolled, so a hit's parking offset is an immediate and the
+        // batch needs no counter arithmetic; the round's last, partly filled batch leaves the inner loop early.
         while (mask != 0ull) {
-            const int k = __builtin_ctzll(mask);
-            asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(k));
-            const float4 Ac = st.A[k], Bc = st.B[k];
-            const float cbc = st.C[k].x;
-            const uint32_t pos = pos_slot0 - (uint32_t)k;
-            const float dx = Ac.x - pxf, dy = Ac.y - pyf;
-            const float power = dx * (Ac.z * dx + Ac.w * dy) + Bc.x * dy * dy;  // log2 of the Gaussian weight
-            const float G0 = __builtin_amdgcn_exp2f(power);
-            const float alpha0 = fminf(ALPHA_MAX, Bc.y * G0);
-            const bool act = (pos < last_contributor) & (power <= 0.0f) & (alpha0 >= ALPHA_MIN);
-            const float G = act ? G0 : 0.0f, alpha = act ? alpha0 : 0.0f;
-            const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);  // exactly 1 for an inactive lane
-            T = T * inv1ma;
-            const float w = alpha * T;
-            // upstream: dL_dalpha = sum_ch (colour_ch - accum_rec_ch) * dL_dpixel_ch with accum_rec blended per channel,
-            // accum_rec = last_alpha * last_colour + (1 - last_alpha) * accum_rec.  Only the contraction with dL_dpixel is ever
-            // used, and it obeys the same recurrence: arp = sum_ch accum_rec_ch * dL_dpixel_ch  ->  arp += alpha * (cd - arp)
-            // with cd = sum_ch colour_ch * dL_dpixel_ch (blend applied AFTER use: the identical recurrence one step early).
-            const float cd = Bc.z * dpx0 + Bc.w * dpx1 + cbc * dpx2;
-            const float dL = cd - arp;
-            arp = fmaf(alpha, dL, arp);
-            const float u = G * (dL * T + tfbg * inv1ma);  // G * (dL_dalpha * T + tfbg / (1 - alpha)),  tfbg = -T_final * (bg . dL_dpix)
-            park[nb * PARK_STRIDE + lane] = w;
-            park[nb * PARK_STRIDE + 64 + lane] = u;
-            blo = (blo << 8) | (uint32_t)k;
-            if (++nb == PARK_BATCH) {
-                __builtin_amdgcn_wave_barrier();
-#ifndef GS_DIAG_NO_CONTRACT
-                contract_parked(park, st, acc, PARK_BATCH, blo, dpr, pxcol0, pyrow, lane);
-#endif
-                __builtin_amdgcn_wave_barrier();
-                nb = 0;
+            int nb = 0;          // hits parked in this batch
+            uint32_t blo = 0;    // their slots, 8 bits apiece, newest in the low byte
+#pragma unroll
+            for (int hq = 0; hq < PARK_BATCH; hq++) {
+                if (mask == 0ull) break;
+                const int k = __builtin_ctzll(mask);
+                asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(k));
+                const float4 Ac = st.A[k], Bc = st.B[k];
+                const float cbc = st.C[k].x;
+                const uint32_t pos = pos_slot0 - (uint32_t)k;
+                const float dx = Ac.x - pxf, dy = Ac.y - pyf;
+                const float power = dx * (Ac.z * dx + Ac.w * dy) + Bc.x * dy * dy;  // log2 of the Gaussian weight
+                const float G0 = __builtin_amdgcn_exp2f(power);
+                const float alpha0 = fminf(ALPHA_MAX, Bc.y * G0);
+                const bool act = (pos < last_contributor) & (power <= 0.0f) & (alpha0 >= ALPHA_MIN);
+                const float G = act ? G0 : 0.0f, alpha = act ? alpha0 : 0.0f;
+                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);  // exactly 1 for an inactive lane
+                T = T * inv1ma;
+                const float w = alpha * T;
+                // upstream: dL_dalpha = sum_ch (colour_ch - accum_rec_ch) * dL_dpixel_ch with accum_rec blended per channel,
+                // accum_rec = last_alpha * last_colour + (1 - last_alpha) * accum_rec.  Only the contraction with dL_dpixel is ever
+                // used, and it obeys the same recurrence: arp = sum_ch accum_rec_ch * dL_dpixel_ch  ->  arp += alpha * (cd - arp)
+                // with cd = sum_ch colour_ch * dL_dpixel_ch (blend applied AFTER use: the identical recurrence one step early).
+                const float cd = Bc.z * dpx0 + Bc.w * dpx1 + cbc * dpx2;
+                const float dL = cd - arp;
+                arp = fmaf(alpha, dL, arp);
+                const float u = G * (dL * T + tfbg * inv1ma);  // G * (dL_dalpha * T + tfbg / (1 - alpha)),  tfbg = -T_final * (bg . dL_dpix)
+                park[hq * PARK_STRIDE + lane] = w;
+                park[hq * PARK_STRIDE + 64 + lane] = u;
+                blo = (blo << 8) | (uint32_t)k;
+                nb = hq + 1;
             }
-        }
-        if (nb != 0) {  // the round's last, partly filled batch
             __builtin_amdgcn_wave_barrier();
+#ifndef GS_DIAG_NO_CONTRACT
             contract_parked(park, st, acc, nb, blo, dpr, pxcol0, pyrow, lane);
+#endif
             __builtin_amdgcn_wave_barrier();
         }
         if (lane == 0) sTouched[wave] = touched;
