@@ -32,6 +32,9 @@ def test_chain_matrix_zero_blocks(orc):
         col = orc.chain(r, unit)
         if q >= 3:
             assert not col["dL_dsh"].any()
+        else:   # colour sum q reaches channel q of every SH coefficient only
+            sh = col["dL_dsh"].reshape(P, M, 3)
+            assert not np.delete(sh, q, axis=2).any() and sh[:, :, q].any()
         if q not in (5, 6, 7):
             assert not col["dL_dscale"].any() and not col["dL_drot"].any()
         if q == 8:

@@ -131,7 +131,7 @@ def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4):
     S = f32(samples)
     chain_names = {"loc": ("dL_dmean3D", 3), "sh": ("dL_dsh", 3 * M), "scale": ("dL_dscale", 3), "rot": ("dL_drot", 4)}
     strides = dict(loc=3, sh=3 * M, scale=3, rot=4, opac=1, var=1)
-    out = {k: {"budget": np.zeros((P, st)), "sumabs": np.zeros((P, st)), "want": np.zeros((P, st), f32)} for k, st in strides.items()}
+    out = {k: {"budget": np.zeros((P, st), f32), "sumabs": np.zeros((P, st), f32), "want": np.zeros((P, st), f32)} for k, st in strides.items()}
     num_rendered = []
     truths = np.asarray(truths, np.uint32).reshape(V, N)
     for v in range(V):
@@ -148,7 +148,7 @@ def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4):
         out["opac"]["want"][:, 0] += og["dL_dopacity"] / S
         abs9 = og["abs9"].astype(f32)
         tol9 = (1e-4 * og["abs9"] + og["flip9"]).astype(f32)
-        loc_b, loc_a = np.zeros((P, 3)), np.zeros((P, 3))
+        loc_b, loc_a = np.zeros((P, 3), f32), np.zeros((P, 3), f32)
         for q in range(8):   # (sum 8, dL_dopacity, does not enter the chain)
             unit = np.zeros((P, 9), f32); unit[:, q] = 1.0
             col = orc.chain(r, unit)
@@ -156,6 +156,11 @@ def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4):
                 # which sums reach which output (tests/test_step_budget.py checks the zero blocks): the SH gradient is
                 # basis x dL_dcolour (sums 0-2); scale and rotation come from the conic sums (5-7) alone
                 if (k == "sh" and q >= 3) or (k in ("scale", "rot") and q not in (5, 6, 7)):
+                    continue
+                if k == "sh":   # colour sum q reaches channel q of every coefficient only (same test as the other zero blocks)
+                    A = np.abs(col[n].reshape(P, M, 3)[:, :, q])
+                    out[k]["budget"].reshape(P, M, 3)[:, :, q] += A * (tol9[:, q, None] / S)
+                    out[k]["sumabs"].reshape(P, M, 3)[:, :, q] += A * (abs9[:, q, None] / S)
                     continue
                 A = np.abs(col[n].reshape(P, st))
                 out[k]["budget"] += A * (tol9[:, q, None] / S)
@@ -166,7 +171,7 @@ def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4):
         out["opac"]["sumabs"] += abs9[:, 8:9] / S
         out["var"]["budget"] += np.linalg.norm(loc_b, axis=1, keepdims=True) / S
         out["var"]["sumabs"] += np.linalg.norm(loc_a, axis=1, keepdims=True) / S
-    res = {k: {a: b.reshape(-1) for a, b in d.items()} for k, d in out.items()}
+    res = {k: {a: (b.reshape(-1) if a == "want" else b.reshape(-1).astype(np.float64)) for a, b in d.items()} for k, d in out.items()}
     res["num_rendered"] = np.asarray(num_rendered, np.int64)
     return res
 
