@@ -550,9 +550,14 @@ def _half_rounded(s):
     return r
 
 
-def _trainer_on(s, cams, fw, fb, W, H, **options):
+def _host(s):
     host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
     host.shDegree = s["D"]
+    return host
+
+
+def _trainer_on(s, cams, fw, fb, W, H, **options):
+    host = _host(s)
     tr = gs.Trainer(W, H)
     for k, v in options.items():
         tr.set_option(k, v)
@@ -642,6 +647,19 @@ def test_trainer_options_are_per_trainer(orc):
     with pytest.raises(RuntimeError, match="unknown option"):
         a.set_option("no_such_switch", 1)
     a.close(); b.close()
+    # "share_camera_passes" regroups passes that are already set: switching it off AFTER captureTruths equals a trainer that
+    # never shared (both in the per-pass form: without sharing there are no pairs to fuse), bit for bit
+    c = _trainer_on(s, cams, fw, fb, W, H, fuse_camera_passes=0)
+    c.train(gs.Project())                      # uploads the views, grouped by camera
+    c.set_option("share_camera_passes", 0)     # ... and regroups them
+    c.model = gs.ModelSplatsDevice(_host(s))
+    c.train(gs.Project())
+    e = _trainer_on(s, cams, fw, fb, W, H, fuse_camera_passes=0, share_camera_passes=0)
+    e.train(gs.Project())
+    gc, ge = _read_grads(c, P, M), _read_grads(e, P, M)
+    for k in gc:
+        assert np.array_equal(gc[k].view(np.uint32), ge[k].view(np.uint32)), k
+    c.close(); e.close()
 
 
 def test_long_list_sort_launch_hint_never_changes_a_bit(orc):
