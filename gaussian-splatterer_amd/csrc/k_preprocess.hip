@@ -8,6 +8,8 @@
 // depth, radius and tile rectangle (and therefore the sorted tile lists) are bit-identical.
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
+
 #include "gs_internal.h"
 #include "sh_jac.h"
 
@@ -21,19 +23,44 @@ __device__ __constant__ float SH_C3[7] = { -0.5900435899266435f, 2.8906114426405
                                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                            -0.5900435899266435f };
 
+// The parameters of one splat, loaded once and projected through every camera of the block's chunk: a thread per (camera,
+// splat) re-read the 11 + 3M planes per camera and spent its life waiting for them (0.060 ms per launch at cfg3 for 9 us of
+// arithmetic).
+template <int D> struct SplatIn {
+    static constexpr int NC = (D + 1) * (D + 1);
+    float loc[3], scale[3], rot[4], opacity;
+    float sh[NC][3];
+};
+template <int D, bool H>
+__device__ inline void load_splat(const Dims& d, const float* __restrict__ params, const Scratch& s, int i, SplatIn<D>& in) {
+    const Planes pl{ d.M };
+    const size_t st = (size_t)d.Pa;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { in.loc[c] = params[pl.loc(c) * st + i]; in.scale[c] = params[pl.scale(c) * st + i]; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) in.rot[c] = params[pl.rot(c) * st + i];
+    in.opacity = params[pl.opac() * st + i];
+    const __half* sh16 = reinterpret_cast<const __half*>(s.sh16);
+#pragma unroll
+    for (int k = 0; k < SplatIn<D>::NC; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if constexpr (H) in.sh[k][c] = __half2float(sh16[(size_t)(3 * k + c) * st + i]);
+            else in.sh[k][c] = params[pl.sh(k, c) * st + i];
+        }
+}
+
 // one (view, splat): writes the record and tiles_touched, counts the splat into its super-tiles; returns tiles_touched
 // H: the SH coefficients come from the trainer's half-precision read copy (s.sh16) instead of the fp32 planes; everything
 // else — geometry, lists, ranges — does not touch SH and is bit-identical in both modes.
-template <int D, bool H>
-__device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict__ params, const Scratch& s, int i, int v,
-                                          uint32_t* hist) {
+template <int D>
+__device__ inline uint32_t preprocess_one(const Dims& d, const SplatIn<D>& in, const Scratch& s, int i, int v, uint32_t* hist) {
     const gs_view& vp = s.gviews[v];  // v indexes geometry groups here
-    const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
     GeomRec* rec = s.geom + (size_t)v * st + i;
     uint32_t* tt = s.tiles_touched + (size_t)v * st + i;
 
-    const float px_ = params[pl.loc(0) * st + i], py_ = params[pl.loc(1) * st + i], pz_ = params[pl.loc(2) * st + i];
+    const float px_ = in.loc[0], py_ = in.loc[1], pz_ = in.loc[2];
     const float* vm = vp.view;
     const float* pm = vp.projview;
     // p_view (transformPoint4x3), near-plane cull
@@ -51,10 +78,8 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict
         const float p_w = 1.0f / (phw + 0.0000001f);
         const float ppx = phx * p_w, ppy = phy * p_w;
 
-        const float sx = d.mod * params[pl.scale(0) * st + i], sy = d.mod * params[pl.scale(1) * st + i],
-                    sz = d.mod * params[pl.scale(2) * st + i];
-        const float r = params[pl.rot(0) * st + i], x = params[pl.rot(1) * st + i], y = params[pl.rot(2) * st + i],
-                    z = params[pl.rot(3) * st + i];
+        const float sx = d.mod * in.scale[0], sy = d.mod * in.scale[1], sz = d.mod * in.scale[2];
+        const float r = in.rot[0], x = in.rot[1], y = in.rot[2], z = in.rot[3];
         float Rg[3][3];
         Rg[0][0] = 1.0f - 2.0f * (y * y + z * z); Rg[0][1] = 2.0f * (x * y - r * z); Rg[0][2] = 2.0f * (x * z + r * y);
         Rg[1][0] = 2.0f * (x * y + r * z); Rg[1][1] = 1.0f - 2.0f * (x * x + z * z); Rg[1][2] = 2.0f * (y * z - r * x);
@@ -122,11 +147,7 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict
     dx = dx / len; dy = dy / len; dz = dz / len;
     float res[3], jac[9];
     uint32_t flags = 0;
-    const __half* sh16 = reinterpret_cast<const __half*>(s.sh16);
-    auto shv = [&](int k, int c) -> float {
-        if constexpr (H) return __half2float(sh16[(size_t)(3 * k + c) * st + i]);
-        else return params[pl.sh(k, c) * st + i];
-    };
+    auto shv = [&](int k, int c) -> float { return in.sh[k][c]; };
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         float val = SH_C0 * shv(0, c);
@@ -167,7 +188,7 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict
     // minimum q over the block exceeds tau — pairs the blend would skip anyway.  1 % + 0.01 of margin covers the
     // fp32 error of conic / log / the block test; tau < 0 marks splats that can never reach 1/255; a conic that is
     // not positive definite (the block test assumes convexity) or culling switched off gives tau = 3e38.
-    const float opacity = params[pl.opac() * st + i];
+    const float opacity = in.opacity;
     float hx, hy = 0.0f;
     {
         const float dc = conx * conz - cony * cony;
@@ -195,45 +216,58 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const float* __restrict
     return ntiles;
 }
 
+#ifndef GS_PREPROCESS_CAMERAS
+#define GS_PREPROCESS_CAMERAS 8  // cameras a block projects its splats through (tuning hook, tools/build_variant.sh)
+#endif
+// blockIdx.y selects a chunk of `cpb` geometry groups (cameras): the block loads its 256 splats once and projects them through
+// every camera of the chunk, one LDS histogram per camera.
 template <int D, bool H>
-__global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restrict__ params, Scratch s) {
-    extern __shared__ uint32_t hist[];  // [NST] candidates of this block per super-tile
+__global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restrict__ params, Scratch s, int cpb) {
+    extern __shared__ uint32_t hist[];  // [cpb][NST] candidates of this block per (camera, super-tile)
     __shared__ uint32_t wsum[WG / 64];
     const int i = blockIdx.x * WG + threadIdx.x;
-    const int v = blockIdx.y;
-    for (int k = threadIdx.x; k < d.NST; k += WG) hist[k] = 0;
+    const int v0 = blockIdx.y * cpb, v1 = min(d.VG, v0 + cpb);
+    for (int k = threadIdx.x; k < (v1 - v0) * d.NST; k += WG) hist[k] = 0;
+    SplatIn<D> in;
+    if (i < d.P) load_splat<D, H>(d, params, s, i, in);
     __syncthreads();
-    uint32_t n = 0;
-    if (i < d.P) n = preprocess_one<D, H>(d, params, s, i, v, hist);
-    // the block's share of the offsets scan (k_coarse_colscan's extra workgroup turns the block sums into prefixes, the coarse
-    // scatter finishes the scan inside each block): no separate pass over tiles_touched
+    for (int v = v0; v < v1; v++) {
+        uint32_t* h = hist + (size_t)(v - v0) * d.NST;
+        uint32_t n = 0;
+        if (i < d.P) n = preprocess_one<D>(d, in, s, i, v, h);
+        // the block's share of the offsets scan (k_coarse_colscan's extra workgroup turns the block sums into prefixes, the
+        // coarse scatter finishes the scan inside each block): no separate pass over tiles_touched
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
-    __syncthreads();
-    if (threadIdx.x == 0) s.block_sums[(size_t)v * splat_blocks(d.Pa) + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    // the block's row of the (block x super-tile) count matrix: the binning needs no global atomics at all
-    uint32_t* row = s.wg_hist + ((size_t)v * splat_blocks(d.Pa) + blockIdx.x) * d.NST;
-    for (int k = threadIdx.x; k < d.NST; k += WG) row[k] = hist[k];
+        for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+        __syncthreads();  // also: every thread's LDS atomics into this camera's histogram are done
+        if (threadIdx.x == 0) s.block_sums[(size_t)v * splat_blocks(d.Pa) + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        // the block's row of the (block x super-tile) count matrix: the binning needs no global atomics at all
+        uint32_t* row = s.wg_hist + ((size_t)v * splat_blocks(d.Pa) + blockIdx.x) * d.NST;
+        for (int k = threadIdx.x; k < d.NST; k += WG) row[k] = h[k];
+        __syncthreads();  // wsum is reused by the next camera
+    }
 }
 
 int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st) {
     if (d.P == 0 || d.VG == 0) return GS_OK;
-    dim3 grid((d.P + WG - 1) / WG, d.VG);
-    const size_t lds = (size_t)d.NST * sizeof(uint32_t);
+    // cameras per block: as many as fit 32 KB of LDS histograms, at most GS_PREPROCESS_CAMERAS
+    const int cpb = std::max(1, std::min({ d.VG, GS_PREPROCESS_CAMERAS, (int)(32768 / ((size_t)d.NST * sizeof(uint32_t))) }));
+    dim3 grid((d.P + WG - 1) / WG, (d.VG + cpb - 1) / cpb);
+    const size_t lds = (size_t)cpb * d.NST * sizeof(uint32_t);
     if (s.sh16) {
         switch (d.D) {
-            case 0: hipLaunchKernelGGL((k_preprocess<0, true>), grid, dim3(WG), lds, st, d, params, s); break;
-            case 1: hipLaunchKernelGGL((k_preprocess<1, true>), grid, dim3(WG), lds, st, d, params, s); break;
-            case 2: hipLaunchKernelGGL((k_preprocess<2, true>), grid, dim3(WG), lds, st, d, params, s); break;
-            default: hipLaunchKernelGGL((k_preprocess<3, true>), grid, dim3(WG), lds, st, d, params, s); break;
+            case 0: hipLaunchKernelGGL((k_preprocess<0, true>), grid, dim3(WG), lds, st, d, params, s, cpb); break;
+            case 1: hipLaunchKernelGGL((k_preprocess<1, true>), grid, dim3(WG), lds, st, d, params, s, cpb); break;
+            case 2: hipLaunchKernelGGL((k_preprocess<2, true>), grid, dim3(WG), lds, st, d, params, s, cpb); break;
+            default: hipLaunchKernelGGL((k_preprocess<3, true>), grid, dim3(WG), lds, st, d, params, s, cpb); break;
         }
     } else {
         switch (d.D) {
-            case 0: hipLaunchKernelGGL((k_preprocess<0, false>), grid, dim3(WG), lds, st, d, params, s); break;
-            case 1: hipLaunchKernelGGL((k_preprocess<1, false>), grid, dim3(WG), lds, st, d, params, s); break;
-            case 2: hipLaunchKernelGGL((k_preprocess<2, false>), grid, dim3(WG), lds, st, d, params, s); break;
-            default: hipLaunchKernelGGL((k_preprocess<3, false>), grid, dim3(WG), lds, st, d, params, s); break;
+            case 0: hipLaunchKernelGGL((k_preprocess<0, false>), grid, dim3(WG), lds, st, d, params, s, cpb); break;
+            case 1: hipLaunchKernelGGL((k_preprocess<1, false>), grid, dim3(WG), lds, st, d, params, s, cpb); break;
+            case 2: hipLaunchKernelGGL((k_preprocess<2, false>), grid, dim3(WG), lds, st, d, params, s, cpb); break;
+            default: hipLaunchKernelGGL((k_preprocess<3, false>), grid, dim3(WG), lds, st, d, params, s, cpb); break;
         }
     }
     GS_HIP(hipGetLastError());
