@@ -80,7 +80,11 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
 #pragma clang fp contract(fast)
     __shared__ StagedTile<WG> st;
     const int v = blockIdx.y;  // v = geometry group (camera)
+#ifdef GS_DIAG_XCD_STRIPES  // timing experiment: workgroups b, b+8, b+16 ... (one XCD) take a contiguous stripe of tiles, row-major
+    const int tile = (int)((blockIdx.x % 8) * (d.T / 8) + blockIdx.x / 8);
+#else
     const int tile = (int)s.tile_order[(size_t)v * d.T + blockIdx.x];
+#endif
     if (s.flags[v * 4 + 0] & 1u) return;
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -326,7 +330,11 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
     __shared__ uint32_t sMaxLast;
     __shared__ float sLoss[F][4];
     const int g = item[0];  // item = {group, pass 0[, pass 1]}; lists, records, T and n_contrib live in the geometry group
+#ifdef GS_DIAG_XCD_STRIPES
+    const int tile = (int)((blockIdx.x % 8) * (d.T / 8) + blockIdx.x / 8);
+#else
     const int tile = (int)s.tile_order[(size_t)g * d.T + blockIdx.x];
+#endif
     int vin[F];  // the passes whose residual images are summed; the rows go to the slice of the first one
 #pragma unroll
     for (int q = 0; q < F; q++) vin[q] = item[1 + q];
