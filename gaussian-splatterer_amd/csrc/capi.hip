@@ -133,7 +133,7 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
 }
 
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads, shjac;
+    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads, shjac;
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
     Scratch s{};
@@ -158,6 +158,7 @@ struct ScratchSet {
         GS_TRY(zero_block.ensure(zero_bytes));
         GS_TRY(wghist.ensure(v * splat_blocks(Pa) * NST * 4));
         GS_TRY(coarse_count.ensure(v * NST * 4));
+        GS_TRY(colscan.ensure(std::max<size_t>(4, colscan_partial_words(Pa, NST, (int)v) * 4)));
         GS_TRY(coarse_end.ensure(v * NST * 4));
         GS_TRY(tile_count.ensure(v * T * 4));
         GS_TRY(tile_end.ensure(v * T * 4));
@@ -184,6 +185,7 @@ struct ScratchSet {
         s.point_offsets = offsets.as<uint32_t>();
         s.wg_hist = wghist.as<uint32_t>();
         s.coarse_count = coarse_count.as<uint32_t>();
+        s.colscan_partial = colscan_partial_words(Pa, NST, (int)v) ? colscan.as<uint32_t>() : nullptr;
         s.flags = zero_block.as<uint32_t>();
         s.loss_total = reinterpret_cast<float*>(s.flags + v * 4);
         s.loss = tloss.as<float>();
@@ -205,7 +207,7 @@ struct ScratchSet {
         return GS_OK;
     }
     void release() {
-        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &wghist, &coarse_count, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &color,
+        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &wghist, &colscan, &coarse_count, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &color,
                            &finalT, &ncontrib, &scan_tmp, &sgrads, &shjac })
             b->release();
     }

@@ -98,6 +98,7 @@ struct Scratch {
     uint32_t* wg_hist;         // [G][splat_blocks(Pa)][NST] candidates per (256-splat block, super-tile); k_coarse_colscan turns
                                //     every super-tile's column into its exclusive prefix over the blocks
     uint32_t* coarse_count;    // [G][NST] candidates per super-tile
+    uint32_t* colscan_partial; // [G][chunks][NST] chunk sums of the two-pass column scan (large models only; null: one-pass form)
     uint32_t* coarse_end;      // [G][NST] inclusive scan of coarse_count
     uint4* coarse_list;        // [V][Rcap] {splat id, rect_min, rect_max, first slot} per (splat, super-tile)
     uint32_t* coarse_depth;    // [V][Rcap] depth bits of the same entries
@@ -128,6 +129,7 @@ int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipS
 // after preprocess, one launch: column scan of the (block x super-tile) count matrix + the prefix of the per-block tile
 // sums (-> flags: num_rendered, arena overflow); the scan of the super-tile totals happens inside k_coarse_scatter
 int launch_coarse_colscan(const Dims& d, const Scratch& s, hipStream_t st);
+size_t colscan_partial_words(int Pa, int NST, int V);  // scratch the two-pass column scan needs (0: one-pass form)
 // batched inclusive scan of u32: one workgroup per batch entry up to g_scan_single_max items, three phases beyond
 int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int batch, uint32_t* partials, hipStream_t st);
 size_t scan_partials_count(int n, int batch);

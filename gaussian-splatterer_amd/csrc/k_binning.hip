@@ -126,6 +126,27 @@ int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int ba
     return GS_OK;
 }
 
+// per-block tile sums -> exclusive prefixes; entry count and overflow verdict of the group (every flag word is rewritten each
+// step: nothing to clear beforehand)
+__device__ inline void block_sums_prefix(const Dims& d, const Scratch& s, int v) {
+    const int nb = (d.P + WG - 1) / WG;
+    uint32_t* p = s.block_sums + (size_t)v * splat_blocks(d.Pa);
+    uint32_t carry = 0;
+    for (int base = 0; base < nb; base += WG) {
+        const int idx = base + threadIdx.x;
+        const uint32_t x = idx < nb ? p[idx] : 0;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(x, &total);
+        if (idx < nb) p[idx] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        s.flags[v * 4 + 2] = carry;  // num_rendered of this group
+        s.flags[v * 4 + 0] = carry > d.Rcap ? 1u : 0u;  // arena too small: the later stages skip the group, the host grows and replays
+        s.flags[v * 4 + 3] = 0u;
+    }
+}
+
 // Column scan of the (splat block x super-tile) count matrix: one WAVE per super-tile walks the column over the
 // blocks, replaces every count by the exclusive prefix of its column and writes the column total (the super-tile's
 // candidate count).  With the scan of the totals this gives every block its private output range per super-tile:
@@ -137,22 +158,7 @@ __global__ __launch_bounds__(WG) void k_coarse_colscan(Dims d, Scratch s) {
         // The launch's extra workgroup: turns the per-block tile sums (k_preprocess) into exclusive prefixes and
         // publishes the group's entry count (flags[2]) and the arena-overflow bit (flags[0]).  It needs nothing of the
         // column scan, so it rides in the same launch (one dependent launch less per step).
-        const int nb = (d.P + WG - 1) / WG;
-        uint32_t* p = s.block_sums + (size_t)v * splat_blocks(d.Pa);
-        uint32_t carry = 0;
-        for (int base = 0; base < nb; base += WG) {
-            const int idx = base + threadIdx.x;
-            const uint32_t x = idx < nb ? p[idx] : 0;
-            uint32_t total;
-            const uint32_t ex = block_excl_scan(x, &total);
-            if (idx < nb) p[idx] = carry + ex;
-            carry += total;
-        }
-        if (threadIdx.x == 0) {
-            s.flags[v * 4 + 2] = carry;  // num_rendered of this group
-            s.flags[v * 4 + 0] = carry > d.Rcap ? 1u : 0u;  // arena too small: the later stages skip the group, the host grows and replays
-            s.flags[v * 4 + 3] = 0u;  // (every flag word is rewritten each step: nothing to clear beforehand)
-        }
+        block_sums_prefix(d, s, v);
         return;
     }
     const int st = blockIdx.x * (WG / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -172,11 +178,59 @@ __global__ __launch_bounds__(WG) void k_coarse_colscan(Dims d, Scratch s) {
 // Column scan of the count matrix + (extra workgroup) the prefix of the block tile sums with the entry count and the
 // overflow verdict.  The scan of the super-tile totals that used to be a launch of its own is done by the consumer
 // (k_coarse_scatter): NST is at most MAX_SUPER_TILES, a few LDS scan trips per workgroup.
+// Large models (>= COLSCAN_TWO_PASS_BLOCKS splat blocks): the one-wave-per-column walk above touches the matrix through a stride
+// of NST words — one 64-byte line per lane and access, 0.23 ms for the 128 MB of four 1M-splat cameras.  Two coalesced passes
+// instead: thread = column (256 consecutive super-tiles per workgroup), rows in chunks of COLSCAN_CHUNK blocks.
+//   pass 1  sum of every (chunk, column)                                  -> partial[chunk][column]
+//   pass 2  prefix of the chunk sums in front of the chunk, then the chunk's rows again, writing the exclusive prefix in
+//           place; the last chunk also writes the column total.  The extra workgroup (block-sum prefix, entry count,
+//           overflow verdict) rides in pass 2.
+constexpr int COLSCAN_CHUNK = 64;
+constexpr int COLSCAN_TWO_PASS_BLOCKS = 1024;
+__global__ __launch_bounds__(WG) void k_colscan_partial(Dims d, Scratch s, uint32_t* __restrict__ partial, int nch) {
+    const int col = blockIdx.x * WG + threadIdx.x, c = blockIdx.y, v = blockIdx.z;
+    if (col >= d.NST) return;
+    const int nb = (d.P + WG - 1) / WG;
+    const uint32_t* m = s.wg_hist + (size_t)v * splat_blocks(d.Pa) * d.NST + col;
+    uint32_t sum = 0;
+    const int r1 = min(nb, (c + 1) * COLSCAN_CHUNK);
+    for (int r = c * COLSCAN_CHUNK; r < r1; r++) sum += m[(size_t)r * d.NST];
+    partial[((size_t)v * nch + c) * d.NST + col] = sum;
+}
+__global__ __launch_bounds__(WG) void k_colscan_apply(Dims d, Scratch s, const uint32_t* __restrict__ partial, int nch) {
+    const int c = blockIdx.y, v = blockIdx.z;
+    if (c == nch) { if (blockIdx.x == 0) block_sums_prefix(d, s, v); return; }
+    const int col = blockIdx.x * WG + threadIdx.x;
+    if (col >= d.NST) return;
+    const int nb = (d.P + WG - 1) / WG;
+    uint32_t run = 0;
+    for (int k = 0; k < c; k++) run += partial[((size_t)v * nch + k) * d.NST + col];
+    uint32_t* m = s.wg_hist + (size_t)v * splat_blocks(d.Pa) * d.NST + col;
+    const int r1 = min(nb, (c + 1) * COLSCAN_CHUNK);
+    for (int r = c * COLSCAN_CHUNK; r < r1; r++) {
+        const uint32_t x = m[(size_t)r * d.NST];
+        m[(size_t)r * d.NST] = run;
+        run += x;
+    }
+    if (c == nch - 1) s.coarse_count[(size_t)v * d.NST + col] = run;
+}
+
 int launch_coarse_colscan(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.NST == 0 || d.VG == 0) return GS_OK;
-    hipLaunchKernelGGL(k_coarse_colscan, dim3((d.NST + WG / 64 - 1) / (WG / 64) + 1, d.VG), dim3(WG), 0, st, d, s);
+    const int nb = (d.P + WG - 1) / WG;
+    if (nb >= COLSCAN_TWO_PASS_BLOCKS && s.colscan_partial) {
+        const int nch = (nb + COLSCAN_CHUNK - 1) / COLSCAN_CHUNK;
+        hipLaunchKernelGGL(k_colscan_partial, dim3((d.NST + WG - 1) / WG, nch, d.VG), dim3(WG), 0, st, d, s, s.colscan_partial, nch);
+        hipLaunchKernelGGL(k_colscan_apply, dim3((d.NST + WG - 1) / WG, nch + 1, d.VG), dim3(WG), 0, st, d, s, (const uint32_t*)s.colscan_partial, nch);
+    } else {
+        hipLaunchKernelGGL(k_coarse_colscan, dim3((d.NST + WG / 64 - 1) / (WG / 64) + 1, d.VG), dim3(WG), 0, st, d, s);
+    }
     GS_HIP(hipGetLastError());
     return GS_OK;
+}
+size_t colscan_partial_words(int Pa, int NST, int V) {
+    const int nb = splat_blocks(Pa);
+    return nb >= COLSCAN_TWO_PASS_BLOCKS ? (size_t)V * ((nb + COLSCAN_CHUNK - 1) / COLSCAN_CHUNK) * NST : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
