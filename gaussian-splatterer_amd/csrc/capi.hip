@@ -133,7 +133,7 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
 }
 
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, color, finalT, ncontrib, scan_tmp, sgrads, shjac;
+    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, hmask, color, finalT, ncontrib, scan_tmp, sgrads, shjac;
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
     Scratch s{};
@@ -170,6 +170,7 @@ struct ScratchSet {
         GS_TRY(plist.ensure(v * Rcap * 4));
         GS_TRY(slist.ensure(v * Rcap * 4));
         GS_TRY(G.ensure(v * Rcap * G_STRIDE * 4));
+        GS_TRY(hmask.ensure(want_splat_grads ? v * hit_mask_words(Rcap, T) * 4 * sizeof(unsigned long long) : 8));
         GS_TRY(color.ensure(v * 3 * N * 4));
         GS_TRY(finalT.ensure(v * N * 4));
         GS_TRY(ncontrib.ensure(v * N * 4));
@@ -199,6 +200,7 @@ struct ScratchSet {
         s.point_list = plist.as<uint32_t>();
         s.slot_list = slist.as<uint32_t>();
         s.G = G.as<float>();
+        s.hit_masks = want_splat_grads ? hmask.as<unsigned long long>() : nullptr;  // only a trainer runs a backward behind the forward
         s.out_color = color.as<float>();
         s.final_T = finalT.as<float>();
         s.n_contrib = ncontrib.as<uint32_t>();
@@ -207,7 +209,7 @@ struct ScratchSet {
         return GS_OK;
     }
     void release() {
-        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &wghist, &colscan, &coarse_count, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &color,
+        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &wghist, &colscan, &coarse_count, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &hmask, &color,
                            &finalT, &ncontrib, &scan_tmp, &sgrads, &shjac })
             b->release();
     }
@@ -1120,8 +1122,8 @@ ImageLayout image_layout(int W, int H) {
     L.total = o;
     return L;
 }
-struct BinLayout { size_t clist, cdepth, ids, plist, slist, G, total; uint32_t Rcap; };
-BinLayout bin_layout(int R) {
+struct BinLayout { size_t clist, cdepth, ids, plist, slist, G, hmask, total; uint32_t Rcap; };
+BinLayout bin_layout(int R, int T) {
     BinLayout L; L.Rcap = (uint32_t)std::max(R, 1);
     size_t o = 0;
     L.clist = o; o = al(o + (size_t)L.Rcap * 16);
@@ -1130,6 +1132,7 @@ BinLayout bin_layout(int R) {
     L.plist = o; o = al(o + (size_t)L.Rcap * 4);
     L.slist = o; o = al(o + (size_t)L.Rcap * 4);
     L.G = o; o = al(o + (size_t)L.Rcap * G_STRIDE * 4);
+    L.hmask = o; o = al(o + hit_mask_words(L.Rcap, T) * 4 * sizeof(unsigned long long));  // (appended: the offsets above are part of the seam)
     L.total = o;
     return L;
 }
@@ -1156,6 +1159,7 @@ Scratch seam_scratch(char* geom, const GeomLayout& g, char* img, const ImageLayo
         s.point_list = reinterpret_cast<uint32_t*>(bin + b->plist);
         s.slot_list = reinterpret_cast<uint32_t*>(bin + b->slist);
         s.G = reinterpret_cast<float*>(bin + b->G);
+        s.hit_masks = reinterpret_cast<unsigned long long*>(bin + b->hmask);
     }
     return s;
 }
@@ -1177,7 +1181,7 @@ extern "C" int gs_raster_chunk_field(const char* chunk, const char* field, int P
         if (f == "final_T") { *offset = L.final_T; *bytes = N * 4; return GS_OK; }
         if (f == "n_contrib") { *offset = L.n_contrib; *bytes = N * 4; return GS_OK; }
     } else if (c == "binning") {
-        const BinLayout L = bin_layout(R);
+        const BinLayout L = bin_layout(R, image_layout(width, height).T);
         if (f == "point_list") { *offset = L.plist; *bytes = (size_t)R * 4; return GS_OK; }
         if (f == "point_list_slots") { *offset = L.slist; *bytes = (size_t)R * 4; return GS_OK; }
     }
@@ -1243,7 +1247,7 @@ extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_u
         GS_HIP(hipStreamSynchronize(st));
         R = (int)r32;
     }
-    const BinLayout bl = bin_layout(R);
+    const BinLayout bl = bin_layout(R, il.T);
     char* bin = binning_alloc(bl.total, binning_user);
     if (!bin) { set_error("binning allocator returned null"); return GS_ERR_OUT_OF_MEMORY; }
     s = seam_scratch(geom, gl, img, il, bin, &bl);
@@ -1281,7 +1285,7 @@ extern "C" int gs_rasterize_backward(int P, int D_in, int M, int R, const float*
     if (P == 0) return GS_OK;
     const GeomLayout gl = geom_layout(P, M, width, height);
     const ImageLayout il = image_layout(width, height);
-    const BinLayout bl = bin_layout(R);
+    const BinLayout bl = bin_layout(R, il.T);
     Scratch s = seam_scratch(geom_buffer, gl, image_buffer, il, binning_buffer, &bl);
     s.dL_dpix = dL_dpix;
     Dims d = make_dims(P, gl.Pa, D, M, width, height, 1, bl.Rcap, scale_modifier);

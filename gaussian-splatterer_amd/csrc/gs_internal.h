@@ -109,6 +109,8 @@ struct Scratch {
     uint32_t* point_list;      // [V][Rcap]  sorted splat ids
     uint32_t* slot_list;       // [V][Rcap]  sorted slots
     float* G;                  // [V][Rcap][G_STRIDE]
+    unsigned long long* hit_masks;  // [G][hit_mask_words(Rcap, T)][4]  per (tile, 64-entry sub-block, wave): which entries can reach the
+                               // wave's 8x8 block — the forward's ballots, reused by the backward (null: the backward tests again)
     float* splat_grads;        // [V][Pa][16]  per-(view,splat) backward records (trainer only)
     float* sh_jac;             // [G][Pa][12]  d colour / d view direction (9 used), written by the projection (trainer only, else null)
     const uint16_t* sh16;      // [3M][Pa] IEEE half read copy of the SH planes (trainer option "sh_fp16"), or null: read the fp32 planes
@@ -160,6 +162,9 @@ int launch_sh_to_half(int M, int P, int Pa, const float* planes, uint16_t* sh16,
 // Floats every plane-major buffer of a model is allocated with: the 11+3M parameter planes, one spare plane (the
 // gradient buffer's `var`), and padding so that the buffer divides into equal chunks for any rank count <= 64 (the
 // sharded update reduce-scatters gradients and all-gathers parameters with ONE chunking, gs_trainer_set_sharded_update).
+// 64-entry sub-blocks of all tile lists of a group, indexed (tile_start >> 6) + tile + sub_block (lists are not 64-aligned:
+// consecutive tiles never collide under this index)
+__host__ __device__ inline size_t hit_mask_words(uint32_t Rcap, int T) { return ((size_t)Rcap >> 6) + (size_t)T + 1; }
 inline size_t plane_buffer_floats(int M, int Pa) { return (size_t)(12 + 3 * M) * Pa + 64 * 64; }
 inline size_t shard_total_floats(int M, int Pa, int world) {
     const size_t n = (size_t)(12 + 3 * M) * Pa, q = (size_t)world * 64;

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
     const uint32_t start = s.tile_end[(size_t)v * d.T + tile] - (uint32_t)n;
     const uint32_t* __restrict__ plist = s.point_list + (size_t)v * d.Rcap + start;
     const GeomRec* __restrict__ geom = s.geom + (size_t)v * d.Pa;
+    unsigned long long* const hm = s.hit_masks ? s.hit_masks + ((size_t)v * hit_mask_words(d.Rcap, d.T) + (start >> 6) + (uint32_t)tile) * 4 : nullptr;
 
     // Branch-free per-lane blend.  Tw > 0 is the transmittance of a pixel that still blends; once the pixel saturates
     // (upstream's `done`) or for pixels outside the image Tw <= 0 holds MINUS the transmittance it stopped at, which
@@ -122,6 +123,8 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
                 hit = block_reaches(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
             }
             unsigned long long mask = __ballot(hit);
+            // the backward of the same camera walks the same lists against the same blocks: it reuses this ballot
+            if (hm && lane == 0) hm[(size_t)((base + sub) >> 6) * 4 + wave] = mask;
             while (mask) {
                 const int k = __builtin_ctzll(mask);
                 asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(k));  // one SALU instruction instead of the add / addc / and of mask &= mask - 1
@@ -354,6 +357,7 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
     const uint32_t* __restrict__ slist = s.slot_list + (size_t)g * d.Rcap + start;
     const GeomRec* __restrict__ geom = s.geom + (size_t)g * d.Pa;
     float* const Gout = s.G + (size_t)vin[0] * d.Rcap * G_STRIDE;
+    const unsigned long long* const hm = s.hit_masks ? s.hit_masks + ((size_t)g * hit_mask_words(d.Rcap, d.T) + (start >> 6) + (uint32_t)tile) * 4 : nullptr;
 
     // per-pixel state
     float T_final = 0.0f;
@@ -447,6 +451,8 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
         else part.x = __uint_as_float(idx0);
     }
 
+    // the forward's ballot of the first round walked (only rounds this wave still has entries to visit in are ever used)
+    unsigned long long ballot_next = (hm && rounds > 0) ? hm[(size_t)(rounds - 1) * 4 + wave] : 0ull;
     for (int r = rounds - 1; r >= 0; r--) {
         const int base = r * ROUND;
         const int cnt = min(ROUND, n - base);
@@ -461,15 +467,24 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
             else part.x = __uint_as_float(idx_next);
             if (r > 1) idx_next = (wave < 3 ? plist : slist)[entry_of(r - 2)];
         }
-        bool hit = false;
-        {
+        unsigned long long mask;
+        if (hm) {
+            // the forward of this camera tested the same 64 entries against the same block: its ballot (bit j = entry j of the
+            // sub-block), reversed into slot order and cut to the entries this wave still has to visit.  (The forward computed
+            // it for every sub-block in which a pixel of the wave was still alive, which includes the one holding the wave's last
+            // contributor and all before it.)
+            const int nvalid = max(0, min(cnt, (int)min((uint32_t)ROUND, wave_max_last - min(wave_max_last, (uint32_t)base))));
+            mask = nvalid > 0 ? (__builtin_bitreverse64(ballot_next) & (~0ull << (ROUND - nvalid))) : 0ull;
+            if (r > 0) ballot_next = hm[(size_t)(r - 1) * 4 + wave];  // requested a round ahead, like the staging
+        } else {
+            bool hit = false;
             const int j = ROUND - 1 - lane;
             if (j < cnt && (uint32_t)(base + j) < wave_max_last) {
                 const float4 a = st.A[lane];
                 hit = block_reaches(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * st.B[lane].x, st.C[lane].y, bxlo, bxhi, bylo, byhi);
             }
+            mask = __ballot(hit);
         }
-        unsigned long long mask = __ballot(hit);
 #ifdef GS_DIAG_NO_HITS  // timing experiments only (tools/build_variant.sh): the round skeleton without the hit loop
         mask = 0ull;
 #endif
