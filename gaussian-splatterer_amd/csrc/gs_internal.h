@@ -147,7 +147,7 @@ int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_loss_sum(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_backward(const Dims& d, const Scratch& s, const int* items, int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st);
 // Trainer form: loops the views, writes the averaged-gradient planes (incl. var) once.  fuse_pairs: the backward left ONE
-// gradient set per pair item (render_bwd_body<1, 2>): the per-splat chain runs once per item and `var` is written as zero.
+// gradient set per pair item (render_bwd<2>): the per-splat chain runs once per item and `var` is written as zero.
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad_planes, const int* items,
                               int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st);
 // Seam form: one view, reference-shaped AoS outputs with the reference's += / = discipline.

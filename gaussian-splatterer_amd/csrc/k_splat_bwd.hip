@@ -287,7 +287,7 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
 // accumulateGradients (src/Trainer.cu:51-76: var += |g_loc| / S, avg += g / S); the SH gradient is rebuilt as
 // basis(view direction) x dL_dRGB.  Every gradient plane is written exactly once per step.
 // n_fused_items > 0: the records are one per work item (the pair's summed gradient, at the item's first pass) and
-// `var`, which needs every pass's own location gradient, is written as zero (see render_bwd_body).
+// `var`, which needs every pass's own location gradient, is written as zero (see render_bwd in k_render.hip).
 template <int D>
 __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __restrict__ params, Scratch s, float samples,
                                                          const float4* __restrict__ rec_in, float* __restrict__ grad,

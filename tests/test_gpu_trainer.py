@@ -150,7 +150,7 @@ def test_step_sgd_matches_oracle(orc, P, M, n_cams, W, H):
 
 
 def test_fused_pair_switch(orc):
-    """gs_set_option("fuse_camera_passes", 0) makes gs_trainer_step take the per-pass form on every step: its gradient
+    """Option "fuse_camera_passes" = 0 (here through the defaults a new trainer copies) makes gs_trainer_step take the per-pass form on every step: its gradient
     buffer then equals gs_trainer_accumulate's bit for bit (var included), and the loss statistic is the same either way."""
     P, M, n_cams, W, H = 1500, 4, 3, 128, 96
     res = []
