@@ -295,7 +295,13 @@ int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // per-tile entry counts: one workgroup per super-tile walks its candidates once, LDS atomics only
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_tile_count(Dims d, Scratch s) {
+#ifndef GS_WIDE_BIN_MAX_GROUPS
+#define GS_WIDE_BIN_MAX_GROUPS 4  // launches of up to this many cameras use the 1024-thread form (tuning hook; 8 cameras: 256 is faster)
+#endif
+// NT threads per workgroup: 256, or 1024 for launches of up to four cameras (a super-tile's workgroup is then 16 waves wide: the few
+// hundred workgroups of such a launch do not fill the chip, and its time is the latency of one workgroup's candidate walk)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tile_count(Dims d, Scratch s) {
     __shared__ uint32_t cnt[STILE * STILE];
     const int st = blockIdx.x, v = blockIdx.y;
     const int stx = st % d.sgx, sty = st / d.sgx;
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(WG) void k_tile_count(Dims d, Scratch s) {
         // same-address LDS atomic per (candidate, tile) pair (which serialised: 27 M conflict cycles per launch at 1M splats).
         const int lane = threadIdx.x & 63;
         uint32_t mine = 0;  // lane tl < 16 accumulates the wave's count of tile tl
-        for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < nc; c0 += WG) {
+        for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < nc; c0 += NT) {
             const uint32_t c = c0 + lane;
             int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
             if (c < nc) {
@@ -338,7 +344,8 @@ __global__ __launch_bounds__(WG) void k_tile_count(Dims d, Scratch s) {
 
 int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.NST == 0 || d.VG == 0) return GS_OK;
-    hipLaunchKernelGGL(k_tile_count, dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+    if (d.VG <= GS_WIDE_BIN_MAX_GROUPS) hipLaunchKernelGGL(k_tile_count<1024>, dim3(d.NST, d.VG), dim3(1024), 0, st, d, s);
+    else hipLaunchKernelGGL(k_tile_count<WG>, dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -402,12 +409,15 @@ __global__ __launch_bounds__(WG) void k_tile_scan_order_scan(Dims d, Scratch s) 
 // the single-workgroup scan (14 us) disappears behind the scatter.  !SELF (images with more tiles than one workgroup
 // scans, or the "scan_single_max" test switch): tile_end comes from the separate scan launches in front.
 // ---------------------------------------------------------------------------------------------
-template <bool SELF>
-__global__ __launch_bounds__(WG) void k_tile_scatter(Dims d, Scratch s) {
+template <bool SELF, int NT>
+__global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
     __shared__ uint32_t cur[STILE * STILE], first[STILE * STILE], big[STILE * STILE];
-    __shared__ uint32_t rowsum[STILE][WG / 64];
+    __shared__ uint32_t rowsum[STILE][NT / 64];
     const int st = blockIdx.x, v = blockIdx.y;
-    if (SELF && st == d.NST) { tile_scan_order_body<true>(d, s, v); return; }
+    if (SELF && st == d.NST) {  // the scan + order workgroup is written for 256 threads: the other waves of a wide workgroup leave
+        if (threadIdx.x < WG) tile_scan_order_body<true>(d, s, v);
+        return;
+    }
     if (s.flags[v * 4 + 0] & 1u) return;
     const int stx = st % d.sgx, sty = st / d.sgx;
     const int tx0 = stx * STILE, ty0 = sty * STILE;
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(WG) void k_tile_scatter(Dims d, Scratch s) {
 #pragma unroll
         for (int r = 0; r < STILE; r++) rs[r] = min(d.T, (ty0 + r) * d.gx + tx0);
         uint32_t acc[STILE] = { 0, 0, 0, 0 };
-        for (int t = threadIdx.x; t < rs[STILE - 1]; t += WG) {
+        for (int t = threadIdx.x; t < rs[STILE - 1]; t += NT) {
             const uint32_t c = cnt[t];
 #pragma unroll
             for (int r = 0; r < STILE; r++) acc[r] += t < rs[r] ? c : 0u;
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(WG) void k_tile_scatter(Dims d, Scratch s) {
         if (tx < d.gx && ty < d.gy) {
             n = cnt[ty * d.gx + tx];
             if (SELF) {
-                f = rowsum[ly][0] + rowsum[ly][1] + rowsum[ly][2] + rowsum[ly][3];
+                for (int w = 0; w < NT / 64; w++) f += rowsum[ly][w];
                 for (int x = 0; x < lx; x++) f += cnt[ty * d.gx + tx0 + x];
             } else {
                 f = s.tile_end[(size_t)v * d.T + ty * d.gx + tx] - n;
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(WG) void k_tile_scatter(Dims d, Scratch s) {
     // (One thread per candidate looping over its own tiles took 0.70 ms per launch at 1M splats @2048^2, almost all of it
     // waiting for scattered 8-byte stores and same-address LDS atomics.)
     const int lane = threadIdx.x & 63;
-    for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < nc; c0 += WG) {
+    for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < nc; c0 += NT) {
         const uint32_t c = c0 + lane;
         uint4 e = make_uint4(0, 0, 0, 0);
         uint64_t dz = 0;
@@ -505,14 +515,15 @@ int launch_tile_scatter(const Dims& d, const Scratch& s, uint32_t* partials, hip
     // every scatter workgroup of the one-launch form reads the tile counts in front of its rows: T / 2 words on average,
     // 64 MB per camera at 2048 x 2048 (T = 16384) — beyond that the separate scan is cheaper than the repeated reads
     if (d.T <= g_scan_single_max && d.T <= 16384) {
-        hipLaunchKernelGGL(k_tile_scatter<true>, dim3(d.NST + 1, d.VG), dim3(WG), 0, st, d, s);
+        if (d.VG <= GS_WIDE_BIN_MAX_GROUPS) hipLaunchKernelGGL((k_tile_scatter<true, 1024>), dim3(d.NST + 1, d.VG), dim3(1024), 0, st, d, s);
+        else hipLaunchKernelGGL((k_tile_scatter<true, WG>), dim3(d.NST + 1, d.VG), dim3(WG), 0, st, d, s);
     } else if (d.T <= g_scan_single_max) {
         hipLaunchKernelGGL(k_tile_scan_order_scan, dim3(d.VG), dim3(WG), 0, st, d, s);
-        hipLaunchKernelGGL(k_tile_scatter<false>, dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+        hipLaunchKernelGGL((k_tile_scatter<false, WG>), dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
     } else {
         GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.VG, partials, st));
         hipLaunchKernelGGL(k_tile_scan_order_noscan, dim3(d.VG), dim3(WG), 0, st, d, s);
-        hipLaunchKernelGGL(k_tile_scatter<false>, dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+        hipLaunchKernelGGL((k_tile_scatter<false, WG>), dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
     }
     GS_HIP(hipGetLastError());
     return GS_OK;
