@@ -232,15 +232,69 @@ template <int D> __device__ inline void sh_basis(float X, float Y, float Z, floa
     }
 }
 
+// accumulateGradients (src/Trainer.cu:51-76) for one splat: var += |g_loc| / S, avg += g / S over the records of its passes
+// in the reference's order; the SH gradient is rebuilt as basis(view direction) x dL_dRGB.
+template <int D> struct GradAcc {
+    static constexpr int NC = (D + 1) * (D + 1);
+    float var = 0.0f, aLoc[3] = { 0, 0, 0 }, aScale[3] = { 0, 0, 0 }, aRot[4] = { 0, 0, 0, 0 }, aOpac = 0.0f, aSh[NC][3];
+    __device__ GradAcc() {
+#pragma unroll
+        for (int k = 0; k < NC; k++) aSh[k][0] = aSh[k][1] = aSh[k][2] = 0.0f;
+    }
+    // one record: mean(3) scale(3) rot(4) opacity(1) dL_dRGB(3); (mx, my, mz) the splat, cp the pass's camera position
+    __device__ void add(const float4& r0, const float4& r1, const float4& r2, const float4& r3, float samples, float mx, float my, float mz,
+                        const float* cp) {
+        const float gm[3] = { r0.x, r0.y, r0.z }, gs3[3] = { r0.w, r1.x, r1.y }, gr[4] = { r1.z, r1.w, r2.x, r2.y };
+        const float dRGB[3] = { r2.w, r3.x, r3.y };
+        var += sqrtf((gm[0] * gm[0]) + (gm[1] * gm[1]) + (gm[2] * gm[2])) / samples;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { aLoc[c] += gm[c] / samples; aScale[c] += gs3[c] / samples; }
+        aOpac += r2.z / samples;
+#pragma unroll
+        for (int c = 0; c < 4; c++) aRot[c] += gr[c] / samples;
+        // A pass in which the splat is culled (or its colour gradient is exactly zero) adds +0 to every SH sum: skip it,
+        // as upstream's radii > 0 guard does — the basis of a splat AT the camera position (len = 0) or with a
+        // non-finite mean is NaN, and NaN * 0 would poison the SH planes for good.
+        if (dRGB[0] != 0.0f || dRGB[1] != 0.0f || dRGB[2] != 0.0f) {
+            const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
+            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+            float basis[NC];
+            sh_basis<D>(ox / len, oy / len, oz / len, basis);
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) aSh[k][c] += (basis[k] * dRGB[c]) / samples;
+        }
+    }
+    // every gradient plane of splat i, written exactly once per step
+    __device__ void store(float* __restrict__ grad, const Planes& pl, size_t st, int i, int M, bool zero_var) const {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { grad[pl.loc(c) * st + i] = aLoc[c]; grad[pl.scale(c) * st + i] = aScale[c]; }
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = aSh[k][c];
+        for (int k = NC; k < M; k++)
+            for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = 0.0f;
+        grad[pl.opac() * st + i] = aOpac;
+#pragma unroll
+        for (int c = 0; c < 4; c++) grad[pl.rot(c) * st + i] = aRot[c];
+        grad[pl.var() * st + i] = zero_var ? 0.0f : var;
+    }
+};
+
 // Trainer stage 1: one thread per (pass, splat) — fully parallel.  Sums the splat's gradient rows of that pass and
 // runs the per-splat chain; the result is ONE 64-byte record per (pass, splat):
 //   mean(3) scale(3) rot(4) opacity(1) dL_dRGB(3, clamp-masked) pad(2).   Culled splats write zeros.
 // (Fusing the two passes of a camera into one thread was measured slower: 175 VGPRs, 2 waves/SIMD.)
 // Work items are the backward's {group, pass a, pass b}.  With fused pairs (render_bwd<2>) there is one
 // gradient set per item, in pass a's slice: blockIdx.y then enumerates items and the record is pass a's.
-template <int D>
+// SINGLE: the step has exactly one record per splat (one work item: the per-GPU load of an 8-GPU run) — the record never leaves
+// the registers: accumulateGradients is applied here and the gradient planes are written, no second launch.
+template <int D, bool SINGLE>
 __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __restrict__ params, Scratch s, float4* __restrict__ rec_out,
-                                                       const int* __restrict__ items, int n_pairs, int fused) {
+                                                       const int* __restrict__ items, int n_pairs, int fused, float samples,
+                                                       float* __restrict__ grad) {
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
     // blockIdx.y enumerates passes: the two passes of every pair item first, then the single items
@@ -257,7 +311,8 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     const uint32_t tiles = s.tiles_touched[(size_t)g * st + i];
     if ((s.flags[g * 4 + 0] & 1u) || tiles == 0) {  // culled: the reference's nine buffers stay zero
         const float4 z = make_float4(0, 0, 0, 0);
-        out[0] = z; out[1] = z; out[2] = z; out[3] = z;
+        if constexpr (SINGLE) { GradAcc<D> acc; acc.store(grad, pl, st, i, d.M, fused != 0); }
+        else { out[0] = z; out[1] = z; out[2] = z; out[3] = z; }
         return;
     }
     float mean[3], sc[3], q[4];
@@ -277,10 +332,15 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     const float jv[9] = { j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, j2.x };
     auto jac_at = [&](int ch, float, float, float, float& dx_, float& dy_, float& dz_) { dx_ = jv[3 * ch]; dy_ = jv[3 * ch + 1]; dz_ = jv[3 * ch + 2]; };
     splat_backward_core<D, false>(s.gviews[g], d.W, d.H, mean, sc, q, jac_at, __float_as_uint(j2.y), sum, sum[3], sum[4], sum[5], sum[6], sum[7], o, dRGB);
-    out[0] = make_float4(o.mean[0], o.mean[1], o.mean[2], o.scale[0]);
-    out[1] = make_float4(o.scale[1], o.scale[2], o.rot[0], o.rot[1]);
-    out[2] = make_float4(o.rot[2], o.rot[3], sum[8], dRGB[0]);
-    out[3] = make_float4(dRGB[1], dRGB[2], 0.0f, 0.0f);
+    const float4 r0 = make_float4(o.mean[0], o.mean[1], o.mean[2], o.scale[0]), r1 = make_float4(o.scale[1], o.scale[2], o.rot[0], o.rot[1]),
+                 r2 = make_float4(o.rot[2], o.rot[3], sum[8], dRGB[0]), r3 = make_float4(dRGB[1], dRGB[2], 0.0f, 0.0f);
+    if constexpr (SINGLE) {
+        GradAcc<D> acc;
+        acc.add(r0, r1, r2, r3, samples, mean[0], mean[1], mean[2], s.views[v].campos);
+        acc.store(grad, pl, st, i, d.M, fused != 0);
+    } else {
+        out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3;
+    }
 }
 
 // Trainer stage 2: one thread per splat walks the views in the reference's order and applies
@@ -292,55 +352,19 @@ template <int D>
 __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __restrict__ params, Scratch s, float samples,
                                                          const float4* __restrict__ rec_in, float* __restrict__ grad,
                                                          const int* __restrict__ items, int n_fused_items) {
-    constexpr int NC = (D + 1) * (D + 1);
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
     const float mx = params[pl.loc(0) * st + i], my = params[pl.loc(1) * st + i], mz = params[pl.loc(2) * st + i];
-    float var = 0.0f, aLoc[3] = { 0, 0, 0 }, aScale[3] = { 0, 0, 0 }, aRot[4] = { 0, 0, 0, 0 }, aOpac = 0.0f, aSh[NC][3];
-#pragma unroll
-    for (int k = 0; k < NC; k++) aSh[k][0] = aSh[k][1] = aSh[k][2] = 0.0f;
+    GradAcc<D> acc;
     const int n_rec = n_fused_items > 0 ? n_fused_items : d.V;
     for (int k = 0; k < n_rec; k++) {
         const int v = n_fused_items > 0 ? items[3 * k + 1] : k;
         const float4* r = rec_in + ((size_t)v * st + i) * 4;
-        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-        const float gm[3] = { r0.x, r0.y, r0.z }, gs3[3] = { r0.w, r1.x, r1.y }, gr[4] = { r1.z, r1.w, r2.x, r2.y };
-        const float dRGB[3] = { r2.w, r3.x, r3.y };
-        var += sqrtf((gm[0] * gm[0]) + (gm[1] * gm[1]) + (gm[2] * gm[2])) / samples;
-#pragma unroll
-        for (int c = 0; c < 3; c++) { aLoc[c] += gm[c] / samples; aScale[c] += gs3[c] / samples; }
-        aOpac += r2.z / samples;
-#pragma unroll
-        for (int c = 0; c < 4; c++) aRot[c] += gr[c] / samples;
-        // A pass in which the splat is culled (or its colour gradient is exactly zero) adds +0 to every SH sum: skip it,
-        // as upstream's radii > 0 guard does — the basis of a splat AT the camera position (len = 0) or with a
-        // non-finite mean is NaN, and NaN * 0 would poison the SH planes for good.
-        if (dRGB[0] != 0.0f || dRGB[1] != 0.0f || dRGB[2] != 0.0f) {
-            const float* cp = s.views[v].campos;
-            const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
-            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
-            float basis[NC];
-            sh_basis<D>(ox / len, oy / len, oz / len, basis);
-#pragma unroll
-            for (int k = 0; k < NC; k++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) aSh[k][c] += (basis[k] * dRGB[c]) / samples;
-        }
+        acc.add(r[0], r[1], r[2], r[3], samples, mx, my, mz, s.views[v].campos);
     }
-#pragma unroll
-    for (int c = 0; c < 3; c++) { grad[pl.loc(c) * st + i] = aLoc[c]; grad[pl.scale(c) * st + i] = aScale[c]; }
-#pragma unroll
-    for (int k = 0; k < NC; k++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = aSh[k][c];
-    for (int k = NC; k < d.M; k++)
-        for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = 0.0f;
-    grad[pl.opac() * st + i] = aOpac;
-#pragma unroll
-    for (int c = 0; c < 4; c++) grad[pl.rot(c) * st + i] = aRot[c];
-    grad[pl.var() * st + i] = n_fused_items > 0 ? 0.0f : var;
+    acc.store(grad, pl, st, i, d.M, n_fused_items > 0);
 }
 
 template <int D>
@@ -350,7 +374,11 @@ static void launch_splat_avg_d(const Dims& d, const float* params, const Scratch
     float4* rec = reinterpret_cast<float4*>(s.splat_grads);
     fuse = fuse && n2 > 0;
     const int ny = fuse ? n2 + n1 : 2 * n2 + n1;
-    if (ny > 0) hipLaunchKernelGGL(k_splat_bwd_view<D>, dim3(bx, ny), dim3(WG), 0, stream, d, params, s, rec, items, n2, fuse ? 1 : 0);
+    if (ny == 1) {  // one record per splat: chain and accumulateGradients in one launch
+        hipLaunchKernelGGL((k_splat_bwd_view<D, true>), dim3(bx, 1), dim3(WG), 0, stream, d, params, s, rec, items, n2, fuse ? 1 : 0, samples, grad);
+        return;
+    }
+    if (ny > 0) hipLaunchKernelGGL((k_splat_bwd_view<D, false>), dim3(bx, ny), dim3(WG), 0, stream, d, params, s, rec, items, n2, fuse ? 1 : 0, samples, grad);
     hipLaunchKernelGGL(k_splat_bwd_reduce<D>, dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
                        fuse ? n2 + n1 : 0);
 }
