@@ -1178,6 +1178,7 @@ extern "C" int gs_raster_chunk_field(const char* chunk, const char* field, int P
         const ImageLayout L = image_layout(width, height);
         const size_t N = (size_t)width * height;
         if (f == "ranges") { *offset = L.ranges; *bytes = (size_t)L.T * 8; return GS_OK; }
+        if (f == "tile_order") { *offset = L.tile_order; *bytes = (size_t)L.T * 4; return GS_OK; }
         if (f == "final_T") { *offset = L.final_T; *bytes = N * 4; return GS_OK; }
         if (f == "n_contrib") { *offset = L.n_contrib; *bytes = N * 4; return GS_OK; }
     } else if (c == "binning") {

@@ -361,19 +361,41 @@ constexpr int ORDER_BINS = 256;
 __device__ inline int order_bin(uint32_t c) { return c < 1024u ? (int)(c >> 3) : min(ORDER_BINS - 1, 128 + (int)((c - 1024u) >> 6)); }
 constexpr int ORDER_LONG_BIN = 128 + (SORT_SMALL_CAP - 1024) / 64;
 // One workgroup per camera: tile_end = inclusive scan of tile_count (SCAN), tile_order, the longest list (flags[1]) and
-// the number of long tiles (flags[3]).
+// the length of the order's prefix that holds all long tiles (flags[3]).
+//
+// XCD affinity.  Workgroups are dealt round-robin over the chip's eight XCDs (position p of the order runs on XCD p % 8 —
+// observed, not promised: it only ever matters for speed), and each XCD has its own L2.  With one global longest-first list the
+// tiles that share a splat's record run on all eight XCDs and half of the record gathers of the render kernels miss L2.  So the
+// 64x64-px super-tiles are dealt to XC = 8 classes (a hash of the super-tile's coordinates: every class is a fair sample of the
+// image), every class gets its OWN longest-first list, and the lists are interleaved: position 8 k + x holds the k-th longest tile
+// of class x (lists of unequal length are compacted, which only disturbs the tail).  An XCD then only ever touches the records
+// of an eighth of the image, and the launch keeps its longest-first balance inside every XCD.
+#ifndef GS_XCD_TILE_CLASSES
+#define GS_XCD_TILE_CLASSES 8  // 1: one global longest-first list (tuning hook, tools/build_variant.sh)
+#endif
+#ifndef GS_XCD_BLOCK_W
+#define GS_XCD_BLOCK_W STILE  // the blocks of tiles dealt to the classes, in tiles
+#define GS_XCD_BLOCK_H STILE
+#endif
+constexpr int ORDER_CLASSES = GS_XCD_TILE_CLASSES;
+__device__ inline int order_class(const Dims& d, int t) {
+    if (ORDER_CLASSES == 1) return 0;
+    const int bx = (t % d.gx) / GS_XCD_BLOCK_W, by = (t / d.gx) / GS_XCD_BLOCK_H;
+    return (bx + 3 * by) % ORDER_CLASSES;
+}
 template <bool SCAN>
 __device__ inline void tile_scan_order_body(const Dims& d, const Scratch& s, int v) {
-    __shared__ uint32_t hist[ORDER_BINS], start[ORDER_BINS];
+    __shared__ uint32_t hist[ORDER_CLASSES][ORDER_BINS], start[ORDER_CLASSES][ORDER_BINS], csize[ORDER_CLASSES], clong[ORDER_CLASSES];
     const uint32_t* cnt = s.tile_count + (size_t)v * d.T;
     uint32_t* order = s.tile_order + (size_t)v * d.T;
-    hist[threadIdx.x] = 0;
+#pragma unroll
+    for (int x = 0; x < ORDER_CLASSES; x++) hist[x][threadIdx.x] = 0;
     __syncthreads();
     uint32_t longest = 0;
     for (int t = threadIdx.x; t < d.T; t += WG) {
         const uint32_t c = cnt[t];
         longest = max(longest, c);
-        atomicAdd(&hist[ORDER_BINS - 1 - order_bin(c)], 1u);  // bin 0 = longest
+        atomicAdd(&hist[order_class(d, t)][ORDER_BINS - 1 - order_bin(c)], 1u);  // bin 0 = longest
     }
     // statistic: the longest tile list of the group (a global atomicMax per TILE cost 210 us: same-address atomics serialise)
 #pragma unroll
@@ -384,13 +406,29 @@ __device__ inline void tile_scan_order_body(const Dims& d, const Scratch& s, int
     if (threadIdx.x == 0) s.flags[v * 4 + 1] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
     if (SCAN) scan_single(cnt, s.tile_end + (size_t)v * d.T, d.T);  // tile_end: the same workgroup has the counts in cache
     __syncthreads();
-    const uint32_t h = hist[threadIdx.x];
-    const uint32_t ex = block_excl_scan(h, nullptr);
-    start[threadIdx.x] = ex;
-    // the long tiles are the first entries of the order: publish how many there are for k_tile_sort_long
-    if (threadIdx.x == ORDER_BINS - ORDER_LONG_BIN) s.flags[v * 4 + 3] = ex;
+    for (int x = 0; x < ORDER_CLASSES; x++) {  // every class: exclusive scan of its bins, longest first
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(hist[x][threadIdx.x], &total);
+        start[x][threadIdx.x] = ex;
+        if (threadIdx.x == ORDER_BINS - ORDER_LONG_BIN) clong[x] = ex;  // long tiles (k_tile_sort_long's) of the class: its first clong[x]
+        if (threadIdx.x == 0) csize[x] = total;
+    }
     __syncthreads();
-    for (int t = threadIdx.x; t < d.T; t += WG) order[atomicAdd(&start[ORDER_BINS - 1 - order_bin(cnt[t])], 1u)] = (uint32_t)t;
+    if (threadIdx.x == 0) {
+        // all long tiles sit in the first ORDER_CLASSES * max(clong) positions of the interleaved order: k_tile_sort_long walks
+        // that prefix and skips what is not long
+        uint32_t m = 0;
+        for (int x = 0; x < ORDER_CLASSES; x++) m = max(m, clong[x]);
+        s.flags[v * 4 + 3] = min((uint32_t)d.T, (uint32_t)ORDER_CLASSES * m);
+    }
+    for (int t = threadIdx.x; t < d.T; t += WG) {
+        const int x = order_class(d, t);
+        const uint32_t k = atomicAdd(&start[x][ORDER_BINS - 1 - order_bin(cnt[t])], 1u);  // rank in the class's longest-first list
+        uint32_t pos = 0;  // tiles in front of (k, x) in the interleaved order: ranks < k of every class, rank k of the classes before x
+#pragma unroll
+        for (int y = 0; y < ORDER_CLASSES; y++) pos += min(k, csize[y]) + ((y < x && csize[y] > k) ? 1u : 0u);
+        order[pos] = (uint32_t)t;
+    }
 }
 __global__ __launch_bounds__(WG) void k_tile_scan_order_noscan(Dims d, Scratch s) { tile_scan_order_body<false>(d, s, blockIdx.x); }
 __global__ __launch_bounds__(WG) void k_tile_scan_order_scan(Dims d, Scratch s) { tile_scan_order_body<true>(d, s, blockIdx.x); }
@@ -692,7 +730,7 @@ __global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
     sort_tile<WG, SORT_SMALL_CAP, 256>(d, s, v, tile, n, sk, sid);
 }
 
-// Lists of SORT_SMALL_CAP entries and more: the tile order starts with them (flags[3] = how many).  A few persistent
+// Lists of SORT_SMALL_CAP entries and more: they all sit in the first flags[3] positions of the tile order.  A few persistent
 // 1024-thread workgroups per camera walk that prefix with SORT_LDS_CAP (8192) entries of LDS each — 96 KB, one
 // workgroup per CU, which is why short lists do not go through here; only lists beyond that spill to global scratch.
 constexpr int LONG_NT = 1024;
@@ -704,7 +742,8 @@ __global__ __launch_bounds__(LONG_NT) void k_tile_sort_long(Dims d, Scratch s) {
     const uint32_t n_long = s.flags[v * 4 + 3];
     for (uint32_t idx = blockIdx.x; idx < n_long; idx += gridDim.x) {
         const int tile = (int)s.tile_order[(size_t)v * d.T + idx];
-        const uint32_t n = s.tile_count[(size_t)v * d.T + tile];  // >= SORT_SMALL_CAP by construction of the order
+        const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
+        if (n < (uint32_t)SORT_SMALL_CAP) continue;  // the prefix interleaves the classes' lists: not every tile in it is long
         sort_tile<LONG_NT, SORT_LDS_CAP, 1024>(d, s, v, tile, n, sk, sid);
         __syncthreads();  // LDS is reused by the next tile
     }

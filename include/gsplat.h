@@ -310,7 +310,8 @@ int gs_rasterize_backward(int P, int D, int M, int R, const float* background, i
  * "binning" or "image".  Geometry fields: "record" (64-byte per-splat records: means2D, conic,
  * opacity, rgb, cull box, depth, radius, clamp flags, tile rect), "tiles_touched", "point_offsets".
  * Binning fields: "point_list" (u32[R], the sorted splat ids), "point_list_slots".
- * Image fields: "ranges" (u32x2 per tile), "final_T", "n_contrib". */
+ * Image fields: "ranges" (u32x2 per tile), "final_T", "n_contrib", "tile_order" (u32[T]: the order
+ * the per-tile workgroups take the tiles in — speed only). */
 int gs_raster_chunk_field(const char* chunk, const char* field, int P, int width, int height, int R,
                           size_t* offset, size_t* bytes);
 

@@ -348,3 +348,42 @@ def test_rigid_motion_invariance_on_the_gpu():
     assert a.std() > 0.01 and abs(Ra - Rb) <= 0.01 * Ra     # a few splats may gain or lose a tile through fp32 rounding of the radius
     diff = np.abs(a - b)
     assert np.quantile(diff, 0.999) < 1e-4 and diff.max() < 0.05
+
+
+def _order_bin(c):
+    """k_binning.hip order_bin: 8-wide bins below 1024 entries, 64-wide from there."""
+    return np.where(c < 1024, c >> 3, np.minimum(255, 128 + ((c - 1024) >> 6)))
+
+
+@pytest.mark.parametrize("W,H,P", [(800, 800, 60000), (250, 130, 3000), (32, 32, 6000)])
+def test_tile_order_is_longest_first_inside_each_xcd_class(orc, W, H, P):
+    """The order workgroups take the tiles in (image chunk field "tile_order"): a permutation of the tiles; the tiles
+    of one class (64x64-px blocks dealt to 8 classes by (bx + 3 by) % 8) appear longest list first; the classes' lists are
+    interleaved, so position 8 k + x holds the k-th tile of class x for as long as every class has a k-th tile.  Only speed
+    rests on the order — results never do — which is why it has its own test."""
+    s = util.gs.synth.random_splats(P, 1, 31)
+    if W == 32:
+        s["loc"] = (s["loc"] * 0.05).astype(np.float32)  # lists beyond 2048 entries: the long-list prefix
+    cams = util.gs.camera.get_cameras(1, 10.0, 20.0)
+    vp = view_parts(util.gs.camera.train_views(cams, W, H)[0])
+    sr = SeamRaster()
+    sr.forward(s, 0, 1, vp, W, H)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+    order = sr.field("image", "tile_order", np.uint32).astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(T))
+    ranges = sr.field("image", "ranges", np.uint32).reshape(T, 2).astype(np.int64)
+    bins = _order_bin(ranges[:, 1] - ranges[:, 0])
+    cls = (((order % gx) // 4) + 3 * ((order // gx) // 4)) % 8
+    sizes = np.bincount(cls, minlength=8)
+    for x in range(8):
+        b = bins[order[cls == x]]
+        assert np.all(b[:-1] >= b[1:]), x
+    full = 8 * int(sizes.min())
+    assert np.array_equal(cls[:full], np.arange(full) % 8)
+    # compaction of the tail: rank k of class x sits behind all ranks < k and behind rank k of the classes before x
+    rank = np.zeros(T, np.int64)
+    for x in range(8):
+        rank[cls == x] = np.arange(sizes[x])
+    key = rank * 8 + cls
+    assert np.all(key[:-1] < key[1:])

@@ -11,7 +11,7 @@ args=${BENCH_ARGS:---steps 2 --warmup 1 --no-cpu-baseline}
 i=0
 for grp in "$@"; do
     i=$((i + 1))
-    rocprofv3 --pmc $grp -d "$out/p$i" -o p --output-format csv -- python3 bench.py $args > "$out/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/p$i.log"; }
+    timeout -k 10 400 rocprofv3 --pmc $grp -d "$out/p$i" -o p --output-format csv -- python3 bench.py $args > "$out/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/p$i.log"; }
 done
 python3 - "$out" <<'EOF'
 import csv, glob, sys, collections, json

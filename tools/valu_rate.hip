@@ -10,7 +10,8 @@
 #define REP64(x) REP4(REP16(x))
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long long* cyc) {
+__global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long long* cyc, int active) {
+    if ((int)(threadIdx.x & 63) >= active) return;  // EXEC = the low `active` lanes for the whole kernel (partial-EXEC issue cost)
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const float b = 1.0001f, c = 0.5f;
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -107,16 +108,16 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
-template <int KIND> void run(const char* name, int insts_per_iter, int waves_per_simd) {
+template <int KIND> void run(const char* name, int insts_per_iter, int waves_per_simd, int active = 64) {
     const int iters = 2000;
     const int blocks = 256 * waves_per_simd;  // 256 CUs x (waves_per_simd blocks of 4 waves)
     float* out; unsigned long long* cyc;
     hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&cyc, 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<KIND><<<blocks, 256>>>(out, 10, cyc);
+    k<KIND><<<blocks, 256>>>(out, 10, cyc, active);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<KIND><<<blocks, 256>>>(out, iters, cyc);
+    k<KIND><<<blocks, 256>>>(out, iters, cyc, active);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
@@ -146,6 +147,11 @@ int main() {
         run<15>("dpp add bank-masked, 8 indep", 64, w);
         run<16>("plain add, 8 independent", 64, w);
         run<17>("mov_dpp + plain add (counts both)", 64, w);
+        run<0>("v_fma_f32, EXEC = lanes 0-31", 64, w, 32);
+        run<0>("v_fma_f32, EXEC = lanes 0-15", 64, w, 16);
+        run<3>("v_exp_f32, EXEC = lanes 0-31", 64, w, 32);
+        run<5>("v_cndmask, EXEC = lanes 0-31", 64, w, 32);
+        run<14>("dpp add,   EXEC = lanes 0-31", 64, w, 32);
     }
     return 0;
 }
