@@ -77,7 +77,7 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
     d.P = P; d.Pa = Pa; d.D = D; d.M = M; d.W = W; d.H = H; d.N = W * H;
     d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
     d.sgx = (d.gx + STILE - 1) / STILE; d.sgy = (d.gy + STILE - 1) / STILE; d.NST = d.sgx * d.sgy;
-    d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = cull < 0 ? g_defaults.cull : cull; d.long_sort = 1;
+    d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = cull < 0 ? g_defaults.cull : cull; d.long_sort = 1; d.mid_sort = 1; d.small_first = 0; d.mid_grid = 0;
     return d;
 }
 
@@ -143,6 +143,7 @@ struct ScratchSet {
         Pa = std::max(64, round_up(P, 64));
         V = V_; N = W * H;
         T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+        if (Rcap_ >= (1u << 31) - 64u) { set_error("binning arena: %u entries per view exceed the 2^31 the index arithmetic holds", Rcap_); return GS_ERR_OUT_OF_MEMORY; }
         Rcap = (std::max<uint32_t>(Rcap_, 1024) + 63u) & ~63u;  // multiple of 64: every view's slice of G (36-byte rows) stays 8-byte aligned for the sort keys
         const size_t v = (size_t)std::max(V, 1);
         GS_TRY(views.ensure(view_block_bytes((int)v)));
@@ -154,7 +155,7 @@ struct ScratchSet {
             NST = ((gx + STILE - 1) / STILE) * ((gy + STILE - 1) / STILE);
         }
         // flags | loss totals (every word is rewritten by the kernels of a step: no memset)
-        zero_bytes = v * 16 + v * 4;
+        zero_bytes = v * 16 + v * 4 + v * 8;  // flags[4] per group | loss totals | sort marks[2] per group
         GS_TRY(zero_block.ensure(zero_bytes));
         GS_TRY(wghist.ensure(v * splat_blocks(Pa) * NST * 4));
         GS_TRY(coarse_count.ensure(v * NST * 4));
@@ -189,6 +190,7 @@ struct ScratchSet {
         s.colscan_partial = colscan_partial_words(Pa, NST, (int)v) ? colscan.as<uint32_t>() : nullptr;
         s.flags = zero_block.as<uint32_t>();
         s.loss_total = reinterpret_cast<float*>(s.flags + v * 4);
+        s.sort_marks = s.flags + v * 5;
         s.loss = tloss.as<float>();
         s.tile_order = torder.as<uint32_t>();
         s.coarse_end = coarse_end.as<uint32_t>();
@@ -698,11 +700,29 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
         // device writes it after the early flag copy, which therefore carries the previous step's value): with a quarter of
         // headroom the launch is skipped; a list that outgrows the hint anyway is sorted by k_tile_build_sort's global-scratch
         // path — slower, never wrong.
-        if (t->opt.long_sort >= 0) d.long_sort = t->opt.long_sort;
+        // The same holds one class down: k_tile_sort_mid takes the lists of SORT_TINY_CAP entries and more.
+        if (t->opt.long_sort >= 0) d.long_sort = d.mid_sort = t->opt.long_sort;
         else if (t->steps_on_these_lists >= 2) {
             uint32_t longest = 0;
             for (int g = 0; g < t->VG; g++) longest = std::max(longest, t->h_flags[g * 4 + 1]);
             d.long_sort = longest >= (uint32_t)(SORT_SMALL_CAP - SORT_SMALL_CAP / 4) ? 1 : 0;
+            d.mid_sort = longest >= (uint32_t)(SORT_TINY_CAP - SORT_TINY_CAP / 4) ? 1 : 0;
+            // Grids by the same kind of hint (flags[3]: where the lists of SORT_TINY_CAP entries and more end in the tile order, and
+            // where the first shorter one sits, two steps ago): the short-list sorter is not launched over a head that holds no short
+            // list (a dense scene: 65k workgroups that would look at a tile and leave, 45 us), k_tile_sort_mid gets a workgroup
+            // per tile of its head and no more.  Stale hints cost speed only: k_tile_sort_mid walks on in strides past its grid
+            // and sorts the short lists in front of small_first itself.
+            if (d.mid_sort) {
+                const uint32_t unit = order_hint_unit(d.T);
+                uint32_t mid_end = 0, small_start = 0xFFFFFFFFu;
+                for (int g = 0; g < t->VG; g++) {
+                    mid_end = std::max(mid_end, (t->h_flags[g * 4 + 3] >> 16) * unit);
+                    small_start = std::min(small_start, (t->h_flags[g * 4 + 3] & 0xFFFFu) * unit);
+                }
+                const uint32_t keep = std::max(64u, small_start / 8);
+                d.small_first = small_start > keep ? (int)std::min((uint32_t)d.T, small_start - keep) : 0;
+                d.mid_grid = (int)std::min((uint32_t)d.T, mid_end + std::max(64u, mid_end / 8));
+            }
         }
         Scratch s = t->train.s;
         s.truth = t->truth.as<uint32_t>();
@@ -1144,6 +1164,7 @@ Scratch seam_scratch(char* geom, const GeomLayout& g, char* img, const ImageLayo
     s.point_offsets = reinterpret_cast<uint32_t*>(geom + g.offsets);
     s.block_sums = reinterpret_cast<uint32_t*>(geom + g.scan_tmp);
     s.flags = reinterpret_cast<uint32_t*>(geom + g.flags);
+    s.sort_marks = s.flags + 5;  // the block holds 8 words: flags[4], a loss total, these two
     s.coarse_count = reinterpret_cast<uint32_t*>(img + im.coarse_count);
     s.wg_hist = reinterpret_cast<uint32_t*>(geom + g.wg_hist);
     s.coarse_end = reinterpret_cast<uint32_t*>(img + im.coarse_end);
@@ -1246,6 +1267,7 @@ extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_u
         uint32_t r32 = 0;
         GS_HIP(hipMemcpyAsync(&r32, s.flags + 2, 4, hipMemcpyDeviceToHost, st));
         GS_HIP(hipStreamSynchronize(st));
+        if (r32 >= (1u << 31) - 64u) { set_error("gs_rasterize_forward: %u (splat, tile) entries exceed what the int num_rendered of the interface holds", r32); return GS_ERR_OUT_OF_MEMORY; }
         R = (int)r32;
     }
     const BinLayout bl = bin_layout(R, il.T);

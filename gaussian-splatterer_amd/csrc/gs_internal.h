@@ -35,7 +35,14 @@ constexpr int WG = 256;            // workgroup = 4 wave64
 constexpr int G_STRIDE = 9;        // floats per (splat, tile, pass) gradient row: 36 bytes, three 12-byte groups (no padding:
                                    // the rows are the step's largest HBM stream, written once and read once)
 struct alignas(4) Row3 { float a, b, c; };  // one 12-byte group of a gradient row
-constexpr int SORT_SMALL_CAP = 2048;  // lists shorter than this: one 256-thread workgroup per tile, 24 KB LDS
+#ifndef GS_SORT_TILE_NT
+#define GS_SORT_TILE_NT 128              // threads and LDS capacity of the short-list sort (tuning hooks, tools/build_variant.sh)
+#define GS_SORT_TILE_CAP 512
+#endif
+constexpr int SORT_TINY_CAP = GS_SORT_TILE_CAP;  // lists shorter than this: one 128-thread workgroup per tile, 7 KB LDS (22 tiles in flight per CU)
+constexpr int SORT_SMALL_CAP = 2048;  // lists from there up to this: 256-thread workgroups walking the head of the tile order, 24 KB LDS
+// flags[g * 4 + 3] carries two positions of the tile order to the host as 16-bit counts of this many tiles (hints, rounded)
+inline __host__ __device__ uint32_t order_hint_unit(int T) { return (uint32_t)T / 65535u + 1u; }
 constexpr int SORT_LDS_CAP = 8192;    // longest list sorted in LDS (long-list kernel, 96 KB); beyond: global scratch
 constexpr int STILE = 4;           // a super-tile is STILE x STILE tiles (64x64 px): the coarse binning unit
 constexpr int MAX_SUPER_TILES = 8192;  // the binning keeps one LDS counter per super-tile (32 KB): images up to e.g. 8192 x 4096
@@ -81,7 +88,11 @@ struct Dims {
     float mod;    // scale modifier
     int cull;     // 1: sub-tile alpha>=1/255 box culling on (default); 0: evaluate every staged pair
     int long_sort;  // 1: k_tile_sort_long follows k_tile_build_sort (default); 0: the launch is skipped and lists of SORT_SMALL_CAP
-                    //    entries and more take the global-scratch sort inside k_tile_build_sort (the trainer's hint, capi.hip)
+                    //    entries and more stay with the sorter below (its global-scratch path) — the trainer's hint, capi.hip
+    int mid_sort;   // the same for k_tile_sort_mid and lists of SORT_TINY_CAP entries and more
+    int small_first;  // first position of the tile order the short-list sorter's grid covers: short lists in front of it (there
+                      //    are few: the order is longest first) are sorted by k_tile_sort_mid.  0: its grid covers the whole order
+    int mid_grid;     // workgroups per camera of k_tile_sort_mid (0: a default); it walks on in strides when the head is longer
 };
 
 // Device pointers of the scratch.  Arrays marked [G] are per geometry group (camera), [V] per pass.
@@ -105,6 +116,7 @@ struct Scratch {
     uint32_t* tile_count;      // [V][T]
     uint32_t* tile_end;        // [V][T]   inclusive scan of tile_count
     uint32_t* tile_order;      // [V][T]   tiles by descending entry count: the order workgroups take them in
+    uint32_t* sort_marks;      // [G][2]   lengths of the order's heads that hold every list of SORT_SMALL_CAP / SORT_TINY_CAP entries and more
     uint32_t* id_of_slot;      // [V][Rcap] (only tiles longer than the rank-sort limit use it)
     uint32_t* point_list;      // [V][Rcap]  sorted splat ids
     uint32_t* slot_list;       // [V][Rcap]  sorted slots

@@ -143,7 +143,7 @@ __device__ inline void block_sums_prefix(const Dims& d, const Scratch& s, int v)
     if (threadIdx.x == 0) {
         s.flags[v * 4 + 2] = carry;  // num_rendered of this group
         s.flags[v * 4 + 0] = carry > d.Rcap ? 1u : 0u;  // arena too small: the later stages skip the group, the host grows and replays
-        s.flags[v * 4 + 3] = 0u;
+        s.sort_marks[v * 2] = 0u; s.sort_marks[v * 2 + 1] = 0u;  // (flags[3], the host's hint of the last step's tile order, stays)
     }
 }
 
@@ -360,8 +360,10 @@ constexpr int ORDER_BINS = 256;
 // SORT_SMALL_CAP = 2048: "long" tiles, sorted by k_tile_sort_long, are exactly the bins >= ORDER_LONG_BIN)
 __device__ inline int order_bin(uint32_t c) { return c < 1024u ? (int)(c >> 3) : min(ORDER_BINS - 1, 128 + (int)((c - 1024u) >> 6)); }
 constexpr int ORDER_LONG_BIN = 128 + (SORT_SMALL_CAP - 1024) / 64;
+static_assert(SORT_TINY_CAP % 8 == 0 && SORT_TINY_CAP <= 1024, "the short-list limit must be a bin boundary");
+constexpr int ORDER_MID_BIN = SORT_TINY_CAP / 8;  // lists of SORT_TINY_CAP entries and more (k_tile_sort_mid's and k_tile_sort_long's)
 // One workgroup per camera: tile_end = inclusive scan of tile_count (SCAN), tile_order, the longest list (flags[1]) and
-// the length of the order's prefix that holds all long tiles (flags[3]).
+// the lengths of the order's heads that hold all long / mid tiles (sort_marks; flags[3] tells the host about them).
 //
 // XCD affinity.  Workgroups are dealt round-robin over the chip's eight XCDs (position p of the order runs on XCD p % 8 —
 // observed, not promised: it only ever matters for speed), and each XCD has its own L2.  With one global longest-first list the
@@ -385,7 +387,7 @@ __device__ inline int order_class(const Dims& d, int t) {
 }
 template <bool SCAN>
 __device__ inline void tile_scan_order_body(const Dims& d, const Scratch& s, int v) {
-    __shared__ uint32_t hist[ORDER_CLASSES][ORDER_BINS], start[ORDER_CLASSES][ORDER_BINS], csize[ORDER_CLASSES], clong[ORDER_CLASSES];
+    __shared__ uint32_t hist[ORDER_CLASSES][ORDER_BINS], start[ORDER_CLASSES][ORDER_BINS], csize[ORDER_CLASSES], clong[ORDER_CLASSES], cmid[ORDER_CLASSES];
     const uint32_t* cnt = s.tile_count + (size_t)v * d.T;
     uint32_t* order = s.tile_order + (size_t)v * d.T;
 #pragma unroll
@@ -411,15 +413,23 @@ __device__ inline void tile_scan_order_body(const Dims& d, const Scratch& s, int
         const uint32_t ex = block_excl_scan(hist[x][threadIdx.x], &total);
         start[x][threadIdx.x] = ex;
         if (threadIdx.x == ORDER_BINS - ORDER_LONG_BIN) clong[x] = ex;  // long tiles (k_tile_sort_long's) of the class: its first clong[x]
+        if (threadIdx.x == ORDER_BINS - ORDER_MID_BIN) cmid[x] = ex;    // tiles of SORT_TINY_CAP entries and more
         if (threadIdx.x == 0) csize[x] = total;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // all long tiles sit in the first ORDER_CLASSES * max(clong) positions of the interleaved order: k_tile_sort_long walks
-        // that prefix and skips what is not long
-        uint32_t m = 0;
-        for (int x = 0; x < ORDER_CLASSES; x++) m = max(m, clong[x]);
-        s.flags[v * 4 + 3] = min((uint32_t)d.T, (uint32_t)ORDER_CLASSES * m);
+        // Every class's list is longest first, so a rank k of the interleaved order is reached at position
+        // before(k) = sum over the classes of min(k, class size): all tiles of SORT_SMALL_CAP entries and more sit in front of
+        // before(max clong), all of SORT_TINY_CAP and more in front of before(max cmid) — the heads k_tile_sort_long and
+        // k_tile_sort_mid walk (skipping what is not theirs) — and nothing shorter sits in front of before(min cmid).
+        uint32_t kl = 0, km = 0, ks = 0xFFFFFFFFu;
+        for (int x = 0; x < ORDER_CLASSES; x++) { kl = max(kl, clong[x]); km = max(km, cmid[x]); ks = min(ks, cmid[x]); }
+        uint32_t nl = 0, nm = 0, ns = 0;
+        for (int x = 0; x < ORDER_CLASSES; x++) { nl += min(kl, csize[x]); nm += min(km, csize[x]); ns += min(ks, csize[x]); }
+        s.sort_marks[v * 2] = nl;
+        s.sort_marks[v * 2 + 1] = nm;
+        const uint32_t unit = order_hint_unit(d.T);  // to the host, rounded to the safe side (capi.hip: launch grids of the next steps)
+        s.flags[v * 4 + 3] = (min(0xFFFFu, (nm + unit - 1) / unit) << 16) | min(0xFFFFu, ns / unit);
     }
     for (int t = threadIdx.x; t < d.T; t += WG) {
         const int x = order_class(d, t);
@@ -494,7 +504,8 @@ __global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
         }
         // only lists that take the global-scratch sort need ids by slot: those beyond the long-list kernel's LDS, or — when the
         // trainer skips that launch — beyond the per-tile kernel's
-        cur[threadIdx.x] = 0; first[threadIdx.x] = f; big[threadIdx.x] = n > (uint32_t)(d.long_sort ? SORT_LDS_CAP : SORT_SMALL_CAP);
+        cur[threadIdx.x] = 0; first[threadIdx.x] = f; big[threadIdx.x] = n > (uint32_t)((d.long_sort && n >= (uint32_t)SORT_SMALL_CAP) ? SORT_LDS_CAP
+                                                                                                                              : (d.mid_sort && n >= (uint32_t)SORT_TINY_CAP) ? SORT_SMALL_CAP : SORT_TINY_CAP);  // the list will not fit its sorter's LDS
     }
     __syncthreads();
     const size_t c0 = (size_t)v * d.NST + st;
@@ -506,11 +517,13 @@ __global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
     uint32_t* pl = s.point_list + (size_t)v * d.Rcap;
     uint32_t* ids = s.id_of_slot + (size_t)v * d.Rcap;
     // A wave takes 64 consecutive candidates and appends them TILE BY TILE: the candidates that cover the tile (a ballot) get
-    // consecutive positions behind one LDS atomic per wave, so the key / id stores of a tile are contiguous runs instead of
+    // consecutive positions of a run reserved by the wave, so the key / id stores of a tile are contiguous runs instead of
     // 64 different cache lines per store instruction, and the 16 cursors are no longer hit by 64 lanes at once.
     // (One thread per candidate looping over its own tiles took 0.70 ms per launch at 1M splats @2048^2, almost all of it
     // waiting for scattered 8-byte stores and same-address LDS atomics.)
     const int lane = threadIdx.x & 63;
+    const uint32_t seg_first = lane < STILE * STILE ? first[lane] : 0u;  // lane tl: start of tile tl's segment
+    const unsigned long long big_mask = __ballot(lane < STILE * STILE && big[lane] != 0u);
     for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < nc; c0 += NT) {
         const uint32_t c = c0 + lane;
         uint4 e = make_uint4(0, 0, 0, 0);
@@ -524,25 +537,41 @@ __global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
             x0 = max(rx0, tx0); x1 = min(rx1, tx0 + STILE);
             y0 = max(ry0, ty0); y1 = min(ry1, ty0 + STILE);
         }
+        // pass 1: how many of the wave's candidates cover each of the 16 tiles (lane tl collects tile tl's count) ...
+        uint32_t mine = 0;
+#pragma unroll
+        for (int tl = 0; tl < STILE * STILE; tl++) {
+            const int x = tx0 + (tl % STILE), y = ty0 + (tl / STILE);
+            const uint32_t k = (uint32_t)__popcll(__ballot(x >= x0 && x < x1 && y >= y0 && y < y1));
+            mine = lane == tl ? k : mine;
+        }
+        // ... ONE LDS atomic instruction reserves the runs of all 16 tiles (a returning atomic per tile round was 16 dependent
+        // LDS round trips per 64 candidates: -6 % on the dense scene, nothing at cfg3) ...
+        uint32_t runs = 0;
+        if (lane < STILE * STILE && mine != 0u) runs = atomicAdd(&cur[lane], mine);
+        runs += seg_first;  // lane tl: where this wave's entries of tile tl go (index into point_list)
+        // ... pass 2: the entries, tile by tile; the candidates that cover a tile take consecutive positions of its run
 #pragma unroll
         for (int tl = 0; tl < STILE * STILE; tl++) {
             const int x = tx0 + (tl % STILE), y = ty0 + (tl / STILE);
             const bool in = x >= x0 && x < x1 && y >= y0 && y < y1;
             const unsigned long long m = __ballot(in);
             if (m == 0ull) continue;
-            uint32_t run = 0;
-            if (lane == 0) run = atomicAdd(&cur[tl], (uint32_t)__popcll(m));
-            run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)seg_first, tl);
+            const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)runs, tl);
             if (in) {
                 const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 const uint32_t slot = e.w + (uint32_t)((y - ry0) * (rx1 - rx0) + (x - rx0));
-                const uint32_t f = first[tl];
-                keys[2 * (size_t)f + pos] = dz | slot;  // order inside the segment is irrelevant: the key is unique
-                pl[f + pos] = e.x;
-                if (big[tl]) ids[slot] = e.x;  // the long-list path looks the id up by slot after sorting keys only
+                keys[(size_t)f + pos] = dz | slot;  // u64 index 2 * f + position in the segment; order inside the segment is irrelevant: the key is unique
+                pl[pos] = e.x;
+                if ((big_mask >> tl) & 1ull) ids[slot] = e.x;  // the long-list path looks the id up by slot after sorting keys only
             }
         }
     }
+    // (Built and measured, not kept — rocprofv3 medians at cfg3, 55 us for this form: parking a wave's entries in LDS and
+    // storing them as full 64-lane runs, 58 us; every lane walking its own tiles instead of 16 rounds, 70 us, of which 50 are
+    // there without any global store.  k_tile_count, the same loads and ballots without pass 2, takes 15 us: the kernel pays
+    // for pass 2's instructions, and the longest walk of 64 lanes is rarely shorter than 16 rounds.)
 }
 
 // Per-tile segments + tile_end (inclusive scan of tile_count) + tile_order (tiles by descending count) — one launch.
@@ -552,7 +581,11 @@ int launch_tile_scatter(const Dims& d, const Scratch& s, uint32_t* partials, hip
     static_assert(ORDER_BINS == WG, "one bin per thread");
     // every scatter workgroup of the one-launch form reads the tile counts in front of its rows: T / 2 words on average,
     // 64 MB per camera at 2048 x 2048 (T = 16384) — beyond that the separate scan is cheaper than the repeated reads
+#ifdef GS_DIAG_SEPARATE_ORDER  // timing experiment: the scan + order workgroup as a launch of its own
+    if (false) {
+#else
     if (d.T <= g_scan_single_max && d.T <= 16384) {
+#endif
         if (d.VG <= GS_WIDE_BIN_MAX_GROUPS) hipLaunchKernelGGL((k_tile_scatter<true, 1024>), dim3(d.NST + 1, d.VG), dim3(1024), 0, st, d, s);
         else hipLaunchKernelGGL((k_tile_scatter<true, WG>), dim3(d.NST + 1, d.VG), dim3(WG), 0, st, d, s);
     } else if (d.T <= g_scan_single_max) {
@@ -717,33 +750,76 @@ __device__ inline void sort_tile(const Dims& d, const Scratch& s, int v, int til
     }
 }
 
-// Lists below SORT_SMALL_CAP entries: one 256-thread workgroup per tile, 24 KB of LDS (6 workgroups per CU).
-__global__ __launch_bounds__(WG) void k_tile_build_sort(Dims d, Scratch s) {
+// Three sorters by list length, each sized for its class (the host skips the launches of classes the scene does not have:
+// Dims::mid_sort / long_sort; a list that outgrows its sorter's LDS anyway takes the global-scratch path there — slow, correct).
+//
+// Lists below SORT_TINY_CAP (512) entries: one 128-thread workgroup per tile, 7 KB of LDS.  A tile's sort is a chain of
+// dependent latencies (order -> count / end -> keys, then a handful of LDS phases) with little work in between, so what
+// counts is how many tiles a CU has in flight: 16-22 of these against the 6 of a 256-thread workgroup with room for 2048
+// entries (cfg3, 100-500 entries per tile: 88 -> 50 us per 8 cameras).
+__global__ __launch_bounds__(GS_SORT_TILE_NT) void k_tile_build_sort(Dims d, Scratch s) {
+    __shared__ __align__(16) uint64_t sk[SORT_TINY_CAP];
+    __shared__ uint32_t sid[SORT_TINY_CAP];
+    const int v = blockIdx.y;
+    const int tile = (int)s.tile_order[(size_t)v * d.T + d.small_first + blockIdx.x];  // (positions in front of small_first: k_tile_sort_mid)
+    if (s.flags[v * 4 + 0] & 1u) return;  // overflowed view: nothing was scattered
+    const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
+    if (n == 0) return;
+    if (n >= (uint32_t)SORT_TINY_CAP && (d.mid_sort || (d.long_sort && n >= (uint32_t)SORT_SMALL_CAP))) return;  // the next sorters' lists
+    sort_tile<GS_SORT_TILE_NT, SORT_TINY_CAP, 128>(d, s, v, tile, n, sk, sid);
+}
+
+// Lists of SORT_TINY_CAP entries and more sit in the first sort_marks[1] positions of the tile order, the lists of SORT_SMALL_CAP
+// entries and more in its first sort_marks[0] positions (the prefixes interleave the XCD classes' lists: a walker skips what is not its
+// class).  Persistent workgroups walk the prefixes: 256 threads with 2048 entries of LDS (24 KB, 6 per CU) ...
+// k_tile_sort_mid takes ONE tile per workgroup (grid: the head's length as the host knows it from two steps ago, or the whole
+// order); k_tile_sort_mid_walk, a few workgroups per camera, walks what is left of the head behind that grid — normally
+// nothing.  (One kernel that walks in strides is the obvious form; the sort inlined into a loop takes 120 registers instead of
+// 80 — four workgroups per CU where the LDS allows six — and ran 15-25 % slower on a dense scene.)
+__device__ inline bool mid_sorter_owns(const Dims& d, uint32_t idx, uint32_t n) {
+    // short lists only where the short-list sorter's grid does not reach; long ones only without their own sorter
+    return n != 0 && (n < (uint32_t)SORT_TINY_CAP ? idx < (uint32_t)d.small_first : !(d.long_sort && n >= (uint32_t)SORT_SMALL_CAP));
+}
+__global__ __launch_bounds__(WG) void k_tile_sort_mid(Dims d, Scratch s) {
     __shared__ __align__(16) uint64_t sk[SORT_SMALL_CAP];
     __shared__ uint32_t sid[SORT_SMALL_CAP];
     const int v = blockIdx.y;
-    const int tile = (int)s.tile_order[(size_t)v * d.T + blockIdx.x];
-    if (s.flags[v * 4 + 0] & 1u) return;  // overflowed view: nothing was scattered
+    if (s.flags[v * 4 + 0] & 1u) return;
+    const uint32_t idx = blockIdx.x;
+    if (idx >= max(s.sort_marks[v * 2 + 1], (uint32_t)d.small_first)) return;
+    const int tile = (int)s.tile_order[(size_t)v * d.T + idx];
     const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
-    if (n == 0 || (n >= (uint32_t)SORT_SMALL_CAP && d.long_sort)) return;  // long lists: k_tile_sort_long, when it was launched
-    // (without it a list of SORT_SMALL_CAP entries is still sorted in LDS here and longer ones in global scratch: slow, correct)
+    if (!mid_sorter_owns(d, idx, n)) return;
     sort_tile<WG, SORT_SMALL_CAP, 256>(d, s, v, tile, n, sk, sid);
 }
+__global__ __launch_bounds__(WG) void k_tile_sort_mid_walk(Dims d, Scratch s, uint32_t first) {
+    __shared__ __align__(16) uint64_t sk[SORT_SMALL_CAP];
+    __shared__ uint32_t sid[SORT_SMALL_CAP];
+    const int v = blockIdx.y;
+    if (s.flags[v * 4 + 0] & 1u) return;
+    const uint32_t n_walk = max(s.sort_marks[v * 2 + 1], (uint32_t)d.small_first);
+    for (uint32_t idx = first + blockIdx.x; idx < n_walk; idx += gridDim.x) {
+        const int tile = (int)s.tile_order[(size_t)v * d.T + idx];
+        const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
+        if (!mid_sorter_owns(d, idx, n)) continue;
+        sort_tile<WG, SORT_SMALL_CAP, 256>(d, s, v, tile, n, sk, sid);
+        __syncthreads();  // LDS is reused by the next tile
+    }
+}
 
-// Lists of SORT_SMALL_CAP entries and more: they all sit in the first flags[3] positions of the tile order.  A few persistent
-// 1024-thread workgroups per camera walk that prefix with SORT_LDS_CAP (8192) entries of LDS each — 96 KB, one
-// workgroup per CU, which is why short lists do not go through here; only lists beyond that spill to global scratch.
+// ... and 1024 threads with SORT_LDS_CAP (8192) entries — 96 KB, one workgroup per CU, which is why shorter lists do not go
+// through here; only lists beyond that spill to global scratch.
 constexpr int LONG_NT = 1024;
 __global__ __launch_bounds__(LONG_NT) void k_tile_sort_long(Dims d, Scratch s) {
     __shared__ __align__(16) uint64_t sk[SORT_LDS_CAP];
     __shared__ uint32_t sid[SORT_LDS_CAP];
     const int v = blockIdx.y;
     if (s.flags[v * 4 + 0] & 1u) return;
-    const uint32_t n_long = s.flags[v * 4 + 3];
+    const uint32_t n_long = s.sort_marks[v * 2];
     for (uint32_t idx = blockIdx.x; idx < n_long; idx += gridDim.x) {
         const int tile = (int)s.tile_order[(size_t)v * d.T + idx];
         const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
-        if (n < (uint32_t)SORT_SMALL_CAP) continue;  // the prefix interleaves the classes' lists: not every tile in it is long
+        if (n < (uint32_t)SORT_SMALL_CAP) continue;
         sort_tile<LONG_NT, SORT_LDS_CAP, 1024>(d, s, v, tile, n, sk, sid);
         __syncthreads();  // LDS is reused by the next tile
     }
@@ -751,11 +827,25 @@ __global__ __launch_bounds__(LONG_NT) void k_tile_sort_long(Dims d, Scratch s) {
 
 int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.T == 0 || d.VG == 0) return GS_OK;
-    hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T, d.VG), dim3(WG), 0, st, d, s);
+    const int small_first = d.mid_sort ? std::min(std::max(d.small_first, 0), d.T) : 0;  // (a head without its walker would stay unsorted)
+    Dims dd = d;
+    dd.small_first = small_first;
+    if (small_first < d.T) hipLaunchKernelGGL(k_tile_build_sort, dim3(d.T - small_first, d.VG), dim3(GS_SORT_TILE_NT), 0, st, dd, s);
+    if (d.mid_sort) {
+        // a workgroup per tile of the head when the host knows its length (and a few that walk on behind, should the head have
+        // outgrown the hint); else one per tile of the order
+#ifdef GS_DIAG_SORT_MID_GRID_T
+        const int per_cam = d.T;
+#else
+        const int per_cam = d.mid_grid > 0 ? std::min(d.T, std::max(d.mid_grid, small_first)) : d.T;
+#endif
+        hipLaunchKernelGGL(k_tile_sort_mid, dim3(per_cam, d.VG), dim3(WG), 0, st, dd, s);
+        if (per_cam < d.T) hipLaunchKernelGGL(k_tile_sort_mid_walk, dim3(std::min(d.T - per_cam, 32), d.VG), dim3(WG), 0, st, dd, s, (uint32_t)per_cam);
+    }
     if (d.long_sort) {
         // one long-list workgroup fills a CU (96 KB LDS): about one per CU over all cameras
         const int per_cam = std::min(d.T, std::max(16, std::min(256, 256 / std::max(d.VG, 1))));
-        hipLaunchKernelGGL(k_tile_sort_long, dim3(per_cam, d.VG), dim3(LONG_NT), 0, st, d, s);
+        hipLaunchKernelGGL(k_tile_sort_long, dim3(per_cam, d.VG), dim3(LONG_NT), 0, st, dd, s);
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

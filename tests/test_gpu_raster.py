@@ -216,10 +216,11 @@ def test_empty_and_all_culled(orc):
     assert R == 0 and np.all(out == 1.0)
 
 
-@pytest.mark.parametrize("P,longer_than", [(6000, 4096), (12000, 8192)])
+@pytest.mark.parametrize("P,longer_than", [(1500, 512), (6000, 4096), (12000, 8192)])
 def test_long_tile_lists_take_the_spill_path(orc, P, longer_than):
-    """Lists of 2048 entries and more go to the long-list kernel (up to 8192 entries in 96 KB of LDS), longer ones
-    are sorted in global scratch (the spill path); the lists stay bit-exact either way."""
+    """Lists of 512 entries and more go to the mid-list sorter (2048 entries in 24 KB of LDS), of 2048 and more to the long-list
+    kernel (up to 8192 entries in 96 KB of LDS), longer ones are sorted in global scratch (the spill path); the lists stay
+    bit-exact either way."""
     M, D, W, H = 1, 0, 32, 32
     s = util.gs.synth.random_splats(P, M, 99)
     s["loc"] = (s["loc"] * 0.05).astype(np.float32)  # everything projects into the same few tiles

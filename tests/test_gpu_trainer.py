@@ -662,14 +662,16 @@ def test_trainer_options_are_per_trainer(orc):
     c.close(); e.close()
 
 
-def test_long_list_sort_launch_hint_never_changes_a_bit(orc):
+@pytest.mark.parametrize("P,spread,longest_over,longest_under", [(6000, 0.05, 4096, 1 << 30), (1500, 0.05, 512, 2048)])
+def test_long_list_sort_launch_hint_never_changes_a_bit(orc, P, spread, longest_over, longest_under):
     """The long-list sort launch is skipped when the longest list of two steps ago was short ("long_list_sort_launch" = -1,
     the default).  Whatever the switch says — never launch (every long list takes the per-tile kernel's global-scratch path),
     always launch, or the hint — lists, statistics and gradients are the same bits, over several steps of a scene whose tile
-    lists exceed 4096 entries."""
-    P, M, W, H = 6000, 1, 32, 32
+    lists exceed 4096 entries, and of one whose longest lists belong to the mid-list sorter (512..2047 entries: the same switch and
+    hint decide its launch, and from the third step on the hint sizes its grid and the short-list sorter's)."""
+    M, W, H = 1, 32, 32
     s = gs.synth.random_splats(P, M, 99)
-    s["loc"] = (s["loc"] * 0.05).astype(np.float32)   # everything projects into the same few tiles
+    s["loc"] = (s["loc"] * spread).astype(np.float32)   # everything projects into the same few tiles
     s["opac"] = (s["opac"] * 0.02).astype(np.float32)
     cams = gs.camera.get_cameras(2, 10.0, 20.0)
     rng = np.random.default_rng(3)
@@ -685,7 +687,7 @@ def test_long_list_sort_launch_hint_never_changes_a_bit(orc):
         out.append(_download(tr))
         res.append(out)
         tr.close()
-    assert res[0][0][1] > 4096
+    assert longest_over < res[0][0][1] < longest_under
     for other in res[1:]:
         for a, b in zip(res[0][:4], other[:4]):
             assert a[:3] == b[:3]
