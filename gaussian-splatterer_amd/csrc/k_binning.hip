@@ -393,11 +393,23 @@ __device__ inline void tile_scan_order_body(const Dims& d, const Scratch& s, int
 #pragma unroll
     for (int x = 0; x < ORDER_CLASSES; x++) hist[x][threadIdx.x] = 0;
     __syncthreads();
+    // The counts are read ORDER_CHUNK at a time into registers — independent loads, one memory latency per chunk; one load per
+    // trip made this workgroup a chain of T / 256 latencies, and at one or two cameras per launch (the per-GPU load of an 8-GPU
+    // run) it is the longest workgroup of k_tile_scatter.
+    constexpr int ORDER_CHUNK = 16;
     uint32_t longest = 0;
-    for (int t = threadIdx.x; t < d.T; t += WG) {
-        const uint32_t c = cnt[t];
-        longest = max(longest, c);
-        atomicAdd(&hist[order_class(d, t)][ORDER_BINS - 1 - order_bin(c)], 1u);  // bin 0 = longest
+    for (int t0 = threadIdx.x; t0 < d.T; t0 += ORDER_CHUNK * WG) {
+        uint32_t c[ORDER_CHUNK];
+#pragma unroll
+        for (int k = 0; k < ORDER_CHUNK; k++) c[k] = t0 + k * WG < d.T ? cnt[t0 + k * WG] : 0u;
+#pragma unroll
+        for (int k = 0; k < ORDER_CHUNK; k++) {
+            const int t = t0 + k * WG;
+            if (t < d.T) {
+                longest = max(longest, c[k]);
+                atomicAdd(&hist[order_class(d, t)][ORDER_BINS - 1 - order_bin(c[k])], 1u);  // bin 0 = longest
+            }
+        }
     }
     // statistic: the longest tile list of the group (a global atomicMax per TILE cost 210 us: same-address atomics serialise)
 #pragma unroll
@@ -431,13 +443,25 @@ __device__ inline void tile_scan_order_body(const Dims& d, const Scratch& s, int
         const uint32_t unit = order_hint_unit(d.T);  // to the host, rounded to the safe side (capi.hip: launch grids of the next steps)
         s.flags[v * 4 + 3] = (min(0xFFFFu, (nm + unit - 1) / unit) << 16) | min(0xFFFFu, ns / unit);
     }
-    for (int t = threadIdx.x; t < d.T; t += WG) {
-        const int x = order_class(d, t);
-        const uint32_t k = atomicAdd(&start[x][ORDER_BINS - 1 - order_bin(cnt[t])], 1u);  // rank in the class's longest-first list
-        uint32_t pos = 0;  // tiles in front of (k, x) in the interleaved order: ranks < k of every class, rank k of the classes before x
+    uint32_t sizes[ORDER_CLASSES];
 #pragma unroll
-        for (int y = 0; y < ORDER_CLASSES; y++) pos += min(k, csize[y]) + ((y < x && csize[y] > k) ? 1u : 0u);
-        order[pos] = (uint32_t)t;
+    for (int y = 0; y < ORDER_CLASSES; y++) sizes[y] = csize[y];
+    for (int t0 = threadIdx.x; t0 < d.T; t0 += ORDER_CHUNK * WG) {
+        uint32_t c[ORDER_CHUNK];
+#pragma unroll
+        for (int k = 0; k < ORDER_CHUNK; k++) c[k] = t0 + k * WG < d.T ? cnt[t0 + k * WG] : 0u;
+#pragma unroll
+        for (int j = 0; j < ORDER_CHUNK; j++) {
+            const int t = t0 + j * WG;
+            if (t < d.T) {
+                const int x = order_class(d, t);
+                const uint32_t k = atomicAdd(&start[x][ORDER_BINS - 1 - order_bin(c[j])], 1u);  // rank in the class's longest-first list
+                uint32_t pos = 0;  // tiles in front of (k, x) in the interleaved order: ranks < k of every class, rank k of the classes before x
+#pragma unroll
+                for (int y = 0; y < ORDER_CLASSES; y++) pos += min(k, sizes[y]) + ((y < x && sizes[y] > k) ? 1u : 0u);
+                order[pos] = (uint32_t)t;
+            }
+        }
     }
 }
 __global__ __launch_bounds__(WG) void k_tile_scan_order_noscan(Dims d, Scratch s) { tile_scan_order_body<false>(d, s, blockIdx.x); }
