@@ -210,9 +210,10 @@ int gs_trainer_apply(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs
  * the copy of every element it writes.  Geometry, tile lists and ranges do not depend on SH and are bit-identical with
  * the switch on or off; colours and gradients are those of the fp32 path run on the half-rounded coefficients, bit for
  * bit (tests/test_gpu_trainer.py::test_sh_fp16_*), i.e. within 2^-11 relative per coefficient of the fp32 result.
- * "long_list_sort_launch" (default -1): the sort of tile lists of 2048 entries and more is a launch of its own that most
- * scenes leave empty; -1 skips it when the longest list of two steps ago stayed below 1536 entries (a list that outgrows the
- * hint is sorted in global scratch by the per-tile kernel: slower, same result), 0 never launches it, 1 always does.
+ * "long_list_sort_launch" (default -1): the sorts of tile lists of 512 and of 2048 entries and more are launches of their own
+ * that many scenes leave empty; -1 skips each while the longest list of two steps ago stayed a quarter below its limit (a
+ * list that outgrows the hint is sorted in global scratch by the sorter one class down: slower, same result) and sizes the
+ * launches' grids from the tile order of two steps ago; 0 never launches them; 1 always does, with grids that need no hint.
  * Changing "share_camera_passes" regroups the passes already set. */
 int gs_trainer_set_option(gs_trainer* trainer, const char* name, int value);
 

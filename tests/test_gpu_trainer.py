@@ -695,3 +695,42 @@ def test_long_list_sort_launch_hint_never_changes_a_bit(orc, P, spread, longest_
                 assert np.array_equal(a[3][k].view(np.uint32), b[3][k].view(np.uint32)), k
         for k in ("loc", "sh", "scale", "opac", "rot"):
             assert np.array_equal(res[0][4][k].view(np.uint32), other[4][k].view(np.uint32)), k
+
+
+def test_stale_sort_grid_hints_never_change_a_bit():
+    """The grids of the short- and mid-list sorters follow the tile order of two steps ago (flags[3]).  With learning rates a
+    thousand times the defaults the lists change by tens of percent from step to step, so those hints are stale on every step:
+    the mid-list sorter's walker and its share of the short lists are in use.  Lists, statistics, gradients and the model
+    after eight steps must be the same bits as with full grids ("long_list_sort_launch" = 1 switches the hints off)."""
+    P, M, W, H = 12000, 1, 128, 128
+    s = gs.synth.random_splats(P, M, 41)
+    s["loc"] = (s["loc"] * 0.25).astype(np.float32)
+    s["opac"] = (s["opac"] * 0.05).astype(np.float32)
+    cams = gs.camera.get_cameras(2, 10.0, 20.0)
+    rng = np.random.default_rng(5)
+    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+    proj = gs.Project()
+    proj.lrLocation *= 1000.0
+    proj.lrScale *= 1000.0
+    res = []
+    for mode in (1, -1):
+        tr = _trainer_on(s, cams, fw, fb, W, H, long_list_sort_launch=mode)
+        out = []
+        for _ in range(8):
+            st = tr.train(proj, stats=True)
+            out.append((st.num_rendered, st.max_tile_list, st.loss, _read_grads(tr, P, M)))
+        out.append(_download(tr))
+        res.append(out)
+        tr.close()
+    longest = [o[1] for o in res[0][:8]]
+    rendered = [o[0] for o in res[0][:8]]
+    print("longest list per step", longest, "entries per step", rendered)
+    assert max(longest) >= 512 and min(longest) < 2048  # the mid-list class is in use
+    assert max(abs(a - b) / max(a, 1) for a, b in zip(rendered[:-1], rendered[1:])) > 0.1  # and the lists do move
+    for a, b in zip(res[0][:8], res[1][:8]):
+        assert a[:3] == b[:3]
+        for k in a[3]:
+            assert np.array_equal(a[3][k].view(np.uint32), b[3][k].view(np.uint32)), k
+    for k in ("loc", "sh", "scale", "opac", "rot"):
+        assert np.array_equal(res[0][8][k].view(np.uint32), res[1][8][k].view(np.uint32)), k
