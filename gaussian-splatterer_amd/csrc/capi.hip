@@ -31,6 +31,7 @@ struct Options {
     int debug_sync = 0;  // wait and check for errors after every stage, like the reference's debug=true rasterizer calls
     int sh_fp16 = 0;     // the projection reads SH coefficients from a half-precision copy (BASELINE cfg5); fp32 master and gradients
     int long_sort = -1;  // k_tile_sort_long launch: -1 by the longest-list hint (default), 0 never (lists take the global-scratch path), 1 always
+    int sort_grids = -1; // test hook: >= 0 replaces the device's hint for the sort grids: small_first | mid_grid << 16 (in tiles)
 };
 static Options g_defaults;
 // returns false for an unknown name
@@ -42,6 +43,7 @@ static bool set_option(Options& o, const char* name, int value) {
     if (strcmp(name, "debug_sync") == 0) { o.debug_sync = value != 0; return true; }
     if (strcmp(name, "sh_fp16") == 0) { o.sh_fp16 = value != 0; return true; }
     if (strcmp(name, "long_list_sort_launch") == 0) { o.long_sort = value < 0 ? -1 : (value != 0); return true; }
+    if (strcmp(name, "debug_sort_grids") == 0) { o.sort_grids = value < 0 ? -1 : value; return true; }
     return false;
 }
 
@@ -723,6 +725,11 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
                 d.small_first = small_start > keep ? (int)std::min((uint32_t)d.T, small_start - keep) : 0;
                 d.mid_grid = (int)std::min((uint32_t)d.T, mid_end + std::max(64u, mid_end / 8));
             }
+        }
+        if (t->opt.sort_grids >= 0) {  // test hook: any grids must give the same lists (tests/test_gpu_trainer.py)
+            d.mid_sort = 1;
+            d.small_first = std::min(d.T, t->opt.sort_grids & 0xFFFF);
+            d.mid_grid = std::max(1, std::min(d.T, t->opt.sort_grids >> 16));
         }
         Scratch s = t->train.s;
         s.truth = t->truth.as<uint32_t>();

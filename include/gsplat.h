@@ -214,6 +214,8 @@ int gs_trainer_apply(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs
  * that many scenes leave empty; -1 skips each while the longest list of two steps ago stayed a quarter below its limit (a
  * list that outgrows the hint is sorted in global scratch by the sorter one class down: slower, same result) and sizes the
  * launches' grids from the tile order of two steps ago; 0 never launches them; 1 always does, with grids that need no hint.
+ * "debug_sort_grids" (default -1; a test hook): a value >= 0 replaces that hint by small_first | mid_grid << 16 (tiles): any
+ * grids must produce the same lists.
  * Changing "share_camera_passes" regroups the passes already set. */
 int gs_trainer_set_option(gs_trainer* trainer, const char* name, int value);
 

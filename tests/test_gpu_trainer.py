@@ -734,3 +734,36 @@ def test_stale_sort_grid_hints_never_change_a_bit():
             assert np.array_equal(a[3][k].view(np.uint32), b[3][k].view(np.uint32)), k
     for k in ("loc", "sh", "scale", "opac", "rot"):
         assert np.array_equal(res[0][8][k].view(np.uint32), res[1][8][k].view(np.uint32)), k
+
+
+@pytest.mark.parametrize("small_first,mid_grid", [(0, 1), (20, 1), (64, 1), (64, 64), (5, 40)])
+def test_any_sort_grids_give_the_same_lists(small_first, mid_grid):
+    """Whatever the host believes about the tile order — the mid-list sorter's grid far too small (its walker does the work), the
+    short-list sorter's grid starting anywhere in the order (the mid-list sorter takes the short lists in front of it), or
+    covering nothing — statistics, gradients and the updated model are the bits of the run with hint-free grids.  The scene has
+    short, mid and long lists (64 tiles)."""
+    P, M, W, H = 12000, 1, 128, 128
+    s = gs.synth.random_splats(P, M, 41)
+    s["loc"] = (s["loc"] * 0.25).astype(np.float32)
+    s["opac"] = (s["opac"] * 0.05).astype(np.float32)
+    cams = gs.camera.get_cameras(2, 10.0, 20.0)
+    rng = np.random.default_rng(5)
+    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+    res = []
+    for opts in ({"long_list_sort_launch": 1}, {"debug_sort_grids": small_first | (mid_grid << 16)}):
+        tr = _trainer_on(s, cams, fw, fb, W, H, **opts)
+        out = []
+        for _ in range(2):
+            st = tr.train(gs.Project(), stats=True)
+            out.append((st.num_rendered, st.max_tile_list, st.loss, _read_grads(tr, P, M)))
+        out.append(_download(tr))
+        res.append(out)
+        tr.close()
+    assert res[0][0][1] >= 512
+    for a, b in zip(res[0][:2], res[1][:2]):
+        assert a[:3] == b[:3]
+        for k in a[3]:
+            assert np.array_equal(a[3][k].view(np.uint32), b[3][k].view(np.uint32)), k
+    for k in ("loc", "sh", "scale", "opac", "rot"):
+        assert np.array_equal(res[0][2][k].view(np.uint32), res[1][2][k].view(np.uint32)), k
