@@ -849,6 +849,7 @@ __global__ __launch_bounds__(LONG_NT) void k_tile_sort_long(Dims d, Scratch s) {
     }
 }
 
+constexpr int MID_WALK_ONLY = 512;  // heads up to this many tiles per camera (by the host's hint) are left to the walker kernel alone
 int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.T == 0 || d.VG == 0) return GS_OK;
     const int small_first = d.mid_sort ? std::min(std::max(d.small_first, 0), d.T) : 0;  // (a head without its walker would stay unsorted)
@@ -863,8 +864,14 @@ int launch_tile_build_sort(const Dims& d, const Scratch& s, hipStream_t st) {
 #else
         const int per_cam = d.mid_grid > 0 ? std::min(d.T, std::max(d.mid_grid, small_first)) : d.T;
 #endif
-        hipLaunchKernelGGL(k_tile_sort_mid, dim3(per_cam, d.VG), dim3(WG), 0, st, dd, s);
-        if (per_cam < d.T) hipLaunchKernelGGL(k_tile_sort_mid_walk, dim3(std::min(d.T - per_cam, 32), d.VG), dim3(WG), 0, st, dd, s, (uint32_t)per_cam);
+        if (per_cam <= MID_WALK_ONLY && per_cam < d.T) {
+            // a short head (a scene at the edge of having such lists: cfg3's longest is 509): the walker alone, one workgroup
+            // per tile of the hint — its four workgroups per CU do not matter for a few tiles, a second launch does
+            hipLaunchKernelGGL(k_tile_sort_mid_walk, dim3(per_cam, d.VG), dim3(WG), 0, st, dd, s, 0u);
+        } else {
+            hipLaunchKernelGGL(k_tile_sort_mid, dim3(per_cam, d.VG), dim3(WG), 0, st, dd, s);
+            if (per_cam < d.T) hipLaunchKernelGGL(k_tile_sort_mid_walk, dim3(std::min(d.T - per_cam, 32), d.VG), dim3(WG), 0, st, dd, s, (uint32_t)per_cam);
+        }
     }
     if (d.long_sort) {
         // one long-list workgroup fills a CU (96 KB LDS): about one per CU over all cameras
