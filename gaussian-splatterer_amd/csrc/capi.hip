@@ -348,6 +348,7 @@ static int model_alloc(int capacity, int sh_degree, int sh_coeffs, int count, gs
     const size_t bytes = plane_buffer_floats(sh_coeffs, m->Pa) * sizeof(float);  // parameter planes + spare plane + chunk padding
     hipError_t e = hipMalloc((void**)&m->planes, bytes);
     if (e != hipSuccess) { delete m; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GS_ERR_OUT_OF_MEMORY; }
+    m->planes_bytes = bytes;
     e = clear_on ? hipMemsetAsync(m->planes, 0, bytes, *clear_on) : hipMemset(m->planes, 0, bytes);
     if (e != hipSuccess) { (void)hipFree(m->planes); delete m; set_error("hipMemset failed: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
     *out = m;
@@ -442,6 +443,8 @@ struct gs_trainer {
     int steps_on_these_lists = 0;  // accumulate calls since the model / views / arena last changed: the longest-list hint below is
                                   // what the device wrote two calls ago and the early flag copy of the last call brought back
     DevBuf densify_work;          // classification flags, ranks and scan partials of densify / prune
+    DevBuf spare_planes, spare_m, spare_v;  // the plane sets the last densify replaced: the next one writes into them (no hipMalloc /
+                                            // hipFree of three plane sets per densify step: they were a third of its 3.5 ms)
     DevBuf sh16;                  // [3M][Pa] half: read copy of the SH planes (option "sh_fp16")
     const void* sh16_of = nullptr;  // the parameter planes the copy was made from and kept current with (null: stale)
     int device = 0, W = 0, H = 0;
@@ -565,6 +568,7 @@ extern "C" int gs_trainer_destroy(gs_trainer* t) {
     (void)hipStreamSynchronize(t->stream);
     gs_model_destroy(t->model);
     t->truth.release(); t->grad.release(); t->adam_m.release(); t->adam_v.release(); t->sh16.release(); t->densify_work.release();
+    t->spare_planes.release(); t->spare_m.release(); t->spare_v.release();
     t->train.release(); t->preview.release();
     if (t->h_flags) (void)hipHostFree(t->h_flags);
     if (t->ev_flags) (void)hipEventDestroy(t->ev_flags);
@@ -845,31 +849,40 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
     const int splits_done = std::min(n_split, std::max(0, cap - count));
     const int clones_done = std::min(n_clone, std::max(0, cap - count - splits_done));
     const int n2 = kept + splits_done + clones_done;
-    gs_model* fresh = nullptr;
-    rc = model_alloc(cap, m->sh_degree, M, n2, &fresh, &t->stream);  // cleared on the trainer's stream, in order with the emit pass
+    // The new plane sets (parameters, and the two Adam moments) go into the trainer's spare buffers — the sets the previous densify
+    // replaced — and the sets replaced now become the spares: a buffer is only allocated when the model has outgrown the spare,
+    // then with half as much again as headroom (never more than the model's capacity needs).
+    const int Pa2 = std::max(64, round_up(n2, 64));
+    const size_t bytes = plane_buffer_floats(M, Pa2) * sizeof(float);
+    const size_t bytes_cap = plane_buffer_floats(M, std::max(64, round_up(std::max(cap, n2), 64))) * sizeof(float);
+    auto spare = [&](DevBuf& b) { return b.cap >= bytes ? GS_OK : b.ensure(std::min(bytes_cap, bytes + bytes / 2)); };
+    rc = spare(t->spare_planes);
+    if (rc == GS_OK && hipMemsetAsync(t->spare_planes.p, 0, bytes, t->stream) != hipSuccess) rc = GS_ERR_HIP;  // in order with the emit pass
     if (rc == GS_OK) rc = launch_densify_emit(count, m->Pa, M, m->planes, t->grad.as<float>(), *h, flags, ranks, fs, splits_done, clones_done, kept,
-                                              fresh->Pa, fresh->planes, t->stream);
+                                              Pa2, t->spare_planes.as<float>(), t->stream);
     // Adam moments follow their splats (twins inherit the parent's); the step counter keeps running
-    DevBuf new_m, new_v;
     if (rc == GS_OK && t->adam_valid) {
-        const size_t bytes = plane_buffer_floats(M, fresh->Pa) * 4;
-        rc = new_m.ensure(bytes);
-        if (rc == GS_OK) rc = new_v.ensure(bytes);
-        if (rc == GS_OK && (hipMemsetAsync(new_m.p, 0, bytes, t->stream) != hipSuccess || hipMemsetAsync(new_v.p, 0, bytes, t->stream) != hipSuccess)) rc = GS_ERR_HIP;
-        if (rc == GS_OK) rc = launch_densify_carry(count, m->Pa, M, *h, flags, ranks, fs, splits_done, clones_done, kept, fresh->Pa,
-                                                   t->adam_m.as<float>(), new_m.as<float>(), t->adam_v.as<float>(), new_v.as<float>(), t->stream);
+        rc = spare(t->spare_m);
+        if (rc == GS_OK) rc = spare(t->spare_v);
+        if (rc == GS_OK && (hipMemsetAsync(t->spare_m.p, 0, bytes, t->stream) != hipSuccess || hipMemsetAsync(t->spare_v.p, 0, bytes, t->stream) != hipSuccess)) rc = GS_ERR_HIP;
+        if (rc == GS_OK) rc = launch_densify_carry(count, m->Pa, M, *h, flags, ranks, fs, splits_done, clones_done, kept, Pa2,
+                                                   t->adam_m.as<float>(), t->spare_m.as<float>(), t->adam_v.as<float>(), t->spare_v.as<float>(), t->stream);
     }
-    // the old planes (and moments) are freed below: wait for the kernels that read them
-    if (rc == GS_OK && hipStreamSynchronize(t->stream) != hipSuccess) { rc = GS_ERR_HIP; set_error("densify failed: %s", hipGetErrorString(hipGetLastError())); }
-    if (rc != GS_OK) { if (fresh) gs_model_destroy(fresh); new_m.release(); new_v.release(); return rc; }
-    std::swap(m->planes, fresh->planes);
-    m->Pa = fresh->Pa; m->count = fresh->count;
+    if (rc != GS_OK) {
+        if (rc == GS_ERR_HIP) set_error("densify failed: %s", hipGetErrorString(hipGetLastError()));
+        (void)hipStreamSynchronize(t->stream);  // nothing was swapped: the model and the moments are as before
+        return rc;
+    }
+    // swap: the model keeps its identity, the replaced sets wait for the next densify.  Everything is ordered on the trainer's
+    // stream, so no wait is needed for the sets that were read; a model shared with other streams is the caller's to synchronise,
+    // as before a gs_model_destroy.
+    DevBuf old_planes;
+    old_planes.p = m->planes; old_planes.cap = m->planes_bytes;
+    m->planes = t->spare_planes.as<float>(); m->planes_bytes = t->spare_planes.cap;
+    t->spare_planes = old_planes;  // DevBuf is a plain (pointer, capacity) pair: ownership moves
+    m->Pa = Pa2; m->count = n2;
     t->sh16_of = nullptr; t->steps_on_these_lists = 0;
-    gs_model_destroy(fresh);
-    if (t->adam_valid) {
-        t->adam_m.release(); t->adam_v.release();
-        t->adam_m = new_m; t->adam_v = new_v;  // DevBuf is a plain (pointer, capacity) pair: ownership moves
-    }
+    if (t->adam_valid) { std::swap(t->adam_m, t->spare_m); std::swap(t->adam_v, t->spare_v); }
     st->count_after = n2;
     return GS_OK;
 }

@@ -209,4 +209,5 @@ struct gs_model {
     int device = 0;
     int Pa = 0;            // plane stride of `planes`
     float* planes = nullptr;  // [11+3M][Pa] device
+    size_t planes_bytes = 0;  // size of that allocation (densify swaps plane sets with the trainer's spare one: it may be larger than Pa needs)
 };
