@@ -271,7 +271,9 @@ def _five(a, n, M):
 def test_adam_state_survives_densify(orc, quat):
     """The Adam moments follow their splats through split / clone / prune (twins inherit the parent's moments, the
     rotation rows follow the quaternion's member permutation) and the step counter keeps running: parameters AND
-    moments equal the oracle's restatement bit for bit right after the densify step and after one more Adam step."""
+    moments equal the oracle's restatement bit for bit right after every densify step and after the Adam steps between them.
+    Three densify steps, two of them back to back: each writes into the plane sets the one before replaced (the trainer's spare
+    sets), the model growing and, once the capacity is reached, shrinking."""
     P, M, n_cams, W, H = 1200, 4, 2, 96, 96
     s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 123)
     cap = P + 400
@@ -287,8 +289,9 @@ def test_adam_state_survives_densify(orc, quat):
     m = np.zeros((11 + 3 * M) * P, np.float32)
     v = np.zeros_like(m)
     n = P
-    for t in range(1, 5):
-        densify = t == 3
+    counts = []
+    for t in range(1, 8):
+        densify = t in (3, 4, 6)
         tr.accumulate()                       # split API: the gradient buffer is read between accumulate and apply
         g = _read_grads(tr, n, M)             # (densify re-indexes the model, the buffer then no longer matches it)
         st = tr.apply(proj, densify=densify, stats=True)
@@ -308,7 +311,8 @@ def test_adam_state_survives_densify(orc, quat):
                       clone_distance=proj.paramCloneDistance)
             n2 = orc.densify(big["loc"], big["sh"], big["scale"], big["opac"], big["rot"], n, cap, M, g["var"], g["loc"], hp,
                              1 if quat == capi.GS_QUAT_XYZW else 0, bm, bv)
-            assert st.count_after == n2 and n2 != n
+            assert st.count_after == n2
+            counts.append((n, n2))
             want = {k: big[k][:w * n2].copy() for k, w in zip(keys, (3, 3 * M, 3, 1, 4))}
             m = np.concatenate([a[:w * n2] for a, w in zip(_five(bm, cap, M), (3, 3 * M, 3, 1, 4))])
             v = np.concatenate([a[:w * n2] for a, w in zip(_five(bv, cap, M), (3, 3 * M, 3, 1, 4))])
@@ -322,6 +326,8 @@ def test_adam_state_survives_densify(orc, quat):
         assert np.array_equal(gm.view(np.uint32), m.view(np.uint32)), t
         assert np.array_equal(gv.view(np.uint32), v.view(np.uint32)), t
     tr.close()
+    print("splat counts through the densify steps", counts)
+    assert all(a != b for a, b in counts)
 
 
 def test_preview_render_matches_oracle(orc):
