@@ -110,6 +110,24 @@ def get_cameras_project(project):
     return out
 
 
+def get_preview_camera(project):
+    """Camera::getPreviewCamera, src/Camera.cpp:60-74 — the camera every Trainer::render caller of the reference builds
+    (src/ui/UiPanelViewOutput.cpp:52-60, src/ui/tools/UiPanelToolsView.cpp:250): one of the truth cameras
+    (project.previewTruth; an index past the end raises like std::vector::at), or the free camera
+    (0, 0, -previewFreeDistance) turned by angleAxis(radians(previewFreeRotY) + orbit, +Y) * angleAxis(radians(previewFreeRotX), +X).
+    The reference adds previewTimer * previewFreeOrbitSpeed to the angle AFTER converting previewFreeRotY to radians
+    (:68-69: the term it calls degRotOrbit is used as radians); reproduced as is."""
+    if project.previewTruth:
+        cams = get_cameras_project(project)
+        if not 0 <= project.previewTruthIndex < len(cams):
+            raise IndexError("vector::at: previewTruthIndex %d of %d cameras" % (project.previewTruthIndex, len(cams)))
+        return cams[project.previewTruthIndex]
+    orbit = F(project.previewTimer) * F(project.previewFreeOrbitSpeed) if project.previewFreeOrbit else F(0.0)
+    rot = (_angle_axis_mat3(F(math.radians(project.previewFreeRotY)) + orbit, (0, 1, 0)) @ _angle_axis_mat3(math.radians(project.previewFreeRotX), (1, 0, 0))).astype(F)
+    loc = (rot @ np.array([0.0, 0.0, -project.previewFreeDistance], F)).astype(F)
+    return Camera(loc, (0, 0, 0), project.previewFreeFovDeg)
+
+
 def get_cameras_count(project):
     """Camera::getCamerasCount, src/Camera.cpp:29-31."""
     return project.sphere1.count + project.sphere2.count

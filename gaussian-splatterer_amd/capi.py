@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPLAT_MI355_LIB") or os.path.join(_HERE, "libgsplat_mi355.so")  # override: kernel-tuning builds only
 
 GS_OK = 0
+GS_ERR_INVALID_ARGUMENT, GS_ERR_HIP, GS_ERR_NO_TRUTH, GS_ERR_NO_DEVICE, GS_ERR_COLLECTIVE = -1, -2, -3, -9, -11
 GS_UPDATE_SGD_CLAMP, GS_UPDATE_ADAM = 0, 1
 GS_QUAT_WXYZ, GS_QUAT_XYZW = 0, 1
 GS_COMM_ID_BYTES = 128
@@ -56,7 +57,7 @@ SYMBOLS = [
     "gs_trainer_destroy", "gs_trainer_set_model", "gs_trainer_get_model", "gs_trainer_set_views", "gs_trainer_step",
     "gs_trainer_accumulate", "gs_trainer_grad_buffer", "gs_trainer_apply", "gs_trainer_set_allreduce",
     "gs_trainer_get_stream", "gs_trainer_synchronize", "gs_trainer_render", "gs_trainer_read_image",
-    "gs_trainer_set_option", "gs_trainer_set_sharded_update", "gs_trainer_attach_comm_sharded", "gs_trainer_set_profiling", "gs_trainer_stage_times", "gs_stage_name", "gs_trainer_adam_state",
+    "gs_trainer_set_option", "gs_trainer_set_sharded_update", "gs_trainer_attach_comm_sharded", "gs_trainer_set_profiling", "gs_trainer_stage_times", "gs_stage_name", "gs_trainer_adam_state", "gs_trainer_set_adam_state",
     "gs_comm_unique_id", "gs_comm_create", "gs_comm_destroy", "gs_trainer_attach_comm", "gs_rasterize_forward",
     "gs_rasterize_backward", "gs_raster_chunk_field", "gs_image_float_to_int", "gs_image_int_to_loss",
 ]
@@ -103,6 +104,7 @@ def lib():
     L.gs_trainer_apply.argtypes = [vp, C.POINTER(gs_hyper), i, C.POINTER(gs_step_stats)]
     L.gs_trainer_set_allreduce.argtypes = [vp, vp, vp]
     L.gs_trainer_adam_state.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(i)]
+    L.gs_trainer_set_adam_state.argtypes = [vp, vp, vp, C.c_size_t, i, i]
     L.gs_trainer_get_stream.argtypes = [vp, C.POINTER(vp)]
     L.gs_trainer_synchronize.argtypes = [vp]
     L.gs_trainer_render.argtypes = [vp, vp, i, i, i, f, C.POINTER(gs_view)]

@@ -224,7 +224,7 @@ struct ScratchSet {
 // (the scans then define empty lists).
 static int stage_project(const Dims& d, const float* params, const Scratch& s, hipStream_t st) {
     if (d.NST > MAX_SUPER_TILES) {
-        set_error("image of %dx%d has %d super-tiles; this build bins up to %d (e.g. 8192x4096)", d.W, d.H, d.NST, MAX_SUPER_TILES);
+        set_error("image of %dx%d has %d super-tiles; this build bins up to %d (8192x8192, 16384x4096, ...)", d.W, d.H, d.NST, MAX_SUPER_TILES);
         return GS_ERR_INVALID_ARGUMENT;
     }
     GS_TRY(launch_preprocess(d, params, s, st));
@@ -545,7 +545,7 @@ extern "C" int gs_trainer_create(int width, int height, gs_trainer** out) {
     {
         const Dims dd = make_dims(0, 64, 0, 1, width, height, 1, 1, 1.0f);
         if (dd.NST > MAX_SUPER_TILES) {
-            set_error("gs_trainer_create: %dx%d has %d super-tiles; this build bins up to %d (e.g. 8192x4096)", width, height, dd.NST, MAX_SUPER_TILES);
+            set_error("gs_trainer_create: %dx%d has %d super-tiles; this build bins up to %d (8192x8192, 16384x4096, ...)", width, height, dd.NST, MAX_SUPER_TILES);
             return GS_ERR_INVALID_ARGUMENT;
         }
     }
@@ -1009,6 +1009,36 @@ extern "C" int gs_trainer_adam_state(gs_trainer* t, float** m, float** v, size_t
     return GS_OK;
 }
 
+// Checkpoint / resume of an Adam run: the caller hands back what gs_trainer_adam_state gave out (device or host pointers,
+// n_floats = (11 + 3M) * plane stride of the CURRENT model) and the step counter.  m1 == m2 == NULL with steps == 0 resets.
+extern "C" int gs_trainer_set_adam_state(gs_trainer* t, const float* m1, const float* m2, size_t n_floats, int steps, int on_device) {
+    if (!t || !t->model) return GS_ERR_INVALID_ARGUMENT;
+    GS_HIP(hipSetDevice(t->device));
+    GS_HIP(hipStreamSynchronize(t->stream));
+    if (!m1 && !m2 && steps == 0) { t->adam_valid = false; t->adam_t = 0; return GS_OK; }
+    gs_model* m = t->model;
+    const size_t want = (size_t)(11 + 3 * m->sh_coeffs) * m->Pa;
+    if (!m1 || !m2 || steps < 0 || n_floats != want) {
+        set_error("gs_trainer_set_adam_state: expected two moment buffers of %zu floats ((11 + 3M) x plane stride of the current model) and steps >= 0, got %zu floats, steps %d",
+                  want, n_floats, steps);
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    if (t->shard_rs && t->shard_world > 1) {
+        set_error("gs_trainer_set_adam_state: under the sharded update every rank holds the moments of its own chunk only; restore before gs_trainer_set_sharded_update is not kept either (it resets the moments)");
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    const size_t bytes = plane_buffer_floats(m->sh_coeffs, m->Pa) * 4;
+    GS_TRY(t->adam_m.ensure(bytes)); GS_TRY(t->adam_v.ensure(bytes));
+    GS_HIP(hipMemsetAsync(t->adam_m.p, 0, bytes, t->stream));
+    GS_HIP(hipMemsetAsync(t->adam_v.p, 0, bytes, t->stream));
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    GS_HIP(hipMemcpyAsync(t->adam_m.p, m1, want * 4, kind, t->stream));
+    GS_HIP(hipMemcpyAsync(t->adam_v.p, m2, want * 4, kind, t->stream));
+    GS_HIP(hipStreamSynchronize(t->stream));  // host sources may be released on return
+    t->adam_valid = true; t->adam_t = steps;
+    return GS_OK;
+}
+
 extern "C" int gs_trainer_set_option(gs_trainer* t, const char* name, int value) {
     if (!t || !name) return GS_ERR_INVALID_ARGUMENT;
     const int share_before = t->opt.share;
@@ -1018,6 +1048,9 @@ extern "C" int gs_trainer_set_option(gs_trainer* t, const char* name, int value)
         const int* vg = reinterpret_cast<const int*>(t->h_view_block.data() + (size_t)t->V * 2 * sizeof(gs_view));
         t->h_view_group.assign(vg, vg + t->V);
         t->views_on_device = nullptr;
+        // the group count changed: the host's hint words (h_flags[g * 4 + 1 / 3]) belong to other groups, and gradients
+        // accumulated under the old grouping must not be applied (as in gs_trainer_set_views)
+        t->steps_on_these_lists = 0; t->accumulated = false; t->stats_stale = false;
     }
     if (strcmp(name, "sh_fp16") == 0) t->sh16_of = nullptr;
     return GS_OK;

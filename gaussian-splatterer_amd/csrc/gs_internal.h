@@ -45,7 +45,9 @@ constexpr int SORT_SMALL_CAP = 2048;  // lists from there up to this: 256-thread
 inline __host__ __device__ uint32_t order_hint_unit(int T) { return (uint32_t)T / 65535u + 1u; }
 constexpr int SORT_LDS_CAP = 8192;    // longest list sorted in LDS (long-list kernel, 96 KB); beyond: global scratch
 constexpr int STILE = 4;           // a super-tile is STILE x STILE tiles (64x64 px): the coarse binning unit
-constexpr int MAX_SUPER_TILES = 8192;  // the binning keeps one LDS counter per super-tile (32 KB): images up to e.g. 8192 x 4096
+constexpr int MAX_SUPER_TILES = 16384;  // the binning keeps one LDS counter per super-tile (64 KB at most): images up to 8192 x 8192 —
+                                        // the largest render the reference's UI offers (src/ui/tools/UiPanelToolsView.cpp:120,125) —
+                                        // or any other shape of as many 64 x 64-px blocks (16384 x 4096, ...)
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
@@ -147,6 +149,7 @@ size_t colscan_partial_words(int Pa, int NST, int V);  // scratch the two-pass c
 // batched inclusive scan of u32: one workgroup per batch entry up to g_scan_single_max items, three phases beyond
 int launch_scan_u32(const uint32_t* in, uint32_t* out, int n, int stride, int batch, uint32_t* partials, hipStream_t st);
 size_t scan_partials_count(int n, int batch);
+int allow_dynamic_lds(const void* kernel, size_t bytes);  // hipFuncSetAttribute for dynamic LDS beyond the default
 extern int g_scan_single_max;
 __host__ __device__ inline int splat_blocks(int Pa) { return (Pa + WG - 1) / WG; }
 int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st);

@@ -24,6 +24,14 @@ constexpr int SCAN_BLOCK = WG * SCAN_ITEMS;
 
 size_t scan_partials_count(int n, int batch) { return (size_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK) * batch; }
 
+// Dynamic LDS beyond the 64 KB a kernel gets by default has to be asked for (gfx950: 160 KB per CU).  The largest request here is
+// MAX_SUPER_TILES counters = 64 KB + the kernel's few static words.
+int allow_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return GS_OK;
+    GS_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return GS_OK;
+}
+
 __device__ inline uint32_t wave_incl_scan(uint32_t x) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -239,8 +247,9 @@ size_t colscan_partial_words(int Pa, int NST, int V) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
     extern __shared__ uint32_t sm[];
-    uint32_t* base = sm;            // [NST] first output position of this block in every super-tile's list
-    uint32_t* cur = sm + d.NST;     // [NST] entries of this block placed so far
+    uint32_t* cur = sm;             // [NST] next output position of this block in every super-tile's list: starts at the block's
+                                    //       first position there and is advanced by LDS atomics (one array: 64 KB at the 16384
+                                    //       super-tiles of an 8192 x 8192 render, 16 KB at 2048 x 2048 — it bounds the occupancy)
     const int i = blockIdx.x * WG + threadIdx.x;
     const int v = blockIdx.y;
     const size_t pv = (size_t)v * d.Pa;
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
             uint32_t total;
             const uint32_t ex = carry + block_excl_scan(c, &total);
             if (k < d.NST) {
-                base[k] = ex + row[k]; cur[k] = 0;
+                cur[k] = ex + row[k];
                 if (blockIdx.x == 0) cend[k] = ex + c;
             }
             carry += total;
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
     }
     const uint32_t tiles = i < d.P ? s.tiles_touched[pv + i] : 0u;
     // finish the offsets scan inside the block: exclusive prefix of the block (k_coarse_colscan's extra workgroup) + in-block scan
-    const uint32_t slot_base = s.block_sums[(size_t)v * splat_blocks(d.Pa) + blockIdx.x] + block_excl_scan(tiles, nullptr);  // syncs: base/cur are ready
+    const uint32_t slot_base = s.block_sums[(size_t)v * splat_blocks(d.Pa) + blockIdx.x] + block_excl_scan(tiles, nullptr);  // syncs: cur is ready
     if (i >= d.P) return;
     s.point_offsets[pv + i] = slot_base + tiles;
     if (tiles == 0 || (s.flags[v * 4 + 0] & 1u)) return;
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
     for (int sy = sy0; sy < sy1; sy++)
         for (int sx = sx0; sx < sx1; sx++) {
             const int st = sy * d.sgx + sx;
-            const uint32_t pos = base[st] + atomicAdd(&cur[st], 1u);  // LDS: the block owns [base, base + its count)
+            const uint32_t pos = atomicAdd(&cur[st], 1u);  // LDS: the block owns [its first position, + its count) of the list
             list[pos] = make_uint4((uint32_t)i, rmin, rmax, slot_base);
             dl[pos] = depth;
         }
@@ -287,7 +296,9 @@ __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
 
 int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.P == 0 || d.VG == 0) return GS_OK;
-    hipLaunchKernelGGL(k_coarse_scatter, dim3((d.P + WG - 1) / WG, d.VG), dim3(WG), 2 * (size_t)d.NST * sizeof(uint32_t), st, d, s);
+    const size_t lds = (size_t)d.NST * sizeof(uint32_t);
+    GS_TRY(allow_dynamic_lds((const void*)k_coarse_scatter, lds));
+    hipLaunchKernelGGL(k_coarse_scatter, dim3((d.P + WG - 1) / WG, d.VG), dim3(WG), lds, st, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -785,8 +796,9 @@ __global__ __launch_bounds__(GS_SORT_TILE_NT) void k_tile_build_sort(Dims d, Scr
     __shared__ __align__(16) uint64_t sk[SORT_TINY_CAP];
     __shared__ uint32_t sid[SORT_TINY_CAP];
     const int v = blockIdx.y;
-    const int tile = (int)s.tile_order[(size_t)v * d.T + d.small_first + blockIdx.x];  // (positions in front of small_first: k_tile_sort_mid)
     if (s.flags[v * 4 + 0] & 1u) return;  // overflowed view: nothing was scattered
+    const int tile = (int)s.tile_order[(size_t)v * d.T + d.small_first + blockIdx.x];  // (positions in front of small_first: k_tile_sort_mid)
+    if ((unsigned)tile >= (unsigned)d.T) return;  // never an address unless it is a tile (k_render_fwd)
     const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
     if (n == 0) return;
     if (n >= (uint32_t)SORT_TINY_CAP && (d.mid_sort || (d.long_sort && n >= (uint32_t)SORT_SMALL_CAP))) return;  // the next sorters' lists
@@ -812,6 +824,7 @@ __global__ __launch_bounds__(WG) void k_tile_sort_mid(Dims d, Scratch s) {
     const uint32_t idx = blockIdx.x;
     if (idx >= max(s.sort_marks[v * 2 + 1], (uint32_t)d.small_first)) return;
     const int tile = (int)s.tile_order[(size_t)v * d.T + idx];
+    if ((unsigned)tile >= (unsigned)d.T) return;
     const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
     if (!mid_sorter_owns(d, idx, n)) return;
     sort_tile<WG, SORT_SMALL_CAP, 256>(d, s, v, tile, n, sk, sid);
@@ -824,6 +837,7 @@ __global__ __launch_bounds__(WG) void k_tile_sort_mid_walk(Dims d, Scratch s, ui
     const uint32_t n_walk = max(s.sort_marks[v * 2 + 1], (uint32_t)d.small_first);
     for (uint32_t idx = first + blockIdx.x; idx < n_walk; idx += gridDim.x) {
         const int tile = (int)s.tile_order[(size_t)v * d.T + idx];
+        if ((unsigned)tile >= (unsigned)d.T) continue;
         const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
         if (!mid_sorter_owns(d, idx, n)) continue;
         sort_tile<WG, SORT_SMALL_CAP, 256>(d, s, v, tile, n, sk, sid);
@@ -842,6 +856,7 @@ __global__ __launch_bounds__(LONG_NT) void k_tile_sort_long(Dims d, Scratch s) {
     const uint32_t n_long = s.sort_marks[v * 2];
     for (uint32_t idx = blockIdx.x; idx < n_long; idx += gridDim.x) {
         const int tile = (int)s.tile_order[(size_t)v * d.T + idx];
+        if ((unsigned)tile >= (unsigned)d.T) continue;
         const uint32_t n = s.tile_count[(size_t)v * d.T + tile];
         if (n < (uint32_t)SORT_SMALL_CAP) continue;
         sort_tile<LONG_NT, SORT_LDS_CAP, 1024>(d, s, v, tile, n, sk, sid);

@@ -252,9 +252,24 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
 int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st) {
     if (d.P == 0 || d.VG == 0) return GS_OK;
     // cameras per block: as many as fit 32 KB of LDS histograms, at most GS_PREPROCESS_CAMERAS
+    // (one camera at a time beyond 8192 super-tiles: 64 KB of counters at the 16384 of an 8192 x 8192 render)
     const int cpb = std::max(1, std::min({ d.VG, GS_PREPROCESS_CAMERAS, (int)(32768 / ((size_t)d.NST * sizeof(uint32_t))) }));
     dim3 grid((d.P + WG - 1) / WG, (d.VG + cpb - 1) / cpb);
     const size_t lds = (size_t)cpb * d.NST * sizeof(uint32_t);
+    if (lds > 48 * 1024) {
+        const void* k = nullptr;
+        switch (d.D * 2 + (s.sh16 ? 1 : 0)) {
+            case 0: k = (const void*)k_preprocess<0, false>; break;
+            case 1: k = (const void*)k_preprocess<0, true>; break;
+            case 2: k = (const void*)k_preprocess<1, false>; break;
+            case 3: k = (const void*)k_preprocess<1, true>; break;
+            case 4: k = (const void*)k_preprocess<2, false>; break;
+            case 5: k = (const void*)k_preprocess<2, true>; break;
+            case 6: k = (const void*)k_preprocess<3, false>; break;
+            default: k = (const void*)k_preprocess<3, true>; break;
+        }
+        GS_TRY(allow_dynamic_lds(k, lds));
+    }
     if (s.sh16) {
         switch (d.D) {
             case 0: hipLaunchKernelGGL((k_preprocess<0, true>), grid, dim3(WG), lds, st, d, params, s, cpb); break;

@@ -80,12 +80,13 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
 #pragma clang fp contract(fast)
     __shared__ StagedTile<WG> st;
     const int v = blockIdx.y;  // v = geometry group (camera)
+    if (s.flags[v * 4 + 0] & 1u) return;  // overflowed arena: the binning skipped the group, tile_order / lists hold nothing of this step
 #ifdef GS_DIAG_XCD_STRIPES  // timing experiment: workgroups b, b+8, b+16 ... (one XCD) take a contiguous stripe of tiles, row-major
     const int tile = (int)((blockIdx.x % 8) * (d.T / 8) + blockIdx.x / 8);
 #else
     const int tile = (int)s.tile_order[(size_t)v * d.T + blockIdx.x];
 #endif
-    if (s.flags[v * 4 + 0] & 1u) return;
+    if ((unsigned)tile >= (unsigned)d.T) return;  // an order that is not a permutation of the tiles must never become an address (round-3 fault)
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int bx0 = tx * TILE + (wave & 1) * 8, by0 = ty * TILE + (wave >> 1) * 8;
@@ -342,6 +343,7 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
 #pragma unroll
     for (int q = 0; q < F; q++) vin[q] = item[1 + q];
     if (s.flags[g * 4 + 0] & 1u) return;
+    if ((unsigned)tile >= (unsigned)d.T) return;  // see k_render_fwd
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the per-wave roles below are scalar branches

@@ -201,6 +201,30 @@ class Trainer:
         capi.check(capi.lib().gs_trainer_read_image(self.handle, local_view, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def adam_state(self):
+        """gs_trainer_adam_state: (moment1, moment2, steps) as host arrays [(11 + 3M) * plane stride] — or (None, None, 0)
+        before the first Adam step.  Together with the model this is what a checkpoint of an Adam run holds."""
+        m, v, n, steps = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_int()
+        capi.check(capi.lib().gs_trainer_adam_state(self.handle, C.byref(m), C.byref(v), C.byref(n), C.byref(steps)))
+        if not m.value:
+            return None, None, 0
+        out = []
+        for p in (m, v):
+            a = np.empty(n.value, np.float32)
+            capi.check(capi.lib().gs_memcpy_d2h(a.ctypes.data_as(C.c_void_p), p, n.value * 4))
+            out.append(a)
+        return out[0], out[1], steps.value
+
+    def set_adam_state(self, moment1, moment2, steps):
+        """gs_trainer_set_adam_state: resume an Adam run (call after assigning .model, which resets the optimizer state)."""
+        if moment1 is None:
+            capi.check(capi.lib().gs_trainer_set_adam_state(self.handle, None, None, 0, 0, 0))
+            return
+        m1 = np.ascontiguousarray(moment1, np.float32).reshape(-1)
+        m2 = np.ascontiguousarray(moment2, np.float32).reshape(-1)
+        assert m1.size == m2.size
+        capi.check(capi.lib().gs_trainer_set_adam_state(self.handle, m1.ctypes.data_as(C.c_void_p), m2.ctypes.data_as(C.c_void_p), m1.size, int(steps), 0))
+
     def grad_buffer(self):
         p, n = C.c_void_p(), C.c_size_t()
         capi.check(capi.lib().gs_trainer_grad_buffer(self.handle, C.byref(p), C.byref(n)))

@@ -197,7 +197,11 @@ int gs_trainer_step(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs_
 /* The same step split at the point where data-parallel ranks exchange gradients:
  *   gs_trainer_accumulate : src/Trainer.cu:303-425 for the local passes
  *   gs_trainer_grad_buffer: the averaged-gradient buffer [loc 3 | sh 3M | scale 3 | opacity 1 |
- *                           rot 4 | var 1] planes x plane stride floats, contiguous, fp32 (device)
+ *                           rot 4 | var 1] planes x plane stride floats, contiguous, fp32 (device).
+ *                           The `var` plane holds accumulateGradients' var (src/Trainer.cu:52) after
+ *                           gs_trainer_accumulate and after a gs_trainer_step WITH densify; a
+ *                           gs_trainer_step without densify leaves it ZERO (option "fuse_camera_passes":
+ *                           the reference itself reads var only inside the densify block, :444,453)
  *   gs_trainer_apply      : src/Trainer.cu:427-542 (update, optional densify) */
 int gs_trainer_accumulate(gs_trainer* trainer, gs_step_stats* stats);
 int gs_trainer_grad_buffer(gs_trainer* trainer, float** device_ptr, size_t* n_floats);
@@ -225,6 +229,16 @@ int gs_trainer_set_option(gs_trainer* trainer, const char* name, int value);
  * split and a clone's twin start from the parent's moments) and the step counter keeps running; replacing the model
  * (gs_trainer_set_model) resets both.  Synchronises the trainer's stream. */
 int gs_trainer_adam_state(gs_trainer* trainer, float** moment1, float** moment2, size_t* n_floats, int* steps);
+/* The other direction — resume of an Adam run from a checkpoint (the reference's .gobj / settings.json hold
+ * no optimizer state because its update rule has none; src/ui/UiFrame.cpp:323-358 save, :373-450 load): installs the two
+ * moments (n_floats each = (11 + 3M) x the plane stride of the trainer's CURRENT model, the layout gs_trainer_adam_state
+ * reports; host pointers, or device pointers when on_device != 0; copied before return) and the number of Adam steps
+ * already taken.  Call it after gs_trainer_set_model (which resets the state).  Model + moments + step counter restored,
+ * the next steps equal the uninterrupted run's bit for bit (tests/test_gpu_trainer.py::test_adam_state_restore_resumes_bit_exact).
+ * moment1 == moment2 == NULL with steps == 0 clears the state.  Not available under the sharded update (each rank holds
+ * its own chunk's moments only). */
+int gs_trainer_set_adam_state(gs_trainer* trainer, const float* moment1, const float* moment2, size_t n_floats, int steps,
+                              int on_device);
 
 /* Collective hook called by gs_trainer_step between accumulate and apply: must sum `n_floats`
  * fp32 values at `device_buf` in place over all ranks, enqueued on `hip_stream`.  Return 0 on success. */

@@ -183,6 +183,43 @@ public:
         out[11] = -1.0f;
         out[14] = -(2.0f * zFar * zNear) / (zFar - zNear);
     }
+    // Camera::getCamerasCount / getCameras / getPreviewCamera, src/Camera.cpp:29-74.  Templates over the project type: the
+    // reference's own Project (src/Project.h) fits, and so does gsplat_shim::Project below.
+    template <class ProjectT> static int getCamerasCount(const ProjectT& project) { return project.sphere1.count + project.sphere2.count; }
+    // two Fibonacci spheres (:9-27), each turned by angleAxis(radians(rotX), +Y) * angleAxis(radians(rotY), +X) (:40-41,49-50)
+    template <class ProjectT> static std::vector<Camera> getCameras(const ProjectT& project) {
+        std::vector<Camera> out;
+        out.reserve((size_t)getCamerasCount(project));
+        const auto sphere = [&out](int count, float distance, float fovDeg, float rotX, float rotY) {
+            float rot[3][3];
+            orbit(rotX * kRadians, rotY * kRadians, rot);
+            const float goldenRatio = (1.0f + std::sqrt(5.0f)) / 2.0f;
+            const float angleStep = 2.0f * 3.14159265358979323846f * goldenRatio;
+            for (int i = 0; i < count; i++) {
+                const float t = (float)i / (float)count;
+                const float angle1 = std::acos(1.0f - 2.0f * t), angle2 = angleStep * (float)i;
+                const float p[3] = { std::sin(angle1) * std::cos(angle2) * distance, std::sin(angle1) * std::sin(angle2) * distance, std::cos(angle1) * distance };
+                out.push_back(turned(rot, p, fovDeg));
+            }
+        };
+        sphere(project.sphere1.count, project.sphere1.distance, project.sphere1.fovDeg, project.sphere1.rotX, project.sphere1.rotY);
+        sphere(project.sphere2.count, project.sphere2.distance, project.sphere2.fovDeg, project.sphere2.rotX, project.sphere2.rotY);
+        return out;
+    }
+    // The camera every Trainer::render caller of the reference builds (src/ui/UiPanelViewOutput.cpp:52-60,
+    // src/ui/tools/UiPanelToolsView.cpp:250): one of the truth cameras (previewTruth, .at() throws past the end like the
+    // reference's), or the free camera — (0, 0, -previewFreeDistance) turned by angleAxis(radians(previewFreeRotY) + orbit, +Y)
+    // * angleAxis(radians(previewFreeRotX), +X), where the reference adds previewTimer * previewFreeOrbitSpeed to the angle
+    // AFTER the conversion to radians (src/Camera.cpp:68-69: the "degRotOrbit" term is used as radians; kept as is).
+    template <class ProjectT> static Camera getPreviewCamera(const ProjectT& project) {
+        if (project.previewTruth) return getCameras(project).at((size_t)project.previewTruthIndex);
+        const float degRotOrbit = project.previewFreeOrbit ? project.previewTimer * project.previewFreeOrbitSpeed : 0.0f;
+        float rot[3][3];
+        orbit(project.previewFreeRotY * kRadians + degRotOrbit, project.previewFreeRotX * kRadians, rot);
+        const float p[3] = { 0.0f, 0.0f, -project.previewFreeDistance };
+        return turned(rot, p, project.previewFreeFovDeg);
+    }
+
     // One pass of this camera as the trainer passes it to the rasterizer (src/Trainer.cu:317-326, :355-356): view,
     // projection * view, camera position, tan(fov / 2) on both axes, background.
     gs_view pass(int width, int height, float background) const {
@@ -200,6 +237,26 @@ public:
     }
 
 private:
+    static constexpr float kRadians = 0.01745329251994329576923690768489f;  // glm::radians
+    // (glm::mat4)glm::angleAxis(angle, axis) for a unit axis, as a row-major 3x3
+    static void angleAxis(float angle, float ax, float ay, float az, float m[3][3]) {
+        const float sn = std::sin(angle * 0.5f), w = std::cos(angle * 0.5f), x = ax * sn, y = ay * sn, z = az * sn;
+        m[0][0] = 1.0f - 2.0f * (y * y + z * z); m[0][1] = 2.0f * (x * y - w * z); m[0][2] = 2.0f * (x * z + w * y);
+        m[1][0] = 2.0f * (x * y + w * z); m[1][1] = 1.0f - 2.0f * (x * x + z * z); m[1][2] = 2.0f * (y * z - w * x);
+        m[2][0] = 2.0f * (x * z - w * y); m[2][1] = 2.0f * (y * z + w * x); m[2][2] = 1.0f - 2.0f * (x * x + y * y);
+    }
+    // angleAxis(aboutY, +Y) * angleAxis(aboutX, +X)
+    static void orbit(float aboutY, float aboutX, float out[3][3]) {
+        float a[3][3], b[3][3];
+        angleAxis(aboutY, 0.0f, 1.0f, 0.0f, a);
+        angleAxis(aboutX, 1.0f, 0.0f, 0.0f, b);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) out[r][c] = a[r][0] * b[0][c] + a[r][1] * b[1][c] + a[r][2] * b[2][c];
+    }
+    static Camera turned(const float rot[3][3], const float p[3], float fovDeg) {
+        return Camera(rot[0][0] * p[0] + rot[0][1] * p[1] + rot[0][2] * p[2], rot[1][0] * p[0] + rot[1][1] * p[1] + rot[1][2] * p[2],
+                      rot[2][0] * p[0] + rot[2][1] * p[1] + rot[2][2] * p[2], 0.0f, 0.0f, 0.0f, fovDeg);
+    }
     static float dot(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
     static void cross(const float a[3], const float b[3], float o[3]) {
         o[0] = a[1] * b[2] - b[1] * a[2]; o[1] = a[2] * b[0] - b[2] * a[0]; o[2] = a[0] * b[1] - b[0] * a[1];
@@ -210,7 +267,12 @@ private:
 // The run-time hyper-parameters of src/Project.h:24-45 under the reference's names and defaults (the GUI / JSON
 // fields of the reference's Project are not needed by this path).  Trainer::train is a template over the project
 // type, so the reference's own Project class works unchanged.
+struct CameraSphere {  // Project::CameraSphere, src/Project.h:14-22
+    int count = 16;
+    float distance = 10.0f, fovDeg = 60.0f, rotX = 0.0f, rotY = 0.0f;
+};
 struct Project {
+    CameraSphere sphere1, sphere2;  // (UiFrame::initProject empties the second one: count 0, fovDeg 30, src/ui/UiFrame.cpp:129-134)
     float lrLocation = 0.00005f, lrSh = 0.0001f, lrScale = 0.00002f, lrOpacity = 0.0001f, lrRotation = 0.000025f;
     float paramScaleMax = 0.3f;
     float paramCullOpacity = 0.005f, paramCullSize = 0.004f, paramDensifyVariance = 2.0f;
@@ -218,7 +280,13 @@ struct Project {
     int iterations = 0;
     int intervalCapture = 50;
     int intervalDensify = 200;
+    // the preview camera's fields (src/Project.h:47-58), read by Camera::getPreviewCamera
+    float previewTimer = 0.0f;
     float previewSplatScale = 1.0f;
+    bool previewTruth = false;
+    int previewTruthIndex = 0;
+    bool previewFreeOrbit = true;
+    float previewFreeOrbitSpeed = 0.5f, previewFreeDistance = 10.0f, previewFreeFovDeg = 60.0f, previewFreeRotX = 25.0f, previewFreeRotY = 0.0f;
 };
 
 class Trainer {
@@ -324,6 +392,22 @@ public:
         hy.update_rule = updateRule; hy.adam_beta1 = adamBeta1; hy.adam_beta2 = adamBeta2; hy.adam_eps = adamEps;
         hy.quat_layout = quatLayout;
         return hy;
+    }
+
+    // Optimizer state of GS_UPDATE_ADAM for checkpoint / resume (build-side extension: the reference's update rule has no state).
+    // adamState: host copies of the two moments + the number of Adam steps (empty vectors before the first Adam step);
+    // setAdamState: installs them again — after `model` was assigned, which resets the state.
+    int adamState(std::vector<float>& moment1, std::vector<float>& moment2) {
+        float *m1 = nullptr, *m2 = nullptr; size_t n = 0; int steps = 0;
+        check(gs_trainer_adam_state(handle, &m1, &m2, &n, &steps));
+        moment1.assign(m1 ? n : 0, 0.0f); moment2.assign(m2 ? n : 0, 0.0f);
+        if (m1) { check(gs_memcpy_d2h(moment1.data(), m1, n * sizeof(float))); check(gs_memcpy_d2h(moment2.data(), m2, n * sizeof(float))); }
+        return steps;
+    }
+    void setAdamState(const std::vector<float>& moment1, const std::vector<float>& moment2, int steps) {
+        syncModel();
+        if (moment1.size() != moment2.size()) throw std::runtime_error("setAdamState: the two moments differ in size");
+        check(gs_trainer_set_adam_state(handle, moment1.empty() ? nullptr : moment1.data(), moment2.empty() ? nullptr : moment2.data(), moment1.size(), steps, 0));
     }
 
     gs_trainer* native() { return handle; }

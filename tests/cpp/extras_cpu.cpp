@@ -47,6 +47,25 @@ int main(int argc, char** argv) {
         if (m->count != 1 || m->locations[0] != 1.0f || m->locations[1] != 2.0f || m->locations[2] != 0.0f) return 8;
         if (m->scales[0] != 1.0f || m->scales[1] != 0.0f || m->scales[2] != 0.0f || m->opacities[0] != 0.0f || m->rotations[0] != 1.0f) return 8;
     }
+    {   // Camera::getCameras / getPreviewCamera (src/Camera.cpp:33-74): written out for the Python mirror to compare with
+        Project pr;
+        pr.sphere1.count = 5; pr.sphere1.rotX = 40.0f; pr.sphere1.rotY = -15.0f;
+        pr.sphere2.count = 3; pr.sphere2.distance = 6.0f; pr.sphere2.fovDeg = 30.0f; pr.sphere2.rotX = 200.0f;
+        pr.previewTimer = 2.5f; pr.previewFreeRotY = 30.0f; pr.previewFreeDistance = 7.0f; pr.previewFreeFovDeg = 45.0f;
+        FILE* f = fopen((dir + "/cpp_cameras.txt").c_str(), "w");
+        if (!f) return 9;
+        auto put = [f](const Camera& c) { fprintf(f, "%.9g %.9g %.9g %.9g\n", c.location[0], c.location[1], c.location[2], c.fovDegY); };
+        if (Camera::getCamerasCount(pr) != 8) return 9;
+        for (const Camera& c : Camera::getCameras(pr)) put(c);
+        put(Camera::getPreviewCamera(pr));                          // free camera, orbiting
+        pr.previewFreeOrbit = false; put(Camera::getPreviewCamera(pr));
+        pr.previewTruth = true; pr.previewTruthIndex = 6; put(Camera::getPreviewCamera(pr));
+        pr.previewTruthIndex = 8;
+        bool past_end = false;
+        try { Camera::getPreviewCamera(pr); } catch (const std::out_of_range&) { past_end = true; }
+        fclose(f);
+        if (!past_end) return 9;
+    }
     printf("extras ok\n");
     return 0;
 }

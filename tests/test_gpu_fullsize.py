@@ -74,6 +74,10 @@ def test_lists_are_the_stable_sort_and_blend_identity(idx):
     views = gs.camera.train_views(cams, W, H)
     n_cams = len(cams)
     vw, vb = view_parts(views[1]), view_parts(views[n_cams + 1])   # camera 1, white and black background
+    _check_lists_and_blend_identity(s, P, M, D, W, H, vw, vb)
+
+
+def _check_lists_and_blend_identity(s, P, M, D, W, H, vw, vb):
     sr = SeamRaster()
     out_w, R = sr.forward(s, D, M, vw, W, H)
     tt = sr.field("geometry", "tiles_touched", np.uint32)
@@ -81,7 +85,7 @@ def test_lists_are_the_stable_sort_and_blend_identity(idx):
     rec = sr.field("geometry", "record", np.uint8).view(REC_DTYPE)
     pl = sr.field("binning", "point_list", np.uint32)
     ranges = sr.field("image", "ranges", np.uint32).reshape(-1, 2).astype(np.int64)
-    assert R > P and int(tt.sum(dtype=np.int64)) == R == int(po[-1])
+    assert R > 0 and int(tt.sum(dtype=np.int64)) == R == int(po[-1])
     assert np.array_equal(np.cumsum(tt, dtype=np.uint64).astype(np.uint32), po)
     # ranges: non-empty tiles partition [0, R) in tile order
     ne = ranges[ranges[:, 1] > ranges[:, 0]]
@@ -110,6 +114,36 @@ def test_lists_are_the_stable_sort_and_blend_identity(idx):
     assert Rb == R and np.array_equal(sb.field("binning", "point_list", np.uint32), pl)
     for c in range(3):
         assert np.abs((out_w[c] - out_b[c]).reshape(-1) - fT).max() <= 2e-7 * max(1.0, float(out_w[c].max()))
+
+
+@pytest.mark.parametrize("W,H,P", [(8192, 8192, 20000), (8192, 16, 20000)])
+def test_render_at_the_reference_maximum_size(orc, W, H, P):
+    """The reference's "Render Splats" tool offers up to 8192 x 8192 (src/ui/tools/UiPanelToolsView.cpp:120,125; call at
+    :249-250): 16384 super-tiles of 64 x 64 px, 262144 tiles (the three-phase tile scan, one LDS counter per super-tile =
+    64 KB in the projection and the coarse scatter).  The lists are the stable sort at that size too, and Trainer::render
+    delivers imageFloatToInt of the very picture the rasterizer seam computes."""
+    M, D = 4, 1
+    s = gs.synth.random_splats(P, M, 8192 + H)
+    cam = gs.camera.get_cameras(3)[1]
+    import math
+    blk_w = gs.camera.view_block(cam, W, H, white=True)
+    blk_b = gs.camera.view_block(cam, W, H, white=False)
+    if H == 16:   # a 512 : 1 strip: keep the horizontal field sane (the reference's tan_fovx formula is its caller's business)
+        for b in (blk_w, blk_b):
+            b[35] = np.float32(1.0)
+    _check_lists_and_blend_identity(s, P, M, D, W, H, view_parts(blk_w), view_parts(blk_b))
+    # Trainer::render (src/Trainer.cu:148-216) on the same pass parameters
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = D
+    tr = gs.Trainer(W, H)
+    tr.model = gs.ModelSplatsDevice(host)
+    v = capi.view_from_block(blk_b)
+    fb = np.zeros(W * H, np.uint32)
+    capi.check(capi.lib().gs_trainer_render(tr.handle, fb.ctypes.data_as(C.c_void_p), 0, W, H, C.c_float(1.0), C.byref(v)))
+    tr.close()
+    out_b, _ = SeamRaster().forward(s, D, M, view_parts(blk_b), W, H)
+    assert np.array_equal(fb, orc.image_float_to_int(out_b, W, H))
+    assert len(np.unique(fb)) > 100   # a picture, not a constant
 
 
 def test_backward_is_exactly_linear_under_doubling_cfg3():

@@ -49,9 +49,11 @@ def test_no_gpu_means_loud_failure_not_fallback():
 
 
 def test_resolution_limits_are_argument_errors_not_crashes():
-    """The binning keeps one LDS counter per 64x64-px super-tile (8192 of them): larger images are refused up front,
-    with or without a GPU (the check precedes the device check)."""
-    for w, h in [(0, 64), (64, -1), (16384, 16384), (8192, 4160)]:
+    """The binning keeps one LDS counter per 64x64-px super-tile (16384 of them = 8192 x 8192 px, the largest render the
+    reference's UI offers, src/ui/tools/UiPanelToolsView.cpp:120,125): larger images are refused up front, with or
+    without a GPU (the check precedes the device check).  8192 x 8192 itself is accepted (tests/test_gpu_fullsize.py
+    renders it on the GPU)."""
+    for w, h in [(0, 64), (64, -1), (16384, 16384), (8192, 8256), (16448, 4096)]:
         with pytest.raises(capi.GsError) as e:
             gs.Trainer(w, h)
         assert e.value.status == -1, (w, h, str(e.value))   # GS_ERR_INVALID_ARGUMENT

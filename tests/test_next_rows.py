@@ -88,6 +88,28 @@ def test_two_sphere_camera_rig():
     assert np.allclose(rot[:, 0], base[:, 2], atol=1e-4) and np.allclose(rot[:, 2], -base[:, 0], atol=1e-4)
 
 
+def test_preview_camera():
+    """Camera::getPreviewCamera, src/Camera.cpp:60-74: truth-index mode and the free (orbiting) camera."""
+    p = gs.Project.initProject()
+    assert (p.previewTruth, p.previewFreeOrbit, p.previewFreeDistance, p.previewFreeRotX) == (False, True, 10.0, 25.0)   # src/Project.h:50-58
+    c = gs.camera.get_preview_camera(p)               # timer 0: no orbit; rotX = 25 degrees about +X lifts the camera
+    assert np.allclose(c.location, [0.0, 10.0 * np.sin(np.radians(25.0)), -10.0 * np.cos(np.radians(25.0))], atol=1e-5)
+    assert c.fovDegY == 60.0 and np.allclose(c.target, 0.0)
+    p.previewTimer, p.previewFreeOrbitSpeed = 3.0, 0.5  # the orbit term is ADDED TO RADIANS as it is (src/Camera.cpp:68-69): 1.5 rad about +Y
+    o = gs.camera.get_preview_camera(p)
+    assert np.isclose(np.linalg.norm(o.location), 10.0, atol=1e-4) and np.isclose(o.location[1], c.location[1], atol=1e-5)
+    ang = np.arctan2(o.location[0], o.location[2]) - np.arctan2(c.location[0], c.location[2])
+    assert np.isclose((ang + np.pi) % (2 * np.pi) - np.pi, 1.5, atol=1e-4)
+    p.previewFreeOrbit = False
+    assert np.allclose(gs.camera.get_preview_camera(p).location, c.location, atol=1e-6)
+    p.previewTruth, p.previewTruthIndex, p.sphere1.count = True, 2, 4
+    t = gs.camera.get_preview_camera(p)
+    assert np.array_equal(t.location, gs.camera.get_cameras_project(p)[2].location) and t.fovDegY == p.sphere1.fovDeg
+    p.previewTruthIndex = 4                            # getCameras(project).at(index) throws past the end
+    with pytest.raises(IndexError):
+        gs.camera.get_preview_camera(p)
+
+
 class _FakeTrainer:
     def __init__(self):
         self.calls = []
@@ -158,6 +180,19 @@ def test_cpp_extras_header_and_gobj_interop(tmp_path):
     (tmp_path / "mesh.obj").write_text(obj)
     out = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "extras ok" in out.stdout, (out.returncode, out.stderr)
+    # cameras: the C++ rig and preview camera against camera.py (same formulas in fp32; sin / cos of two libms)
+    pr = gs.Project.initProject()
+    pr.sphere1.count, pr.sphere1.rotX, pr.sphere1.rotY = 5, 40.0, -15.0
+    pr.sphere2.count, pr.sphere2.distance, pr.sphere2.fovDeg, pr.sphere2.rotX = 3, 6.0, 30.0, 200.0
+    pr.previewTimer, pr.previewFreeRotY, pr.previewFreeDistance, pr.previewFreeFovDeg = 2.5, 30.0, 7.0, 45.0
+    want = [c for c in gs.camera.get_cameras_project(pr)] + [gs.camera.get_preview_camera(pr)]
+    pr.previewFreeOrbit = False
+    want.append(gs.camera.get_preview_camera(pr))
+    pr.previewTruth, pr.previewTruthIndex = True, 6
+    want.append(gs.camera.get_preview_camera(pr))
+    got = np.loadtxt(tmp_path / "cpp_cameras.txt")
+    assert got.shape == (11, 4)
+    assert np.allclose(got[:, :3], [c.location for c in want], atol=2e-5) and np.array_equal(got[:, 3], [c.fovDegY for c in want])
     # copy of a Python-written file: the same bytes as Python's own load -> save
     gs.io.saveSplats(tmp_path / "py_copy.gobj", gs.io.loadSplats(tmp_path / "py.gobj"))
     assert (tmp_path / "cpp_copy.gobj").read_bytes() == (tmp_path / "py_copy.gobj").read_bytes()
