@@ -57,7 +57,7 @@ SYMBOLS = [
     "gs_trainer_destroy", "gs_trainer_set_model", "gs_trainer_get_model", "gs_trainer_set_views", "gs_trainer_step",
     "gs_trainer_accumulate", "gs_trainer_grad_buffer", "gs_trainer_apply", "gs_trainer_set_allreduce",
     "gs_trainer_get_stream", "gs_trainer_synchronize", "gs_trainer_render", "gs_trainer_read_image",
-    "gs_trainer_set_option", "gs_trainer_set_sharded_update", "gs_trainer_attach_comm_sharded", "gs_trainer_set_profiling", "gs_trainer_stage_times", "gs_stage_name", "gs_trainer_adam_state", "gs_trainer_set_adam_state",
+    "gs_trainer_set_option", "gs_trainer_set_sharded_update", "gs_trainer_attach_comm_sharded", "gs_trainer_set_compact_exchange", "gs_trainer_attach_comm_compact", "gs_trainer_set_profiling", "gs_trainer_stage_times", "gs_stage_name", "gs_trainer_adam_state", "gs_trainer_set_adam_state",
     "gs_comm_unique_id", "gs_comm_create", "gs_comm_destroy", "gs_trainer_attach_comm", "gs_rasterize_forward",
     "gs_rasterize_backward", "gs_raster_chunk_field", "gs_image_float_to_int", "gs_image_int_to_loss",
 ]
@@ -119,6 +119,8 @@ def lib():
     L.gs_trainer_attach_comm.argtypes = [vp, vp]
     L.gs_trainer_attach_comm_sharded.argtypes = [vp, vp]
     L.gs_trainer_set_sharded_update.argtypes = [vp, vp, vp, vp, i, i]
+    L.gs_trainer_set_compact_exchange.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    L.gs_trainer_attach_comm_compact.argtypes = [vp, vp, vp, i, vp]
     L.gs_rasterize_forward.argtypes = [ALLOC_FN, vp, ALLOC_FN, vp, ALLOC_FN, vp, i, i, i, vp, i, i, vp, vp, vp, vp, vp, f,
                                        vp, vp, vp, vp, vp, f, f, i, vp, vp, i, C.POINTER(i)]
     L.gs_rasterize_backward.argtypes = [i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, vp, vp, vp, vp,

@@ -32,6 +32,7 @@ struct Options {
     int sh_fp16 = 0;     // the projection reads SH coefficients from a half-precision copy (BASELINE cfg5); fp32 master and gradients
     int long_sort = -1;  // k_tile_sort_long launch: -1 by the longest-list hint (default), 0 never (lists take the global-scratch path), 1 always
     int sort_grids = -1; // test hook: >= 0 replaces the device's hint for the sort grids: small_first | mid_grid << 16 (in tiles)
+    int xchg_overlap = 1; // compact exchange: the all-reduce of the geometry planes runs on a second stream beside the all-gather (0: one after the other)
 };
 static Options g_defaults;
 // returns false for an unknown name
@@ -44,6 +45,7 @@ static bool set_option(Options& o, const char* name, int value) {
     if (strcmp(name, "sh_fp16") == 0) { o.sh_fp16 = value != 0; return true; }
     if (strcmp(name, "long_list_sort_launch") == 0) { o.long_sort = value < 0 ? -1 : (value != 0); return true; }
     if (strcmp(name, "debug_sort_grids") == 0) { o.sort_grids = value < 0 ? -1 : value; return true; }
+    if (strcmp(name, "exchange_overlap") == 0) { o.xchg_overlap = value != 0; return true; }
     return false;
 }
 
@@ -471,6 +473,15 @@ struct gs_trainer {
     gs_collective_fn shard_rs = nullptr, shard_ag = nullptr;  // sharded update (gs_trainer_set_sharded_update)
     void* shard_user = nullptr;
     int shard_rank = 0, shard_world = 1;
+    // compact exchange (gs_trainer_set_compact_exchange): all-gather of dL_dRGB records + all-reduce of the twelve non-SH planes
+    gs_collective_fn xchg_gather = nullptr;
+    gs_allreduce_fn xchg_reduce = nullptr;
+    void* xchg_user = nullptr;
+    int xchg_rank = 0, xchg_world = 1, xchg_cameras = 0;
+    void* xchg_comms[2] = { nullptr, nullptr };  // gs_trainer_attach_comm_compact: the communicators of the all-gather and of the all-reduce
+    DevBuf xgeo, xrgb, xcampos;
+    hipStream_t stream2 = nullptr;           // carries the all-reduce beside the all-gather
+    hipEvent_t ev_packed = nullptr, ev_reduced = nullptr;
     gs_step_stats last{};
     bool accumulated = false;
     // optional per-stage HIP-event timing (bench / roofline evidence)
@@ -569,6 +580,10 @@ extern "C" int gs_trainer_destroy(gs_trainer* t) {
     gs_model_destroy(t->model);
     t->truth.release(); t->grad.release(); t->adam_m.release(); t->adam_v.release(); t->sh16.release(); t->densify_work.release();
     t->spare_planes.release(); t->spare_m.release(); t->spare_v.release();
+    t->xgeo.release(); t->xrgb.release(); t->xcampos.release();
+    if (t->stream2) { (void)hipStreamSynchronize(t->stream2); (void)hipStreamDestroy(t->stream2); }
+    if (t->ev_packed) (void)hipEventDestroy(t->ev_packed);
+    if (t->ev_reduced) (void)hipEventDestroy(t->ev_reduced);
     t->train.release(); t->preview.release();
     if (t->h_flags) (void)hipHostFree(t->h_flags);
     if (t->ev_flags) (void)hipEventDestroy(t->ev_flags);
@@ -658,7 +673,9 @@ static int resolve_stats(gs_trainer* t) {
 // gradients in t->grad.  The only host wait is on the arena-overflow flags, which the device publishes right after the
 // projection (a few tens of microseconds into the step, while the rest of the step is already queued behind it): on
 // return the stream is still busy.  An overflowing arena is grown and the iteration replayed.
-static int accumulate_async(gs_trainer* t, bool need_var) {
+// xchg != null (compact exchange): the per-splat stage leaves the rank's share of the exchange in *xchg's buffers instead of
+// gradient planes (k_sh_rebuild writes those after the collectives); xchg->slots is set here for the form the step takes.
+static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullptr) {
     if (t->V == 0 && t->total_samples <= 0) { set_error("Can't run training iteration, no truth data available!"); return GS_ERR_NO_TRUTH; }
     if (!t->model) return GS_ERR_NO_MODEL;
     GS_HIP(hipSetDevice(t->device));
@@ -781,8 +798,9 @@ static int accumulate_async(gs_trainer* t, bool need_var) {
             prof_stage_end(t, 5);
             GS_TRY(debug_check(t, 5));
             prof_stage_begin(t, 6, 5);
+            if (xchg) xchg->slots = ((t->xchg_cameras + t->xchg_world - 1) / t->xchg_world) * (fuse ? 1 : 2);
             GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), items, t->bwd_pairs,
-                                             t->bwd_singles, fuse, t->stream));
+                                             t->bwd_singles, fuse, t->stream, xchg));
             prof_stage_end(t, 6);
             GS_TRY(debug_check(t, 6));
         }
@@ -943,10 +961,94 @@ static int shard_call(gs_trainer* t, gs_collective_fn fn, float* buf, size_t n, 
     return GS_OK;
 }
 
+// The data-parallel step with the compact exchange.  48 of cfg3's 60 gradient planes are SH gradients, and a record's SH
+// gradient of a splat is rank one (basis(view direction)[M] x dL_dRGB[3], src/Trainer.cu:51-76 as k_splat_bwd_reduce rebuilds
+// it): instead of all-reducing (12 + 3M) P floats the ranks all-gather their records' dL_dRGB (3 floats per record and splat)
+// and all-reduce the twelve other planes; every rank then rebuilds the SH planes from ALL records in the single-GPU order.
+//   main stream:    ... per-splat backward + pack -> [all-gather dL_dRGB] ---------------> wait -> k_sh_rebuild -> update
+//   second stream:                     wait(packed) -> [all-reduce geometry planes] -> (reduced)
+// cfg3 on 8 ranks: 8.4 + 8.4 MB received per rank instead of the 42 MB a ring all-reduce of 24 MB moves; the SH gradients
+// are the single-GPU step's bit for bit (the collective sums only the geometry planes).
+static int step_compact_exchange(gs_trainer* t, const gs_hyper* h, int densify, gs_step_stats* stats) {
+    if (!t->model) return GS_ERR_NO_MODEL;
+    GS_HIP(hipSetDevice(t->device));
+    gs_model* m = t->model;
+    const int C_ = t->xchg_cameras, G = t->xchg_world;
+    const int mine = (C_ - t->xchg_rank + G - 1) / G;   // cameras c with c % world == rank
+    if (t->bwd_singles != 0 || t->VG != mine || t->V != 2 * mine || t->total_samples != 2 * C_) {
+        set_error("compact exchange: rank %d of %d must hold both passes of its %d of the iteration's %d cameras (camera c on rank c %% world) "
+                  "and total_samples = 2 x cameras; the views set are %d passes in %d camera groups (%d unpaired), total_samples %d",
+                  t->xchg_rank, G, mine, C_, t->V, t->VG, t->bwd_singles, t->total_samples);
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    const int cmax = (C_ + G - 1) / G;
+    const size_t Pa = (size_t)m->Pa;
+    GS_TRY(t->xgeo.ensure(12 * Pa * 4));
+    GS_TRY(t->xrgb.ensure((size_t)G * 2 * cmax * 3 * Pa * 4));
+    Exchange x;
+    x.geo = t->xgeo.as<float>(); x.rgb = t->xrgb.as<float>(); x.rank = t->xchg_rank; x.world = G;
+    GS_TRY(accumulate_async(t, densify != 0, &x));   // sets x.slots for the form this step takes
+    const bool per_pass = x.slots == 2 * cmax;
+    if (m->count > 0) {
+        if (!t->stream2) GS_HIP(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+        if (!t->ev_packed) { GS_HIP(hipEventCreateWithFlags(&t->ev_packed, hipEventDisableTiming)); GS_HIP(hipEventCreateWithFlags(&t->ev_reduced, hipEventDisableTiming)); }
+        const bool overlap = t->opt.xchg_overlap != 0;
+        prof_stage_begin(t, 8, 6);
+        int rc = 0;
+        if (overlap) {
+            GS_HIP(hipEventRecord(t->ev_packed, t->stream));
+            GS_HIP(hipStreamWaitEvent(t->stream2, t->ev_packed, 0));
+            rc = t->xchg_reduce(x.geo, 12 * Pa, (void*)t->stream2, t->xchg_user);
+            if (rc == 0) GS_HIP(hipEventRecord(t->ev_reduced, t->stream2));
+        }
+        if (rc != 0) { set_error("all-reduce (geometry planes) hook failed with %d", rc); return GS_ERR_COLLECTIVE; }
+        rc = t->xchg_gather(x.rgb, (size_t)G * x.slots * 3 * Pa, (void*)t->stream, t->xchg_user);
+        if (rc != 0) { set_error("all-gather (dL_dRGB records) hook failed with %d", rc); return GS_ERR_COLLECTIVE; }
+        if (overlap) GS_HIP(hipStreamWaitEvent(t->stream, t->ev_reduced, 0));
+        else {
+            rc = t->xchg_reduce(x.geo, 12 * Pa, (void*)t->stream, t->xchg_user);
+            if (rc != 0) { set_error("all-reduce (geometry planes) hook failed with %d", rc); return GS_ERR_COLLECTIVE; }
+        }
+        prof_stage_end(t, 8);
+        GS_TRY(debug_check(t, 8));
+        Dims d;
+        GS_TRY(trainer_dims(t, &d));
+        prof_stage_begin(t, 6, 8);
+        GS_TRY(launch_sh_rebuild(d, m->planes, x, t->xcampos.as<float>(), C_, per_pass, (float)t->total_samples, t->grad.as<float>(), t->stream));
+        prof_stage_end(t, 6);
+        GS_TRY(debug_check(t, 6));
+    }
+    GS_TRY(apply_update(t, h, 6));
+    if (densify) {   // var and the averaged location gradient are complete on every rank: densify identically, no further exchange
+        GS_TRY(resolve_stats(t));
+        GS_TRY(trainer_densify(t, h, &t->last));
+    }
+    if (stats) { GS_TRY(resolve_stats(t)); *stats = t->last; }
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_set_compact_exchange(gs_trainer* t, gs_collective_fn all_gather, gs_allreduce_fn all_reduce, void* user, int rank,
+                                               int world, int n_cameras, const float* campos) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    GS_HIP(hipSetDevice(t->device));
+    GS_HIP(hipStreamSynchronize(t->stream));
+    if (!all_gather || !all_reduce) { t->xchg_gather = nullptr; t->xchg_reduce = nullptr; t->xchg_user = nullptr; t->xchg_rank = 0; t->xchg_world = 1; t->xchg_cameras = 0; return GS_OK; }
+    if (world < 1 || world > 64 || rank < 0 || rank >= world || n_cameras < world || !campos) {
+        set_error("gs_trainer_set_compact_exchange: rank %d of %d (1..64 ranks), %d cameras (at least one per rank), camera positions %s",
+                  rank, world, n_cameras, campos ? "given" : "missing");
+        return GS_ERR_INVALID_ARGUMENT;
+    }
+    GS_TRY(t->xcampos.ensure((size_t)n_cameras * 3 * sizeof(float)));
+    GS_HIP(hipMemcpy(t->xcampos.p, campos, (size_t)n_cameras * 3 * sizeof(float), hipMemcpyHostToDevice));
+    t->xchg_gather = all_gather; t->xchg_reduce = all_reduce; t->xchg_user = user; t->xchg_rank = rank; t->xchg_world = world; t->xchg_cameras = n_cameras;
+    return GS_OK;
+}
+
 extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs_step_stats* stats) {
     if (!t || !h) return GS_ERR_INVALID_ARGUMENT;
     // `var` (accumulateGradients, src/Trainer.cu:52) is read by the densify block of the same iteration only (:444,453)
     // and starts from zero every iteration (:304-309): a step without densify does not need per-pass gradients
+    if (t->xchg_gather && t->xchg_reduce) return step_compact_exchange(t, h, densify, stats);
     GS_TRY(accumulate_async(t, densify != 0));
     if (t->shard_rs && t->shard_ag) {
         // Data-parallel sharded update: every rank ends up with the sum of its own chunk of the gradient buffer only
@@ -1473,6 +1575,20 @@ static int rccl_ag_hook(float* buf, size_t n, void* stream, void* user) {
     if (!c->comm) return -1;
     const size_t chunk = n / (size_t)c->n_ranks;
     return rccl_result(c, g_rccl.all_gather(buf + chunk * (size_t)c->rank, buf, chunk, 7, c->comm, (hipStream_t)stream), "ncclAllGather");
+}
+// Compact exchange over the library's own communicators.  The all-reduce of the geometry planes is issued on the trainer's second
+// stream beside the all-gather: collectives of ONE communicator execute in issue order whatever their streams, so the overlap
+// needs a communicator of its own (`reduce`; the same handle as `gather` is accepted and serialises the two).
+static int rccl_x_gather(float* buf, size_t n, void* stream, void* user) { return rccl_ag_hook(buf, n, stream, static_cast<void**>(user)[0]); }
+static int rccl_x_reduce(float* buf, size_t n, void* stream, void* user) { return rccl_hook(buf, n, stream, static_cast<void**>(user)[1]); }
+extern "C" int gs_trainer_attach_comm_compact(gs_trainer* t, gs_comm* gather, gs_comm* reduce, int n_cameras, const float* campos) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    if (!gather) return gs_trainer_set_compact_exchange(t, nullptr, nullptr, nullptr, 0, 1, 0, nullptr);
+    if (!reduce) reduce = gather;
+    if (!g_rccl.all_gather) { set_error("librccl lacks ncclAllGather"); return GS_ERR_INTERNAL; }
+    if (gather->rank != reduce->rank || gather->n_ranks != reduce->n_ranks) { set_error("gs_trainer_attach_comm_compact: the two communicators differ in rank / size"); return GS_ERR_INVALID_ARGUMENT; }
+    t->xchg_comms[0] = gather; t->xchg_comms[1] = reduce;
+    return gs_trainer_set_compact_exchange(t, rccl_x_gather, rccl_x_reduce, t->xchg_comms, gather->rank, gather->n_ranks, n_cameras, campos);
 }
 extern "C" int gs_trainer_attach_comm_sharded(gs_trainer* t, gs_comm* c) {
     if (!t) return GS_ERR_INVALID_ARGUMENT;

@@ -163,8 +163,21 @@ int launch_loss_sum(const Dims& d, const Scratch& s, hipStream_t st);
 int launch_render_backward(const Dims& d, const Scratch& s, const int* items, int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st);
 // Trainer form: loops the views, writes the averaged-gradient planes (incl. var) once.  fuse_pairs: the backward left ONE
 // gradient set per pair item (render_bwd<2>): the per-splat chain runs once per item and `var` is written as zero.
+// Buffers of the compact data-parallel exchange (gs_trainer_set_compact_exchange): what leaves the rank instead of the 12 + 3M
+// gradient planes.  48 of cfg3's 60 planes are SH gradients, and a record's SH gradient of a splat is rank one — basis(view
+// direction)[M] x dL_dRGB[3] — so the ranks all-gather dL_dRGB (3 floats per record and splat) and all-reduce only the
+// twelve other planes; every rank rebuilds the SH planes itself (k_sh_rebuild).
+struct Exchange {
+    float* geo = nullptr;  // [12][Pa]  loc 3 | scale 3 | opacity 1 | rot 4 | var 1: this rank's sums -> (all-reduce) -> the iteration's
+    float* rgb = nullptr;  // [world][slots][3][Pa]  dL_dRGB of every record of every rank; this rank writes chunk `rank` -> (all-gather)
+    int rank = 0, world = 1;
+    int slots = 0;         // records per rank: ceil(cameras / world) in the fused form, twice that (white | black) in the per-pass form
+};
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad_planes, const int* items,
-                              int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st);
+                              int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st, const Exchange* x = nullptr);
+// after the exchange: every averaged-gradient plane from the reduced geometry planes and the gathered dL_dRGB (campos: [n_cameras][3], device)
+int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, const float* campos, int n_cameras, bool per_pass, float samples,
+                      float* grad_planes, hipStream_t st);
 // Seam form: one view, reference-shaped AoS outputs with the reference's += / = discipline.
 struct SeamGrads { float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot; };
 int launch_splat_backward_seam(const Dims& d, const float* params, const Scratch& s, const SeamGrads& g, hipStream_t st);

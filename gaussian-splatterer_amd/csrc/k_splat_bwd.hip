@@ -244,14 +244,22 @@ template <int D> struct GradAcc {
     // one record: mean(3) scale(3) rot(4) opacity(1) dL_dRGB(3); (mx, my, mz) the splat, cp the pass's camera position
     __device__ void add(const float4& r0, const float4& r1, const float4& r2, const float4& r3, float samples, float mx, float my, float mz,
                         const float* cp) {
-        const float gm[3] = { r0.x, r0.y, r0.z }, gs3[3] = { r0.w, r1.x, r1.y }, gr[4] = { r1.z, r1.w, r2.x, r2.y };
+        add_geometry(r0, r1, r2, samples);
         const float dRGB[3] = { r2.w, r3.x, r3.y };
+        add_sh(dRGB, samples, mx, my, mz, cp);
+    }
+    // everything of accumulateGradients but the SH planes (the compact data-parallel exchange sums these per rank and all-reduces them)
+    __device__ void add_geometry(const float4& r0, const float4& r1, const float4& r2, float samples) {
+        const float gm[3] = { r0.x, r0.y, r0.z }, gs3[3] = { r0.w, r1.x, r1.y }, gr[4] = { r1.z, r1.w, r2.x, r2.y };
         var += sqrtf((gm[0] * gm[0]) + (gm[1] * gm[1]) + (gm[2] * gm[2])) / samples;
 #pragma unroll
         for (int c = 0; c < 3; c++) { aLoc[c] += gm[c] / samples; aScale[c] += gs3[c] / samples; }
         aOpac += r2.z / samples;
 #pragma unroll
         for (int c = 0; c < 4; c++) aRot[c] += gr[c] / samples;
+    }
+    // the SH planes' share of one record: avg_sh += (basis(direction from the record's camera) x dL_dRGB) / S
+    __device__ void add_sh(const float (&dRGB)[3], float samples, float mx, float my, float mz, const float* cp) {
         // A pass in which the splat is culled (or its colour gradient is exactly zero) adds +0 to every SH sum: skip it,
         // as upstream's radii > 0 guard does — the basis of a splat AT the camera position (len = 0) or with a
         // non-finite mean is NaN, and NaN * 0 would poison the SH planes for good.
@@ -265,6 +273,15 @@ template <int D> struct GradAcc {
 #pragma unroll
                 for (int c = 0; c < 3; c++) aSh[k][c] += (basis[k] * dRGB[c]) / samples;
         }
+    }
+    // the twelve planes that are not SH, in the exchange's order: loc 3 | scale 3 | opacity | rot 4 | var (Exchange::geo)
+    __device__ void store_geometry(float* __restrict__ geo, size_t st, int i, bool zero_var) const {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { geo[c * st + i] = aLoc[c]; geo[(3 + c) * st + i] = aScale[c]; }
+        geo[6 * st + i] = aOpac;
+#pragma unroll
+        for (int c = 0; c < 4; c++) geo[(7 + c) * st + i] = aRot[c];
+        geo[11 * st + i] = zero_var ? 0.0f : var;
     }
     // every gradient plane of splat i, written exactly once per step
     __device__ void store(float* __restrict__ grad, const Planes& pl, size_t st, int i, int M, bool zero_var) const {
@@ -291,10 +308,15 @@ template <int D> struct GradAcc {
 // gradient set per item, in pass a's slice: blockIdx.y then enumerates items and the record is pass a's.
 // SINGLE: the step has exactly one record per splat (one work item: the per-GPU load of an 8-GPU run) — the record never leaves
 // the registers: accumulateGradients is applied here and the gradient planes are written, no second launch.
+// Where a record's dL_dRGB goes in the compact exchange's gather buffer (Exchange::rgb): chunk `rank`, slot, three planes of Pa.
+__device__ inline float* exchange_rgb(const Exchange& x, int rank, int slot, size_t Pa) { return x.rgb + ((size_t)rank * x.slots + slot) * 3 * Pa; }
+
+// SINGLE + x.geo != null (compact exchange): the geometry sums go to the exchange's twelve planes and the record's dL_dRGB to
+// its slot 0 of this rank's chunk of the gather buffer; no SH plane is touched (k_sh_rebuild writes them after the exchange).
 template <int D, bool SINGLE>
 __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __restrict__ params, Scratch s, float4* __restrict__ rec_out,
                                                        const int* __restrict__ items, int n_pairs, int fused, float samples,
-                                                       float* __restrict__ grad) {
+                                                       float* __restrict__ grad, Exchange x) {
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
     // blockIdx.y enumerates passes: the two passes of every pair item first, then the single items
@@ -311,8 +333,14 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     const uint32_t tiles = s.tiles_touched[(size_t)g * st + i];
     if ((s.flags[g * 4 + 0] & 1u) || tiles == 0) {  // culled: the reference's nine buffers stay zero
         const float4 z = make_float4(0, 0, 0, 0);
-        if constexpr (SINGLE) { GradAcc<D> acc; acc.store(grad, pl, st, i, d.M, fused != 0); }
-        else { out[0] = z; out[1] = z; out[2] = z; out[3] = z; }
+        if constexpr (SINGLE) {
+            GradAcc<D> acc;
+            if (x.geo) {
+                acc.store_geometry(x.geo, st, i, fused != 0);
+                float* rgb = exchange_rgb(x, x.rank, 0, st);
+                rgb[i] = 0.0f; rgb[st + i] = 0.0f; rgb[2 * st + i] = 0.0f;
+            } else acc.store(grad, pl, st, i, d.M, fused != 0);
+        } else { out[0] = z; out[1] = z; out[2] = z; out[3] = z; }
         return;
     }
     float mean[3], sc[3], q[4];
@@ -336,8 +364,15 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
                  r2 = make_float4(o.rot[2], o.rot[3], sum[8], dRGB[0]), r3 = make_float4(dRGB[1], dRGB[2], 0.0f, 0.0f);
     if constexpr (SINGLE) {
         GradAcc<D> acc;
-        acc.add(r0, r1, r2, r3, samples, mean[0], mean[1], mean[2], s.views[v].campos);
-        acc.store(grad, pl, st, i, d.M, fused != 0);
+        if (x.geo) {
+            acc.add_geometry(r0, r1, r2, samples);
+            acc.store_geometry(x.geo, st, i, fused != 0);
+            float* rgb = exchange_rgb(x, x.rank, 0, st);
+            rgb[i] = dRGB[0]; rgb[st + i] = dRGB[1]; rgb[2 * st + i] = dRGB[2];
+        } else {
+            acc.add(r0, r1, r2, r3, samples, mean[0], mean[1], mean[2], s.views[v].campos);
+            acc.store(grad, pl, st, i, d.M, fused != 0);
+        }
     } else {
         out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3;
     }
@@ -367,30 +402,114 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __
     acc.store(grad, pl, st, i, d.M, n_fused_items > 0);
 }
 
+// The compact data-parallel exchange (capi.hip, gs_trainer_set_compact_exchange), rank side: the rank's records are summed into
+// the twelve geometry planes it contributes to the all-reduce, and every record's dL_dRGB goes to its slot of the rank's chunk
+// of the all-gather buffer.  Records: one per local camera g in the fused form (slot g), one per local pass in the per-pass
+// form (first pass of local camera g — its white one: slot g; the other: slot x.slots / 2 + g).  Slots the rank does not fill
+// are zeroed.
+__global__ __launch_bounds__(WG) void k_exchange_pack(Dims d, Scratch s, float samples, const float4* __restrict__ rec_in, Exchange x,
+                                                      const int* __restrict__ items, int n_fused_items) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= d.P) return;
+    const size_t st = (size_t)d.Pa;
+    GradAcc<0> acc;
+    const int n_rec = n_fused_items > 0 ? n_fused_items : d.V;
+    for (int k = 0; k < n_rec; k++) {
+        const int v = n_fused_items > 0 ? items[3 * k + 1] : k;
+        const float4* r = rec_in + ((size_t)v * st + i) * 4;
+        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        acc.add_geometry(r0, r1, r2, samples);
+        // local camera = the pass's geometry group (groups are numbered in the order of their first passes); a group's first
+        // pass is its white one in the reference's order (src/Trainer.cu:311-314)
+        const int g = n_fused_items > 0 ? items[3 * k] : s.view_group[v];
+        const int slot = (n_fused_items > 0 || s.group_views[s.group_first[g]] == v) ? g : x.slots / 2 + g;
+        float* rgb = exchange_rgb(x, x.rank, slot, st);
+        rgb[i] = r2.w; rgb[st + i] = r3.x; rgb[2 * st + i] = r3.y;
+    }
+    // a rank with fewer cameras than the others (cameras % ranks != 0) sends zeros in the slots it has no record for
+    const int per_half = n_fused_items > 0 ? x.slots : x.slots / 2;
+    for (int h = 0; h < (n_fused_items > 0 ? 1 : 2); h++)
+        for (int k = d.VG; k < per_half; k++) {
+            float* rgb = exchange_rgb(x, x.rank, h * per_half + k, st);
+            rgb[i] = 0.0f; rgb[st + i] = 0.0f; rgb[2 * st + i] = 0.0f;
+        }
+    acc.store_geometry(x.geo, st, i, n_fused_items > 0);
+}
+
+// ... and after the collectives, on every rank alike: the averaged-gradient planes of the whole iteration.  The twelve geometry
+// planes are the all-reduced sums; the SH planes are rebuilt from the gathered dL_dRGB of EVERY record of the iteration in the
+// order a single GPU walks them (fused form: cameras 0 .. C-1; per-pass form: their white passes, then their black ones —
+// src/Trainer.cu:311-314), each with its own camera's view direction: avg_sh += (basis x dL_dRGB) / S, the very operations of
+// GradAcc::add — the SH gradients are the single-GPU step's bit for bit, whatever order the collective summed in.
+// Camera c of the iteration lives on rank c % world as that rank's local camera c / world.
+template <int D>
+__global__ __launch_bounds__(WG) void k_sh_rebuild(Dims d, const float* __restrict__ params, Exchange x, const float* __restrict__ campos,
+                                                   int n_cameras, int per_pass, float samples, float* __restrict__ grad) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= d.P) return;
+    const Planes pl{ d.M };
+    const size_t st = (size_t)d.Pa;
+    const float mx = params[pl.loc(0) * st + i], my = params[pl.loc(1) * st + i], mz = params[pl.loc(2) * st + i];
+    GradAcc<D> acc;
+    const int n_rec = per_pass ? 2 * n_cameras : n_cameras;
+    for (int k = 0; k < n_rec; k++) {
+        const int c = k < n_cameras ? k : k - n_cameras;
+        const int slot = (k < n_cameras ? 0 : x.slots / 2) + c / x.world;
+        const float* rgb = exchange_rgb(x, c % x.world, slot, st);
+        const float dRGB[3] = { rgb[i], rgb[st + i], rgb[2 * st + i] };
+        acc.add_sh(dRGB, samples, mx, my, mz, campos + 3 * c);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { acc.aLoc[c] = x.geo[c * st + i]; acc.aScale[c] = x.geo[(3 + c) * st + i]; }
+    acc.aOpac = x.geo[6 * st + i];
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc.aRot[c] = x.geo[(7 + c) * st + i];
+    acc.var = x.geo[11 * st + i];
+    acc.store(grad, pl, st, i, d.M, false);
+}
+
+// x != null: the compact exchange's rank side (the rank holds whole cameras: n1 == 0); grad is not written
 template <int D>
 static void launch_splat_avg_d(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, const int* items, int n2,
-                               int n1, bool fuse, hipStream_t stream) {
+                               int n1, bool fuse, const Exchange* x, hipStream_t stream) {
     const int bx = (d.P + WG - 1) / WG;
     float4* rec = reinterpret_cast<float4*>(s.splat_grads);
     fuse = fuse && n2 > 0;
     const int ny = fuse ? n2 + n1 : 2 * n2 + n1;
+    const Exchange none{};
     if (ny == 1) {  // one record per splat: chain and accumulateGradients in one launch
-        hipLaunchKernelGGL((k_splat_bwd_view<D, true>), dim3(bx, 1), dim3(WG), 0, stream, d, params, s, rec, items, n2, fuse ? 1 : 0, samples, grad);
+        hipLaunchKernelGGL((k_splat_bwd_view<D, true>), dim3(bx, 1), dim3(WG), 0, stream, d, params, s, rec, items, n2, fuse ? 1 : 0, samples, grad, x ? *x : none);
         return;
     }
-    if (ny > 0) hipLaunchKernelGGL((k_splat_bwd_view<D, false>), dim3(bx, ny), dim3(WG), 0, stream, d, params, s, rec, items, n2, fuse ? 1 : 0, samples, grad);
-    hipLaunchKernelGGL(k_splat_bwd_reduce<D>, dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
-                       fuse ? n2 + n1 : 0);
+    if (ny > 0) hipLaunchKernelGGL((k_splat_bwd_view<D, false>), dim3(bx, ny), dim3(WG), 0, stream, d, params, s, rec, items, n2, fuse ? 1 : 0, samples, grad, none);
+    if (x) hipLaunchKernelGGL(k_exchange_pack, dim3(bx), dim3(WG), 0, stream, d, s, samples, (const float4*)rec, *x, items, fuse ? n2 : 0);
+    else hipLaunchKernelGGL(k_splat_bwd_reduce<D>, dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
+                            fuse ? n2 + n1 : 0);
 }
 
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, const int* items,
-                              int n_pairs, int n_singles, bool fuse_pairs, hipStream_t stream) {
+                              int n_pairs, int n_singles, bool fuse_pairs, hipStream_t stream, const Exchange* x) {
     if (d.P == 0) return GS_OK;
     switch (d.D) {
-        case 0: launch_splat_avg_d<0>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, stream); break;
-        case 1: launch_splat_avg_d<1>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, stream); break;
-        case 2: launch_splat_avg_d<2>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, stream); break;
-        default: launch_splat_avg_d<3>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, stream); break;
+        case 0: launch_splat_avg_d<0>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream); break;
+        case 1: launch_splat_avg_d<1>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream); break;
+        case 2: launch_splat_avg_d<2>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream); break;
+        default: launch_splat_avg_d<3>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream); break;
+    }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, const float* campos, int n_cameras, bool per_pass, float samples,
+                      float* grad, hipStream_t stream) {
+    if (d.P == 0) return GS_OK;
+    const dim3 grid((d.P + WG - 1) / WG);
+    const int pp = per_pass ? 1 : 0;
+    switch (d.D) {
+        case 0: hipLaunchKernelGGL(k_sh_rebuild<0>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad); break;
+        case 1: hipLaunchKernelGGL(k_sh_rebuild<1>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad); break;
+        case 2: hipLaunchKernelGGL(k_sh_rebuild<2>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad); break;
+        default: hipLaunchKernelGGL(k_sh_rebuild<3>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad); break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

@@ -258,6 +258,25 @@ int gs_trainer_set_allreduce(gs_trainer* trainer, gs_allreduce_fn fn, void* user
 typedef int (*gs_collective_fn)(float* device_buf, size_t n_floats, void* hip_stream, void* user);
 int gs_trainer_set_sharded_update(gs_trainer* trainer, gs_collective_fn reduce_scatter, gs_collective_fn all_gather, void* user,
                                   int rank, int world);
+/* Compact exchange, the third data-parallel form of gs_trainer_step — the one that moves the fewest bytes when a rank holds few
+ * cameras.  3M of the 12 + 3M gradient planes are SH gradients, and one record's SH gradient of a splat is rank one:
+ * basis(view direction)[M] x dL_dRGB[3] (what accumulateGradients sums, src/Trainer.cu:60-64, built per camera).  So the step
+ *   1. leaves, per rank, the sums of the twelve other planes (loc 3 | scale 3 | opacity | rot 4 | var) over its cameras and the
+ *      dL_dRGB record (3 floats per splat) of each of its cameras (each of its passes on a densify step),
+ *   2. all-reduces the twelve planes (hook all_reduce, on the trainer's second stream) WHILE it all-gathers the records (hook
+ *      all_gather, in place: chunk r of the buffer is rank r's), 
+ *   3. rebuilds the SH planes on every rank from ALL records in the order a single GPU accumulates them, and applies the update.
+ * Received per rank at BASELINE cfg3 on 8 GPUs (8 cameras, M = 16, 100k splats): 8.4 MB + 8.4 MB instead of the 42 MB a ring
+ * all-reduce of the 24 MB buffer moves; the form pays while cameras < 2 M (bench.py --collective auto chooses by that).
+ * The SH gradients are those of the single-GPU step bit for bit (no collective sums them); replicas stay bit-identical as
+ * long as the all-reduce leaves identical sums on all ranks (RCCL's does).
+ * Layout contract: the iteration has n_cameras cameras in the reference's order (src/Trainer.cu:311-314: pass c = camera c on
+ * white, pass n_cameras + c = camera c on black); camera c belongs to rank c % world with BOTH passes (at least one camera
+ * per rank), gs_trainer_set_views on each rank holds exactly those passes and total_samples = 2 * n_cameras.  `campos`
+ * [n_cameras][3] (host): every camera's position, rank-independent.  Pass NULL hooks to leave the form.
+ * Trainer option "exchange_overlap" (default 1): 0 issues the two collectives one after the other on the trainer's stream. */
+int gs_trainer_set_compact_exchange(gs_trainer* trainer, gs_collective_fn all_gather, gs_allreduce_fn all_reduce, void* user, int rank,
+                                    int world, int n_cameras, const float* campos);
 /* The HIP stream (hipStream_t) all of this trainer's work is enqueued on. */
 int gs_trainer_get_stream(gs_trainer* trainer, void** hip_stream);
 int gs_trainer_synchronize(gs_trainer* trainer);
@@ -293,6 +312,10 @@ int gs_comm_destroy(gs_comm* comm);
 int gs_trainer_attach_comm(gs_trainer* trainer, gs_comm* comm);
 /* Installs ncclReduceScatter / ncclAllGather (in place) as the hooks of gs_trainer_set_sharded_update. */
 int gs_trainer_attach_comm_sharded(gs_trainer* trainer, gs_comm* comm);
+/* Installs ncclAllGather on `gather` and ncclAllReduce on `reduce` as the hooks of gs_trainer_set_compact_exchange.  Two
+ * communicators so that the two collectives can run side by side (operations of one communicator execute in issue order);
+ * reduce == NULL or == gather serialises them. */
+int gs_trainer_attach_comm_compact(gs_trainer* trainer, gs_comm* gather, gs_comm* reduce, int n_cameras, const float* campos);
 
 /* ------------------------------------------------------------------------------------------
  * Inner seam: the rasterizer pair the reference calls.  Same argument order as

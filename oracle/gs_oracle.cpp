@@ -650,6 +650,56 @@ void preprocess_backward(const ViewState<R>& g, int D, int M, const R* means, co
     }
 }
 
+// Test-side service: the ADMISSIBLE forward results of one pixel.  The blend takes two discrete decisions per (pixel, entry)
+// pair — "alpha < 1/255: skip" and "T (1 - alpha) < 1e-4: stop, entry not applied" — and an implementation whose exp() or
+// running product differs from this one's in the last bits may take the other branch where a pair sits on a threshold.
+// pixel_run blends the pixel with a list of FORCED decisions; at the first decision that is fragile (within alpha_margin /
+// T_margin, relative, of its threshold) and not in the list it stops and reports it.  Exploring both values of every
+// reported decision depth-first enumerates the admissible blends of the pixel (orc_check_pixels_f32): a foreign result
+// has to equal ONE of them — colour, final T and last contributor — instead of being excluded from the comparison.
+struct ForcedDecision { uint32_t k; int kind; bool value; };  // kind 1: skip (alpha test), 2: stop (T test)
+template <class R> struct PixelLeaf { R T, C[3]; uint32_t last; };
+// returns true when the run completed (leaf filled); false when it stopped at an unforced fragile decision (*branch, with its
+// nominal value)
+template <class R>
+inline bool pixel_run(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx, R pixfy, const std::vector<ForcedDecision>& forced,
+                      float alpha_margin, float T_margin, PixelLeaf<R>& leaf, ForcedDecision* branch) {
+    R Tt = R(1.0), C[3] = { 0, 0, 0 };
+    uint32_t contributor = 0, last = 0;
+    auto forced_value = [&](uint32_t k, int kind, bool& v) {
+        for (const ForcedDecision& f : forced) if (f.k == k && f.kind == kind) { v = f.value; return true; }
+        return false;
+    };
+    for (uint32_t k = beg; k < end; k++) {
+        contributor++;
+        const uint32_t id = g.point_list[k];
+        const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+        const R* co = &g.conic_opacity[4 * (size_t)id];
+        const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        if (power > R(0.0)) continue;
+        const R alpha = std::min(R(0.99), co[3] * std::exp(power));
+        bool skip = alpha < R(1.0) / R(255.0);
+        if (!forced_value(k, 1, skip) && (float)(std::fabs(alpha - R(1.0 / 255.0)) * R(255.0)) < alpha_margin) {
+            *branch = { k, 1, skip };
+            return false;
+        }
+        if (skip) continue;
+        const R test_T = Tt * (R(1.0) - alpha);
+        bool stop = test_T < R(0.0001);
+        if (!forced_value(k, 2, stop) && (float)(std::fabs(test_T - R(0.0001)) * R(10000.0)) < T_margin) {
+            *branch = { k, 2, stop };
+            return false;
+        }
+        if (stop) break;
+        for (int c = 0; c < 3; c++) C[c] += g.rgb[3 * (size_t)id + c] * alpha * Tt;
+        Tt = test_T;
+        last = contributor;
+    }
+    leaf.T = Tt; leaf.last = last;
+    for (int c = 0; c < 3; c++) leaf.C[c] = C[c];
+    return true;
+}
+
 template <class R> struct State { ViewState<R> v; };
 
 template <class R>
@@ -761,6 +811,69 @@ void orc_chain_f32(orc_state* s, int D, int M, const float* means, const float* 
     }
     Grads<float> o{ m2.data(), con.data(), op.data(), col.data(), dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
     preprocess_backward<float>(s->f.v, D, M, means, scales, mod, rots, shs, view, proj, campos, tanx, tany, o);
+}
+// Every pixel of a foreign implementation's forward output (colour [3][N] incl. background, final T, last contributor)
+// against the admissible blends of that pixel (pixel_run above).  status[pix]:
+//   0  equals the nominal blend (the one orc_forward_f32 produced)
+//   1  equals another admissible blend: some fragile decision(s) taken the other way
+//   2  equals NO admissible blend
+//   3  undecided: more than max_leaves blends without a match
+// leaves[pix] = blends examined (1: the pixel holds no fragile decision).  "Equals": last contributor identical,
+// |T - T'| <= rtol max(|T'|, floor_T), |C - C'| <= rtol max(|C'|, floor_C) per channel.  Returns the number of pixels
+// with status >= 2.
+int orc_check_pixels_f32(orc_state* s, const float* bg, const float* got_color, const float* got_T, const uint32_t* got_last,
+                         float alpha_margin, float T_margin, float rtol, float floor_T, float floor_C, int max_leaves,
+                         int32_t* status, int32_t* leaves) {
+    const ViewState<float>& g = s->f.v;
+    const int W = g.W, H = g.H;
+    const size_t N = (size_t)W * H;
+    const int T = g.gx * g.gy;
+    int n_bad = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : n_bad)
+    for (int tile = 0; tile < T; tile++) {
+        const int tx = tile % g.gx, ty = tile / g.gx;
+        const uint32_t beg = g.ranges[2 * (size_t)tile], end = g.ranges[2 * (size_t)tile + 1];
+        std::vector<std::vector<ForcedDecision>> stack;
+        for (int py = ty * TILE; py < std::min(H, (ty + 1) * TILE); py++)
+            for (int px = tx * TILE; px < std::min(W, (tx + 1) * TILE); px++) {
+                const size_t pix = (size_t)py * W + px;
+                auto matches = [&](const PixelLeaf<float>& l) {
+                    if (l.last != got_last[pix]) return false;
+                    if (!(std::fabs(got_T[pix] - l.T) <= rtol * std::max(std::fabs(l.T), floor_T))) return false;
+                    for (int c = 0; c < 3; c++) {
+                        const float want = l.C[c] + l.T * bg[c];
+                        if (!(std::fabs(got_color[c * N + pix] - want) <= rtol * std::max(std::fabs(want), floor_C))) return false;
+                    }
+                    return true;
+                };
+                stack.clear();
+                stack.push_back({});
+                int n_leaves = 0, st = 2;
+                bool first = true;
+                while (!stack.empty()) {
+                    std::vector<ForcedDecision> forced = std::move(stack.back());
+                    stack.pop_back();
+                    PixelLeaf<float> leaf;
+                    ForcedDecision br;
+                    if (pixel_run<float>(g, beg, end, (float)px, (float)py, forced, alpha_margin, T_margin, leaf, &br)) {
+                        n_leaves++;
+                        // the nominal blend is the leaf reached by taking the nominal value at every branch: explored first
+                        if (matches(leaf)) { st = first ? 0 : 1; break; }
+                        first = false;
+                        if (n_leaves >= max_leaves) { st = 3; break; }
+                    } else {
+                        std::vector<ForcedDecision> other = forced;
+                        other.push_back({ br.k, br.kind, !br.value });
+                        forced.push_back(br);
+                        stack.push_back(std::move(other));   // explored after ...
+                        stack.push_back(std::move(forced));  // ... the nominal value (LIFO)
+                    }
+                }
+                status[pix] = st; leaves[pix] = n_leaves;
+                if (st >= 2) n_bad++;
+            }
+    }
+    return n_bad;
 }
 void orc_backward_f64(orc_state* s, int D, int M, const double* bg, const double* means, const double* shs,
                       const double* scales, double mod, const double* rots, const double* view, const double* proj,

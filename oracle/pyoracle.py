@@ -151,6 +151,26 @@ class Rasterizer:
         return g
 
 
+def check_pixels(r, got_color, got_T, got_last, alpha_margin=1e-4, T_margin=1e-4, rtol=1e-4, floor_T=1e-4, floor_C=1e-3, max_leaves=4096):
+    """Every pixel of another implementation's forward output against the ADMISSIBLE blends of Rasterizer `r`'s last
+    forward (gs_oracle.cpp, orc_check_pixels_f32): the nominal blend, or the blend with fragile decisions — pairs within
+    alpha_margin / T_margin (relative) of the alpha = 1/255 / T = 1e-4 thresholds — taken the other way.
+    Returns (status int32[N]: 0 nominal, 1 another admissible blend, 2 none, 3 undecided; leaves int32[N])."""
+    a = r.args
+    assert r.dt == np.float32
+    N = a["W"] * a["H"]
+    col = _c(got_color, np.float32).reshape(-1)
+    gT = _c(got_T, np.float32).reshape(-1)
+    gl = _c(got_last, np.uint32).reshape(-1)
+    assert col.size == 3 * N and gT.size == N and gl.size == N
+    status = np.zeros(N, np.int32)
+    leaves = np.zeros(N, np.int32)
+    lib().orc_check_pixels_f32(r.h, _p(a["bg"], f32p), _p(col, f32p), _p(gT, f32p), _p(gl, u32p), C.c_float(alpha_margin),
+                               C.c_float(T_margin), C.c_float(rtol), C.c_float(floor_T), C.c_float(floor_C), C.c_int(max_leaves),
+                               _p(status, i32p), _p(leaves, i32p))
+    return status, leaves
+
+
 def chain(r, sums9):
     """The per-splat half of the backward (linear in the nine pixel-stage sums) of Rasterizer `r`'s last forward on
     caller-supplied sums9[P, 9]; returns dL_dmean3D / dL_dcov3D / dL_dsh / dL_dscale / dL_drot (fp32)."""

@@ -4,15 +4,16 @@ C-ABI) against the CPU oracle on identical inputs.
 Bars (BASELINE.json north_star): tile / sort indices bit-exact; pixels and gradients <= 1e-4 relative.
 The projection stage is bit-exact by construction (same fp32 operation order, no FMA contraction), so
 every per-splat geometry field is compared with ==.  The blend differs from the oracle only through
-exp() (hardware v_exp_f32 vs libm): pixels that sit within 1e-3 relative of one of the blend's
-discrete thresholds (alpha = 1/255, T = 1e-4) are reported by the oracle (`margin`) and excluded from
-the per-pixel comparisons; everything else must meet 1e-4.  Gradients are compared for EVERY splat: the budget is
-1e-4 of sum|term| plus the oracle's decision-flip allowance (check_pixel_stage)."""
+exp() (hardware v_exp_f32 vs libm) and the contracted exponent, which can move one of the blend's discrete
+decisions (alpha = 1/255, T = 1e-4) for a pair that sits on its threshold.  NO pixel and NO splat is excluded:
+every pixel must equal, to 1e-4, an admissible blend of that pixel — the oracle's, or the oracle's with decisions within
+1e-4 of a threshold taken the other way (orc.check_pixels) — and every gradient entry must lie within 1e-4 of sum|term|
+plus the oracle's decision-flip allowance, carried through the per-splat chain (check_pixel_stage, util.unexplained)."""
 import numpy as np
 import pytest
 
 import util
-from util import REC_DTYPE, SeamRaster, assert_close_rel, make_scene, oracle_forward, view_parts
+from util import REC_DTYPE, SeamRaster, make_scene, oracle_forward, view_parts
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +27,7 @@ CASES = [
 ]
 
 
-def _check_forward(orc, s, D, M, vp, W, H, mod=1.0, min_solid=0.99, check_pixels=True):
+def _check_forward(orc, s, D, M, vp, W, H, mod=1.0, min_solid=0.99, check_pixels=True, T_margin=1e-4):
     sr = SeamRaster()
     out, R = sr.forward(s, D, M, vp, W, H, mod)
     r, oout, oR = oracle_forward(orc, s, D, M, vp, W, H, mod)
@@ -58,20 +59,21 @@ def _check_forward(orc, s, D, M, vp, W, H, mod=1.0, min_solid=0.99, check_pixels
     # bit-exact sorted lists and tile ranges
     assert np.array_equal(sr.field("binning", "point_list", np.uint32), r.get("point_list"))
     assert np.array_equal(sr.field("image", "ranges", np.uint32), r.get("ranges"))
-    # pixels
-    margin = r.get("margin")
-    solid = margin > 1e-3
-    assert solid.mean() > min_solid
-    ncon = sr.field("image", "n_contrib", np.uint32)
-    assert np.array_equal(ncon[solid], r.get("n_contrib")[solid])
     if not check_pixels:
         return sr, r, out, oout
+    # pixels: EVERY pixel is compared — colour, final T and last contributor must equal (1e-4) an ADMISSIBLE blend of the
+    # pixel: the oracle's own, or the oracle's with decisions that sit within 1e-4 (alpha = 1/255) / T_margin (T = 1e-4) of their
+    # threshold taken the other way (oracle/gs_oracle.cpp orc_check_pixels_f32 enumerates them; the hardware's v_exp_f32 and
+    # the contracted power differ from libm in the last bits).  Through round 3 the pixels within 1e-3 of a threshold were
+    # left out of the comparison and bounded by 0.02.
+    ncon = sr.field("image", "n_contrib", np.uint32)
     fT = sr.field("image", "final_T", np.float32)
-    assert_close_rel("final_T", fT[solid], r.get("final_T")[solid], rtol=1e-4, floor=1e-4)
-    for c in range(3):
-        assert_close_rel(f"out_color[{c}]", out[c].reshape(-1)[solid], oout[c].reshape(-1)[solid], rtol=1e-4, floor=1e-3)
-    # fragile pixels may flip one threshold decision: bounded by one blend term
-    assert np.abs(out - oout).max() <= 0.02
+    status, leaves = orc.check_pixels(r, out, fT, ncon, alpha_margin=1e-4, T_margin=T_margin, rtol=1e-4, floor_T=1e-4, floor_C=1e-3)
+    n_other, n_none, n_open = int((status == 1).sum()), int((status == 2).sum()), int((status == 3).sum())
+    print(f"pixels {W}x{H}: {status.size - n_other - n_none - n_open} equal the oracle's blend, {n_other} an admissible blend with a flipped "
+          f"threshold decision (T margin {T_margin:g}), {n_none} NO admissible blend, {n_open} undecided; largest decision tree {int(leaves.max())} blends")
+    assert n_none == 0 and n_open == 0, (n_none, n_open, np.flatnonzero(status >= 2)[:8])
+    assert n_other <= (1.0 - min_solid) * status.size, (n_other, status.size)   # flipped decisions stay the exception
     return sr, r, out, oout
 
 
@@ -124,10 +126,15 @@ def check_pixel_stage(P, g, r, dpix, max_allow_frac, assert_margin=ASSERT_MARGIN
     assert allow[assert_margin] <= max_allow_frac, allow
     # how BIG the allowance is where it applies, in units of the sums' own scale sum|term|: an allowance that rivals
     # sum|term| would bound nothing
-    size = (og_assert["flip9"] / np.maximum(og_assert["abs9"], 1e-30)).max(1)
-    size = size[og_assert["abs9"].max(1) > 0]
-    q50, q99, qmax = (float(np.quantile(size, q)) for q in (0.5, 0.99, 1.0)) if size.size else (0.0, 0.0, 0.0)
-    print(f"    flip allowance / sum|term| per splat (largest of the nine) at margin {assert_margin:g}: median {q50:.2e}, 99 % {q99:.2e}, max {qmax:.2e}")
+    a9 = og_assert["abs9"]
+    size = (og_assert["flip9"] / np.maximum(a9, 1e-30)).max(1)
+    live = a9.max(1) > 0
+    q50, q99 = (float(np.quantile(size[live], q)) for q in (0.5, 0.99)) if live.any() else (0.0, 0.0)
+    # the maximum over the splats that HAVE a scale: every one of their nine sums at least 1e-6 of that sum's largest value in the scene
+    weighty = np.all(a9 >= 1e-6 * a9.max(0, keepdims=True), axis=1)
+    qmax = float(size[weighty].max()) if weighty.any() else 0.0
+    print(f"    flip allowance / sum|term| per splat (largest of the nine) at margin {assert_margin:g}: median {q50:.2e}, 99 % {q99:.2e}, "
+          f"max over the {int(weighty.sum())} splats whose sums are not ~0: {qmax:.2e}")
     if max_allow_size is not None:
         assert q99 <= max_allow_size[0] and qmax <= max_allow_size[1], (q50, q99, qmax)
     assert counts[0.0] <= (max(3, 0.02 * P) if max_plain_outliers is None else max_plain_outliers), counts   # without any allowance only a handful of splats may be off at all
@@ -154,14 +161,18 @@ def test_backward_parity(orc, P, M, D, W, H, seed):
     for q in range(9):
         unit = np.zeros((P, 9), np.float32); unit[:, q] = 1.0
         col = orc.chain(r, unit)
-        tol_q = 1e-4 * np.maximum(abs9[:, q], 1e-3 * abs9[:, q].max() + 1e-30) + og["flip9"][:, q]
+        tol_q = 1e-4 * abs9[:, q] + og["flip9"][:, q]
         for n, k in names:
             budget[n] += np.abs(col[n].reshape(P, k).astype(np.float64)) * tol_q[:, None]
+    # ZERO entries outside the budget (through round 3: 0.2 % of the entries were waved through here, while the step-level
+    # tests already asserted zero with the same accounting); the only other term is the chain's own fp32 rounding,
+    # 4e-6 of the splat's largest component of the same output (util.unexplained)
+    report = []
     for name, stride in names:
-        got, want = g[name].reshape(P, stride).astype(np.float64), og[name].reshape(P, stride).astype(np.float64)
-        tol = 1e-4 * np.maximum(np.abs(want), 1e-3 * np.abs(want).max()) + budget[name] + 1e-30
-        bad = np.abs(got - want) > tol
-        assert bad.mean() <= 0.002, (name, int(bad.sum()), bad.size)
+        n_bad, worst = util.unexplained(name, g[name], og[name], budget[name].reshape(-1), stride)
+        report.append(f"{name} {n_bad} (worst error/budget {worst:.2f})")
+        assert n_bad == 0, (name, n_bad, worst)
+    print(f"[seam, {P} splats @{W}x{H}, M={M}] chain outputs outside the accounted budget: " + ", ".join(report))
     # culled splats: all nine buffers exactly zero (src/Trainer.cu:366-375 + radii>0 guard)
     culled = r.get("radii") <= 0
     if culled.any():
@@ -227,7 +238,7 @@ def test_long_tile_lists_take_the_spill_path(orc, P, longer_than):
     s["opac"] = (s["opac"] * 0.02).astype(np.float32)
     cams = util.gs.camera.get_cameras(1, 10.0, 20.0)
     vp = view_parts(util.gs.camera.train_views(cams, W, H)[0])
-    sr, r, out, oout = _check_forward(orc, s, D, M, vp, W, H, min_solid=0.9)
+    sr, r, out, oout = _check_forward(orc, s, D, M, vp, W, H, min_solid=0.9, T_margin=1e-3)
     ranges = r.get("ranges").reshape(-1, 2)
     assert (ranges[:, 1] - ranges[:, 0]).max() > longer_than
     dpix = np.ones((3, H, W), np.float32)
@@ -237,10 +248,73 @@ def test_long_tile_lists_take_the_spill_path(orc, P, longer_than):
     # T is a running product of up to `longer_than` factors here: its fp32 rounding error grows to ~n * 2^-24 (5e-4 at
     # 8192 entries), so the T = 1e-4 decision can flip anywhere within that distance of the threshold: margin 1e-3
     # The allowance is bounded in SIZE instead: for 99 % of the splats it stays below half of sum|term| of the sum it
-    # protects (measured: median 4e-3..5e-3, 99 % 0.08..0.2; the maximum belongs to splats whose sum|term| is ~0), and
-    # without ANY allowance at most 0.2 % of the splats may leave the plain 1e-4 budget (measured: 0 and 8).
-    og = check_pixel_stage(P, g, r, dpix, max_allow_frac=1.0, assert_margin=1e-3, max_allow_size=(0.5, np.inf), max_plain_outliers=0.002 * P)
-    assert_close_rel("dL_dopacity", g["dL_dopacity"], og["dL_dopacity"], rtol=1e-4, max_bad_frac=0.005)
+    # protects (measured: median 4e-3..5e-3, 99 % 0.08..0.2), its MAXIMUM below `max_allow_size[1]` times sum|term| for every
+    # splat whose sum|term| is not ~0 (>= 1e-6 of the scene's largest: a splat that contributes nothing has no scale to
+    # measure an allowance against), and without ANY allowance at most 0.2 % of the splats may leave the plain 1e-4
+    # budget (measured: 0 and 8).  dL_dopacity is sum 8 of the nine: it is inside this accounting, with no separate slack
+    # (round 3 allowed 0.5 % of its entries outside an array-scale bar on top).
+    check_pixel_stage(P, g, r, dpix, max_allow_frac=1.0, assert_margin=1e-3, max_allow_size=(0.5, 4.0), max_plain_outliers=0.002 * P)
+
+
+def _corner_cluster(k, W, H, seed):
+    """k small, faint splats that all project into the LAST tile of a W x H image (and into no other), overlapping at its
+    centre pixel: the tile's list is the whole arena, [0, k)."""
+    cam = util.gs.camera.get_cameras(1, 10.0, 20.0)[0]
+    vp = view_parts(util.gs.camera.view_block(cam, W, H, white=True))
+    pv = np.asarray(vp["proj"], np.float64).reshape(4, 4).T   # column-major float[16] -> matrix
+    fwd = -np.asarray(cam.location, np.float64); fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, [0.0, 1.0, 0.0]); right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+
+    def pix(p):
+        h = pv @ np.append(p, 1.0)
+        return ((h[:2] / h[3] + 1.0) * np.array([W, H]) - 1.0) * 0.5
+    p0 = pix(np.zeros(3))
+    J = np.stack([pix(right) - p0, pix(up) - p0], axis=1)     # pixels per world unit along right / up (exact: the plane z = const)
+    want = np.array([W - 8.0, H - 8.0])                       # the centre of the last tile
+    a, b = np.linalg.solve(J, want - p0)
+    centre = a * right + b * up
+    rng = np.random.default_rng(seed)
+    s = util.gs.synth.random_splats(k, 1, seed)
+    s["loc"] = (centre[None, :] + rng.uniform(-0.02, 0.02, (k, 3))).astype(np.float32).reshape(-1)
+    s["scale"] = np.full(3 * k, 0.01, np.float32)
+    s["opac"] = rng.uniform(0.02, 0.05, k).astype(np.float32)
+    return s, vp
+
+
+@pytest.mark.parametrize("k", [65, 127, 64, 1])
+def test_partial_first_round_at_the_end_of_the_arena(orc, k):
+    """The backward walks a tile's list back to front in rounds of 64 staged one round AHEAD; the first round it walks is the
+    list's partial tail.  Here that tail (n % 64 = 1, 63; also a full round and a single entry) belongs to the last tile
+    of the image and ends exactly at the end of the binning arena (the seam sizes the chunk to num_rendered): a lane
+    whose entry lies behind the list must not read the list there.  Round 3 had a working-tree version of the look-ahead
+    staging that did (tests aborted on the GPU box, gpurun log r3g; fixed by the `first_valid` guard in k_render.hip before
+    it was committed) — this pins it: the words behind the lists are poisoned with indices that fault or corrupt if they
+    are ever used, and the gradients must equal the unpoisoned run bit for bit, and the oracle."""
+    import ctypes as C
+    from gsplat_amd import capi
+    W = H = 32
+    s, vp = _corner_cluster(k, W, H, 1000 + k)
+    sr, r, out, oout = _check_forward(orc, s, 0, 1, vp, W, H, min_solid=0.9)
+    ranges = r.get("ranges").reshape(-1, 2)
+    assert sr.R == k and np.array_equal(ranges, [[0, 0], [0, 0], [0, 0], [0, k]])   # one list, in the last tile, = the whole arena
+    assert int(r.get("n_contrib").max()) == k                                        # some pixel is reached by the deepest entry
+    dpix = np.random.default_rng(k).uniform(-1, 1, (3, H, W)).astype(np.float32)
+    clean = sr.backward(dpix)
+    off, nb = C.c_size_t(), C.c_size_t()
+    chunk = sr.chunks["binning"]
+    for field in ("point_list", "point_list_slots"):
+        capi.check(capi.lib().gs_raster_chunk_field(b"binning", field.encode(), k, W, H, k, C.byref(off), C.byref(nb)))
+        assert nb.value == 4 * k
+        pad = (-(off.value + nb.value)) % 256    # the chunk's sub-arrays are 256-byte aligned: what lies behind the list
+        if pad:
+            poison = np.full(pad // 4, 0x7FFFFFF0, np.uint32)
+            capi.check(capi.lib().gs_memcpy_h2d(C.c_void_p(chunk.ptr.value + off.value + nb.value), poison.ctypes.data_as(C.c_void_p), poison.nbytes))
+    dirty = sr.backward(dpix)
+    for name in clean:
+        assert np.array_equal(clean[name].view(np.uint32), dirty[name].view(np.uint32)), name
+    check_pixel_stage(k, dirty, r, dpix, max_allow_frac=1.0)
+    assert np.abs(dirty["dL_dopacity"]).max() > 0
 
 
 def test_elongated_splats_cull_box_is_conservative(orc):

@@ -330,6 +330,54 @@ def test_adam_state_survives_densify(orc, quat):
     assert all(a != b for a, b in counts)
 
 
+def test_adam_state_restore_resumes_bit_exact(orc):
+    """Checkpoint / resume of an Adam run (gs_trainer_set_adam_state; SURVEY section 5: "Adam m,v would need to be added to any
+    checkpoint"): three steps -> model + moments + step counter saved -> a NEW trainer restored from them -> three more steps
+    equal six uninterrupted steps bit for bit (parameters and both moments).  Without the restore the resumed run differs."""
+    P, M, n_cams, W, H = 900, 4, 2, 96, 96
+    s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 4242)
+    proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=1e-3, lrSh=2e-3, lrScale=5e-4, lrOpacity=1e-3, lrRotation=1e-3)
+    assert tr.adam_state() == (None, None, 0)
+    for _ in range(3):
+        tr.train(proj)
+    saved_model = gs.ModelSplatsHost.fromDevice(tr.model)
+    m1, m2, steps = tr.adam_state()
+    assert steps == 3 and m1.size == m2.size == (11 + 3 * M) * ((P + 63) // 64 * 64) and np.abs(m1).max() > 0
+    for _ in range(3):
+        tr.train(proj)
+    straight, (sm1, sm2, ssteps) = _download(tr), tr.adam_state()
+    tr.close()
+    assert ssteps == 6
+
+    def resumed(restore):
+        t2 = gs.Trainer(W, H)
+        t2.model = gs.ModelSplatsDevice(saved_model)
+        t2.captureTruths(cams, fw, fb)
+        if restore:
+            t2.set_adam_state(m1, m2, steps)
+            r1, r2, rs = t2.adam_state()
+            assert rs == 3 and np.array_equal(r1.view(np.uint32), m1.view(np.uint32)) and np.array_equal(r2.view(np.uint32), m2.view(np.uint32))
+        for _ in range(3):
+            t2.train(proj)
+        out = _download(t2), t2.adam_state()
+        # a wrong size is an argument error, not a crash; clearing works
+        with pytest.raises(capi.GsError) as e:
+            t2.set_adam_state(m1[:-64], m2[:-64], 3)
+        assert e.value.status == capi.GS_ERR_INVALID_ARGUMENT
+        t2.set_adam_state(None, None, 0)
+        assert t2.adam_state() == (None, None, 0)
+        t2.close()
+        return out
+
+    got, (gm1, gm2, gsteps) = resumed(True)
+    assert gsteps == 6
+    for k in ["loc", "sh", "scale", "opac", "rot"]:
+        assert np.array_equal(got[k].view(np.uint32), straight[k].view(np.uint32)), k
+    assert np.array_equal(gm1.view(np.uint32), sm1.view(np.uint32)) and np.array_equal(gm2.view(np.uint32), sm2.view(np.uint32))
+    cold, _ = resumed(False)   # the control: a resume that drops the optimizer state is a different run
+    assert not np.array_equal(cold["loc"].view(np.uint32), straight["loc"].view(np.uint32))
+
+
 def test_preview_render_matches_oracle(orc):
     P, M, W, H = 1500, 4, 200, 120
     s = gs.synth.random_splats(P, M, 9)

@@ -62,3 +62,81 @@ def test_forced_flip_is_a_real_alternative_blend(orc):
     dpix = np.zeros((3, H, W), np.float32); dpix[:, 8, 8] = 1.0
     g = r.backward(dpix, flip_margin=2.0)   # margin > 1: every decision counts as fragile
     assert g["flip9"][:, 8].min() > 0      # every splat's dL_dopacity could move
+
+
+def _blend_pixel(r, W, px, py, bg, flip_at=None):
+    """One pixel's forward blend in plain fp32 numpy scalars, written here independently of the
+    oracle's C++; flip_at = (list position, kind): that decision (1: alpha test, 2: T test) is taken the other way.
+    Returns (colour incl. background, T, last contributor, [(position, kind, relative distance from the threshold)])."""
+    f = np.float32
+    gx = (W + 15) // 16
+    beg, end = r.get("ranges").reshape(-1, 2)[(py // 16) * gx + px // 16]
+    pl, m2, co, rgb = r.get("point_list"), r.get("means2D").reshape(-1, 2), r.get("conic_opacity").reshape(-1, 4), r.get("rgb").reshape(-1, 3)
+    T, C, last, dist = f(1.0), np.zeros(3, f), 0, []
+    for n, k in enumerate(range(beg, end), 1):
+        i = pl[k]
+        dx, dy = m2[i, 0] - f(px), m2[i, 1] - f(py)
+        power = f(-0.5) * (co[i, 0] * dx * dx + co[i, 2] * dy * dy) - co[i, 1] * dx * dy
+        if power > 0:
+            continue
+        alpha = min(f(0.99), co[i, 3] * np.exp(power, dtype=f))
+        skip = alpha < f(1.0) / f(255.0)
+        dist.append((k, 1, abs(float(alpha) - 1.0 / 255.0) * 255.0))
+        if flip_at == (k, 1):
+            skip = not skip
+        if skip:
+            continue
+        test_T = T * (f(1.0) - alpha)
+        stop = test_T < f(0.0001)
+        dist.append((k, 2, abs(float(test_T) - 0.0001) * 10000.0))
+        if flip_at == (k, 2):
+            stop = not stop
+        if stop:
+            break
+        C = C + rgb[i] * alpha * T
+        T, last = test_T, n
+    return (C + T * np.asarray(bg, f)).astype(f), T, last, dist
+
+
+def test_pixel_check_accepts_admissible_blends_and_nothing_else(orc):
+    """orc.check_pixels (the forward counterpart of the flip allowance; tests/test_gpu_raster.py::_check_forward uses it to
+    compare EVERY pixel instead of excluding the fragile ones): the fp32 oracle against itself is the nominal blend
+    everywhere; "another implementation" that takes the other branch at the scene's most fragile decision — blended here by
+    an independent numpy restatement of the pixel loop — is admissible at that pixel exactly when the margin reaches that
+    decision, and refused otherwise; results that are no blend of the pixel are refused."""
+    P, M, D, W, H, seed = 20000, 1, 0, 200, 72, 14
+    s, cams, views = make_scene(P, M, seed, W, H, n_cams=2)
+    vp = view_parts(views[1])
+    r32 = orc.Rasterizer(np.float32)
+    out32, _ = r32.forward(D, M, vp["bg"], W, H, s["loc"], s["sh"], s["opac"], s["scale"], 1.0, s["rot"], vp["view"], vp["proj"], vp["campos"],
+                           vp["tanx"], vp["tany"])
+    fT, nc, margin = r32.get("final_T"), r32.get("n_contrib"), r32.get("margin")
+    st, leaves = orc.check_pixels(r32, out32, fT, nc)
+    assert not st.any() and np.all(leaves == 1)                 # the nominal blend is examined first and is the one
+    # the independent pixel blender agrees with the oracle on the nominal blend of the most fragile pixel ...
+    pix = int(np.argmin(margin))
+    py, px = divmod(pix, W)
+    col, T, last, dist = _blend_pixel(r32, W, px, py, vp["bg"])
+    assert last == nc[pix] and abs(float(T) - fT[pix]) <= 1e-6 * fT[pix] + 1e-12 and np.allclose(col, out32[:, py, px], rtol=1e-5, atol=1e-6)
+    k, kind, d = min(dist, key=lambda t: t[2])
+    assert abs(d - margin[pix]) <= 0.5 * margin[pix] + 1e-6 and d < 1e-3    # (fp64 here, fp32 there)
+    # ... and its blend with THAT decision inverted is another admissible blend of the pixel — if the margin reaches it
+    col_f, T_f, last_f, _ = _blend_pixel(r32, W, px, py, vp["bg"], flip_at=(k, kind))
+    assert last_f != last or abs(float(T_f) - float(T)) > 1e-3 * float(T) or np.abs(col_f - col).max() > 1e-4
+    foreign, fT2, nc2 = out32.copy(), fT.copy(), nc.copy()
+    foreign[:, py, px], fT2[pix], nc2[pix] = col_f, T_f, last_f
+    st_in, leaves_in = orc.check_pixels(r32, foreign, fT2, nc2, alpha_margin=3.0 * d + 1e-6, T_margin=3.0 * d + 1e-6)
+    assert st_in[pix] == 1 and leaves_in[pix] >= 2 and (st_in != 0).sum() == 1
+    st_out, _ = orc.check_pixels(r32, foreign, fT2, nc2, alpha_margin=0.0, T_margin=0.0)
+    assert st_out[pix] == 2 and (st_out != 0).sum() == 1
+    # a pixel whose colour is off by more than any admissible blend allows is refused, with or without fragile decisions
+    bad = out32.copy()
+    bad[:, 5, 7] += 0.05
+    st2, _ = orc.check_pixels(r32, bad, fT, nc)
+    assert st2[5 * W + 7] == 2 and (st2 != 0).sum() == 1
+    nc3 = nc.copy(); nc3[11] += 1
+    st3, _ = orc.check_pixels(r32, out32, fT, nc3)
+    assert st3[11] == 2 and (st3 != 0).sum() == 1
+    # a wide margin makes many decisions fragile: the trees grow, the verdict on the oracle's own result does not change
+    st4, leaves4 = orc.check_pixels(r32, out32, fT, nc, alpha_margin=0.05, T_margin=0.05)
+    assert not st4.any()
