@@ -70,9 +70,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (default 3 = the metric's config)")
     ap.add_argument("--update", choices=["adam", "sgd"], default="adam")
-    ap.add_argument("--collective", choices=["torch", "rccl", "torch-sharded", "rccl-sharded"], default="torch",
+    ap.add_argument("--collective", choices=["auto", "torch", "rccl", "torch-sharded", "rccl-sharded", "torch-compact", "rccl-compact"], default="auto",
                     help="torch / rccl: one sum all-reduce of the gradient buffer, update replicated on every rank; *-sharded: "
-                         "reduce-scatter, update of the rank's chunk, all-gather of the parameters (gs_trainer_set_sharded_update)")
+                         "reduce-scatter, update of the rank's chunk, all-gather of the parameters (gs_trainer_set_sharded_update); "
+                         "*-compact: all-gather of the per-camera dL_dRGB records + all-reduce of the twelve non-SH planes, SH planes rebuilt "
+                         "on every rank (gs_trainer_set_compact_exchange); auto (default): torch-compact where it moves fewer bytes "
+                         "than the all-reduce (cameras < ~2 M and >= ranks), else torch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=16, help="views of the workload the CPU baseline leg times")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and the collective hook even with one rank (plumbing test)")
@@ -146,11 +149,22 @@ def main():
     tr.shard(rank, world)
     proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM if args.update == "adam" else capi.GS_UPDATE_SGD_CLAMP)
     hook = None
+    collective = args.collective
+    collective_note = None
     if use_dist:
         from gsplat_amd import dist as gsdist
+        if collective == "auto":
+            collective = "torch-compact" if gsdist.choose_exchange(n_cams, world, M) == "compact" else "torch"
+            collective_note = f"auto -> {collective}"
+        if collective.endswith("compact") and n_cams < world:
+            collective, collective_note = "torch", f"{collective} needs at least one camera per rank ({n_cams} cameras, {world} ranks): all-reduce instead"
+        # the all-reduce of the compact exchange runs beside its all-gather: a process group (communicator) of its own
+        reduce_group = dist.new_group(backend="nccl") if (collective == "torch-compact" and world > 1) else None
         hook = {"torch": lambda: gsdist.TorchAllReduce(tr), "rccl": lambda: gsdist.NativeRcclComm(tr, rank, world),
                 "torch-sharded": lambda: gsdist.TorchShardedUpdate(tr, rank, world),
-                "rccl-sharded": lambda: gsdist.NativeRcclComm(tr, rank, world, sharded=True)}[args.collective]()
+                "rccl-sharded": lambda: gsdist.NativeRcclComm(tr, rank, world, sharded=True),
+                "torch-compact": lambda: gsdist.TorchCompactExchange(tr, rank, world, cams, reduce_group),
+                "rccl-compact": lambda: gsdist.NativeRcclComm(tr, rank, world, compact_cameras=cams)}[collective]()
     setup_s = time.time() - t0
 
     def sync_all():
@@ -160,10 +174,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def replica_digests():
+        import hashlib
+        hm = gs.ModelSplatsHost.fromDevice(tr.model)
+        digest = hashlib.sha256(b"".join(np.ascontiguousarray(a[:k * hm.count]).tobytes() for a, k in
+                                         ((hm.locations, 3), (hm.shs, 3 * hm.shCoeffs), (hm.scales, 3), (hm.opacities, 1), (hm.rotations, 4)))).hexdigest()
+        digests = [None] * world
+        dist.all_gather_object(digests, digest)
+        return digests
+
     # ---- warm-up (untimed), then EXACTLY K timed steps ----
     st = None
     for _ in range(args.warmup):
         st = tr.train(proj, densify=False, stats=True)
+    if use_dist and world > 1 and collective.endswith("compact") and args.warmup > 0:
+        # The compact exchange has never run between real GPUs on the development box (one GPU): check what it must guarantee —
+        # bit-identical replicas after the warm-up steps — before timing anything, and take the all-reduce form otherwise.
+        sync_all()
+        dg = replica_digests()
+        if not all(x == dg[0] for x in dg):
+            collective_note = f"{collective} left different replicas after the warm-up ({len(set(dg))} distinct): fell back to the all-reduce form"
+            collective = "torch"
+            capi.check(L.gs_trainer_set_compact_exchange(tr.handle, None, None, None, 0, 1, 0, None))
+            tr.model = gs.ModelSplatsDevice(host)
+            hook = gsdist.TorchAllReduce(tr)
+            for _ in range(args.warmup):
+                st = tr.train(proj, densify=False, stats=True)
     # Timed region: HIP events bracket ONLY the dominant kernel's stage (render_backward) — an event costs ~3 us of
     # stream time, which is not noise against a 0.55 ms step at 2 views/GPU.  The full stage table comes from an
     # extra, untimed pass below.
@@ -237,12 +273,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
         # every rank applied the same update to the same reduced gradients: the replicas must agree bit for bit
-        import hashlib
-        hm = gs.ModelSplatsHost.fromDevice(tr.model)
-        digest = hashlib.sha256(b"".join(np.ascontiguousarray(a[:k * hm.count]).tobytes() for a, k in
-                                         ((hm.locations, 3), (hm.shs, 3 * hm.shCoeffs), (hm.scales, 3), (hm.opacities, 1), (hm.rotations, 4)))).hexdigest()
-        digests = [None] * world
-        dist.all_gather_object(digests, digest)
+        digests = replica_digests()
         replicas_identical = all(x == digests[0] for x in digests)
 
     if rank == 0 and args.no_stage_events:
@@ -320,8 +351,15 @@ def main():
                        "views_per_gpu": V_local, "width": W, "height": H, "update": args.update,
                        "sh_storage": "fp16 read copy (trainer option sh_fp16; fp32 master and gradients)" if args.sh_fp16 else "fp32",
                        "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
-                       "collective": (args.collective + (" reduce-scatter + all-gather" if args.collective.endswith("sharded") else " all-reduce")
-                                      + " of %d fp32" % ((12 + 3 * M) * P)) if use_dist else "none",
+                       "collective": ({"torch": "torch all-reduce of %d fp32" % ((12 + 3 * M) * P), "rccl": "rccl all-reduce of %d fp32" % ((12 + 3 * M) * P),
+                                       "torch-sharded": "torch reduce-scatter + all-gather of %d fp32" % ((12 + 3 * M) * P),
+                                       "rccl-sharded": "rccl reduce-scatter + all-gather of %d fp32" % ((12 + 3 * M) * P),
+                                       "torch-compact": "torch all-gather of %d dL_dRGB records of %d fp32 + all-reduce of %d fp32 (twelve non-SH planes), side by side" % (n_cams, 3 * P, 12 * P),
+                                       "rccl-compact": "rccl all-gather of %d dL_dRGB records of %d fp32 + all-reduce of %d fp32 (twelve non-SH planes), side by side" % (n_cams, 3 * P, 12 * P)}[collective]
+                                      if use_dist else "none"),
+                       "collective_note": collective_note,
+                       "wire_bytes_received_per_rank_per_step": ({f: gsdist.exchange_wire_bytes(f, n_cams, world, P, M) for f in ("allreduce", "sharded", "compact")}
+                                                                  if use_dist else None),
                        "replicas_identical_after_run": replicas_identical,
                        "mean_num_rendered_per_view": R_mean, "max_tile_list": st.max_tile_list,
                        "camera_pass_sharing": "on (default): the white/black passes of a camera share projection, tile lists and "

@@ -4,6 +4,7 @@
 // without a HIP device the entry points fail with GS_ERR_NO_DEVICE / GS_ERR_HIP.
 #include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -33,6 +34,7 @@ struct Options {
     int long_sort = -1;  // k_tile_sort_long launch: -1 by the longest-list hint (default), 0 never (lists take the global-scratch path), 1 always
     int sort_grids = -1; // test hook: >= 0 replaces the device's hint for the sort grids: small_first | mid_grid << 16 (in tiles)
     int xchg_overlap = 1; // compact exchange: the all-reduce of the geometry planes runs on a second stream beside the all-gather (0: one after the other)
+    int roctx = 0;        // roctx range around every stage of a step (rocprofv3 --marker-trace names them); default from the environment: GS_ROCTX=1
 };
 static Options g_defaults;
 // returns false for an unknown name
@@ -46,6 +48,7 @@ static bool set_option(Options& o, const char* name, int value) {
     if (strcmp(name, "long_list_sort_launch") == 0) { o.long_sort = value < 0 ? -1 : (value != 0); return true; }
     if (strcmp(name, "debug_sort_grids") == 0) { o.sort_grids = value < 0 ? -1 : value; return true; }
     if (strcmp(name, "exchange_overlap") == 0) { o.xchg_overlap = value != 0; return true; }
+    if (strcmp(name, "roctx") == 0) { o.roctx = value != 0; return true; }
     return false;
 }
 
@@ -326,6 +329,12 @@ extern "C" int gs_debug_wave_reduce9(const float* in_host, float* out_host) {
     return rc;
 }
 
+extern "C" int gs_debug_counters(unsigned long long out[8], int reset) {
+    if (!out) return GS_ERR_INVALID_ARGUMENT;
+    GS_TRY(require_device());
+    return debug_counters(out, reset != 0);
+}
+
 extern "C" int gs_hyper_defaults(gs_hyper* h) {
     if (!h) return GS_ERR_INVALID_ARGUMENT;
     h->lr_location = 0.00005f; h->lr_sh = 0.0001f; h->lr_scale = 0.00002f; h->lr_opacity = 0.0001f; h->lr_rotation = 0.000025f;
@@ -492,6 +501,7 @@ struct gs_trainer {
     hipEvent_t prev_mark = nullptr, stage_start = nullptr;
     int prev_mark_stage = -1;
     unsigned profiling_mask = 0;  // bit s: stage s is timed
+    bool roctx_open = false;      // a roctx range of this trainer is open (option "roctx")
     double stage_ms[GS_STAGE_COUNT] = { 0 };
     long long stage_launches[GS_STAGE_COUNT] = { 0 };
 };
@@ -499,6 +509,23 @@ struct gs_trainer {
 namespace {
 const char* const kStageNames[GS_STAGE_COUNT] = { "preprocess", "scan", "scatter", "tile_sort", "render_forward",
                                                   "render_backward", "splat_backward", "update", "collective" };
+// roctx ranges ("roctx ranges name each stage"): the marker library is resolved on first use, so a
+// process that never asks for ranges never loads it.  A range brackets the host-side enqueue of the stage's launches, which
+// is how rocprofv3 --marker-trace attributes the kernels launched inside it.
+struct Roctx { bool tried = false; int (*push)(const char*) = nullptr; int (*pop)() = nullptr; } g_roctx;
+bool roctx_ready() {
+    if (!g_roctx.tried) {
+        g_roctx.tried = true;
+        void* lib = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) {
+            g_roctx.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+            g_roctx.pop = (int (*)())dlsym(lib, "roctxRangePop");
+        }
+    }
+    return g_roctx.push && g_roctx.pop;
+}
 hipEvent_t prof_event(gs_trainer* t) {
     hipEvent_t e = nullptr;
     if (!t->event_pool.empty()) { e = t->event_pool.back(); t->event_pool.pop_back(); }
@@ -509,6 +536,7 @@ hipEvent_t prof_event(gs_trainer* t) {
 // reuses the end event of the stage that ran directly before it when that one was timed too, and stages outside
 // the profiling mask record nothing at all.
 void prof_stage_begin(gs_trainer* t, int stage, int stage_before) {
+    if (t->opt.roctx && roctx_ready()) { g_roctx.push(kStageNames[stage]); t->roctx_open = true; }
     if (!(t->profiling_mask >> stage & 1u)) return;
     if (t->prev_mark && t->prev_mark_stage == stage_before) { t->stage_start = t->prev_mark; return; }
     hipEvent_t e = prof_event(t);
@@ -518,6 +546,7 @@ void prof_stage_begin(gs_trainer* t, int stage, int stage_before) {
     t->marks.push_back(e);
 }
 void prof_stage_end(gs_trainer* t, int stage) {
+    if (t->roctx_open) { g_roctx.pop(); t->roctx_open = false; }
     if (!(t->profiling_mask >> stage & 1u) || !t->stage_start) return;
     hipEvent_t e = prof_event(t);
     if (!e) { t->prev_mark = nullptr; return; }
@@ -563,6 +592,7 @@ extern "C" int gs_trainer_create(int width, int height, gs_trainer** out) {
     GS_TRY(require_device());
     gs_trainer* t = new gs_trainer();
     t->opt = g_defaults;
+    if (const char* e = getenv("GS_ROCTX")) t->opt.roctx = atoi(e) != 0;
     t->W = width; t->H = height;
     if (hipGetDevice(&t->device) != hipSuccess || hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
         delete t; set_error("stream creation failed: %s", hipGetErrorString(hipGetLastError())); return GS_ERR_HIP;

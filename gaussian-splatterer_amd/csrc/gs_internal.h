@@ -206,6 +206,7 @@ int launch_image_float_to_int(const float* src, uint32_t* fb, int w, int h, hipS
 int launch_image_int_to_loss(const uint32_t* truth, const float* rast, float* loss, int w, int h, hipStream_t st);
 int launch_ranges(const Dims& d, const Scratch& s, uint32_t* ranges, hipStream_t st);
 int launch_debug_reduce9(const float* in, float* out, hipStream_t st);
+int debug_counters(unsigned long long out[8], bool reset);  // k_render.hip: the GS_DIAG_COUNT_ACTIVE build's lane counters
 
 // densify / prune on the device (k_densify.hip; the reference does it on the CPU, src/Trainer.cu:433-542)
 int launch_densify_classify(int count, int Pa, int M, const float* params, const float* grad, const gs_hyper& h, uint32_t* flags,

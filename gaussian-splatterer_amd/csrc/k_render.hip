@@ -73,6 +73,19 @@ __device__ inline void unscaled_conic(const float4& A, const float4& B, float& c
     conA = A.z * (-2.0f / LOG2E); conB = A.w * (-1.0f / LOG2E); conC = B.x * (-2.0f / LOG2E);
 }
 
+// Diagnostic counters (gs_debug_counters): with -DGS_DIAG_COUNT_ACTIVE (tools/build_variant.sh) the two blend loops count,
+// per evaluated (entry, 8x8 block) pair — a "hit" —, how many of the wave's 64 lanes do useful work: the pixel is still
+// blending and the pair passes the alpha >= 1/255 test.  The hit is branch-free, so EXEC-based hardware counters cannot see
+// this.  [0] forward hits, [1] forward active lanes, [2] backward hits, [3] backward active lanes, [4] / [5] forward / backward
+// staged (entry, block) pairs before the block test (what a kernel without the exact block test would evaluate).
+__device__ unsigned long long g_diag_counters[8];
+int debug_counters(unsigned long long out[8], bool reset) {
+    GS_HIP(hipDeviceSynchronize());
+    GS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_counters), 8 * sizeof(unsigned long long)));
+    if (reset) { const unsigned long long z[8] = { 0 }; GS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_counters), z, sizeof(z))); }
+    return GS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
@@ -108,6 +121,9 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
     // loop is the scalar walk over the ballot bits.
     float Tw = inside ? 1.0f : -1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
+#ifdef GS_DIAG_COUNT_ACTIVE
+    unsigned long long diag_hits = 0, diag_active = 0, diag_staged = 0;
+#endif
 
     for (int base = 0; base < n; base += WG) {
         if (__syncthreads_and(!(Tw > 0.0f))) break;  // whole tile saturated; also guards LDS reuse
@@ -124,6 +140,9 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
                 hit = block_reaches(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * st.B[j].x, st.C[j].y, bxlo, bxhi, bylo, byhi);
             }
             unsigned long long mask = __ballot(hit);
+#ifdef GS_DIAG_COUNT_ACTIVE
+            diag_staged += (unsigned long long)min(64, cnt - sub);
+#endif
             // the backward of the same camera walks the same lists against the same blocks: it reuses this ballot
             if (hm && lane == 0) hm[(size_t)((base + sub) >> 6) * 4 + wave] = mask;
             while (mask) {
@@ -143,9 +162,15 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
                 Tw = go ? test_T : -fabsf(Tw);
                 C0 += B.z * w; C1 += B.w * w; C2 += cb * w;
                 last = (go & valid) ? (uint32_t)(base + jj + 1) : last;
+#ifdef GS_DIAG_COUNT_ACTIVE
+                diag_hits++; diag_active += (unsigned long long)__popcll(__ballot(go & valid));
+#endif
             }
         }
     }
+#ifdef GS_DIAG_COUNT_ACTIVE
+    if (lane == 0) { atomicAdd(&g_diag_counters[0], diag_hits); atomicAdd(&g_diag_counters[1], diag_active); atomicAdd(&g_diag_counters[4], diag_staged); }
+#endif
     const float T = fabsf(Tw);
     if (inside) {
         const size_t pix = (size_t)py * d.W + px;
@@ -431,6 +456,9 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
         row[0] = Row3{ 0, 0, 0 }; row[1] = Row3{ 0, 0, 0 }; row[2] = Row3{ 0, 0, 0 };
     }
 
+#ifdef GS_DIAG_COUNT_ACTIVE
+    unsigned long long diag_hits = 0, diag_active = 0, diag_staged = 0;
+#endif
     float T = T_final;
     float arp = 0.0f;  // accum_rec . dL_dpixel, already blended with the previously visited entry
     const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
@@ -491,6 +519,9 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
         mask = 0ull;
 #endif
         const unsigned long long touched = mask;
+#ifdef GS_DIAG_COUNT_ACTIVE
+        diag_staged += (unsigned long long)max(0, min(cnt, (int)min((uint32_t)ROUND, wave_max_last - min(wave_max_last, (uint32_t)base))));
+#endif
         const uint32_t pos_slot0 = (uint32_t)(base + ROUND - 1);  // upstream's `contributor` (after its decrement) of slot 0
         // Hits are taken PARK_BATCH at a time: the inner loop is unrolled, so a hit's parking offset is an immediate and the
         // batch needs no counter arithmetic; the round's last, partly filled batch leaves the inner loop early.
@@ -510,6 +541,9 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
                 const float G0 = __builtin_amdgcn_exp2f(power);
                 const float alpha0 = fminf(ALPHA_MAX, Bc.y * G0);
                 const bool act = (pos < last_contributor) & (power <= 0.0f) & (alpha0 >= ALPHA_MIN);
+#ifdef GS_DIAG_COUNT_ACTIVE
+                diag_hits++; diag_active += (unsigned long long)__popcll(__ballot(act));
+#endif
                 const float G = act ? G0 : 0.0f, alpha = act ? alpha0 : 0.0f;
                 const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);  // exactly 1 for an inactive lane
                 T = T * inv1ma;
@@ -534,6 +568,9 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
             __builtin_amdgcn_wave_barrier();
         }
         if (lane == 0) sTouched[wave] = touched;
+#ifdef GS_DIAG_COUNT_ACTIVE
+        if (r == 0 && lane == 0) { atomicAdd(&g_diag_counters[2], diag_hits); atomicAdd(&g_diag_counters[3], diag_active); atomicAdd(&g_diag_counters[5], diag_staged); }
+#endif
         __syncthreads();
         if (wave < 3 && ROUND - 1 - lane < cnt) {
             // moments -> the reference's nine sums (dx = mean2D.x - pixel.x as upstream):

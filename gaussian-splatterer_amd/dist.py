@@ -145,12 +145,113 @@ class TorchShardedUpdate:
                                                             None, self.rank, self.world))
 
 
+def exchange_wire_bytes(form, n_cameras, world, P, M):
+    """Bytes a rank RECEIVES per step under each data-parallel form (the figure that loads its xGMI links; ring algorithms send
+    as much).  P splats (plane stride ~ P), M SH coefficients, n_cameras cameras of the iteration, `world` ranks.
+      allreduce : ring all-reduce of the (12 + 3M) P fp32 gradient buffer: 2 (G-1)/G of it
+      sharded   : reduce-scatter of the gradients + all-gather of the parameters: (G-1)/G of each
+      compact   : all-gather of one dL_dRGB record (3 P fp32) per camera of the other ranks + ring all-reduce of 12 planes"""
+    G = world
+    if G <= 1:
+        return 0
+    grad = (12 + 3 * M) * P * 4
+    if form == "allreduce":
+        return int(2 * (G - 1) / G * grad)
+    if form == "sharded":
+        return int((G - 1) / G * (grad + (11 + 3 * M) * P * 4))
+    if form == "compact":
+        slots = -(-n_cameras // G)
+        return int((G - 1) * slots * 3 * P * 4 + 2 * (G - 1) / G * 12 * P * 4)
+    raise ValueError(form)
+
+
+def choose_exchange(n_cameras, world, M):
+    """--collective auto: the compact exchange where it moves fewer bytes than the all-reduce and its layout contract holds
+    (whole cameras per rank, at least one each), i.e. while the iteration has fewer cameras than about 2 M; else all-reduce."""
+    if world > 1 and n_cameras >= world and exchange_wire_bytes("compact", n_cameras, world, 1 << 16, M) < exchange_wire_bytes("allreduce", n_cameras, world, 1 << 16, M):
+        return "compact"
+    return "allreduce"
+
+
+class TorchCompactExchange:
+    """gs_trainer_set_compact_exchange with torch.distributed: all_gather_into_tensor IN PLACE on the dL_dRGB record buffer and
+    all_reduce on the twelve geometry planes, each enqueued behind the HIP stream the library names (the all-reduce comes on the
+    trainer's second stream, beside the all-gather).  With the nccl backend the all-reduce runs on a process group of its own
+    (`reduce_group`): collectives of one communicator execute in issue order, so sharing the default group would serialise
+    the two.  cameras: every camera of the iteration in the reference's order (camera c -> rank c % world, dist.shard_views)."""
+
+    def __init__(self, trainer, rank, world, cameras, reduce_group=None):
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        self.rank, self.world = int(rank), int(world)
+        self.calls = {"all_gather": 0, "all_reduce": 0}
+        self._alias, self._streams = {}, {}
+        self.reduce_group = reduce_group
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def alias(buf, n):
+            t = self._alias.get((buf, n))
+            if t is None:
+                if len(self._alias) > 8:
+                    self._alias.clear()
+                t = torch.as_tensor(_DevPtr(buf, n), device=dev)
+                self._alias[(buf, n)] = t
+            return t
+
+        def stream_of(ptr):
+            st = self._streams.get(ptr)
+            if st is None:
+                st = self._streams[ptr] = torch.cuda.ExternalStream(ptr)
+            return st
+
+        def ag(buf, n, hip_stream, user):
+            try:
+                t = alias(buf, n)
+                c = n // self.world
+                with torch.cuda.stream(stream_of(hip_stream)):
+                    dist.all_gather_into_tensor(t, t[self.rank * c:(self.rank + 1) * c])
+                self.calls["all_gather"] += 1
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("all-gather hook failed:", repr(e), flush=True)
+                return 1
+
+        def ar(buf, n, hip_stream, user):
+            try:
+                t = alias(buf, n)
+                with torch.cuda.stream(stream_of(hip_stream)):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.reduce_group)
+                self.calls["all_reduce"] += 1
+                return 0
+            except Exception as e:
+                print("all-reduce hook failed:", repr(e), flush=True)
+                return 1
+
+        self._ag, self._ar = capi.ALLREDUCE_FN(ag), capi.ALLREDUCE_FN(ar)
+        campos = np.ascontiguousarray([c.location for c in cameras], np.float32).reshape(-1, 3)
+        capi.check(capi.lib().gs_trainer_set_compact_exchange(trainer.handle, C.cast(self._ag, C.c_void_p), C.cast(self._ar, C.c_void_p), None,
+                                                              self.rank, self.world, campos.shape[0], campos.ctypes.data_as(C.c_void_p)))
+
+
 class NativeRcclComm:
     """The library's own RCCL communicator (gs_comm_*): the 128-byte unique id is created on rank 0
     and broadcast through torch.distributed's store; the collective itself never touches Python.
     sharded=True installs ncclReduceScatter / ncclAllGather as the sharded update's hooks instead of the all-reduce."""
 
-    def __init__(self, trainer, rank, world, sharded=False):
+    def __init__(self, trainer, rank, world, sharded=False, compact_cameras=None):
+        from . import capi
+        L = capi.lib()
+        self.handle = self._communicator(rank, world)
+        if compact_cameras is not None:   # compact exchange: a second communicator carries the all-reduce beside the all-gather
+            self.handle2 = self._communicator(rank, world)
+            campos = np.ascontiguousarray([c.location for c in compact_cameras], np.float32).reshape(-1, 3)
+            capi.check(L.gs_trainer_attach_comm_compact(trainer.handle, self.handle, self.handle2, campos.shape[0], campos.ctypes.data_as(C.c_void_p)))
+        else:
+            capi.check((L.gs_trainer_attach_comm_sharded if sharded else L.gs_trainer_attach_comm)(trainer.handle, self.handle))
+
+    @staticmethod
+    def _communicator(rank, world):
         import torch.distributed as dist
         from . import capi
         L = capi.lib()
@@ -161,6 +262,6 @@ class NativeRcclComm:
             box = [bytes(ident.raw) if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             C.memmove(ident, box[0], capi.GS_COMM_ID_BYTES)
-        self.handle = C.c_void_p()
-        capi.check(L.gs_comm_create(ident, rank, world, C.byref(self.handle)))
-        capi.check((L.gs_trainer_attach_comm_sharded if sharded else L.gs_trainer_attach_comm)(trainer.handle, self.handle))
+        handle = C.c_void_p()
+        capi.check(L.gs_comm_create(ident, rank, world, C.byref(handle)))
+        return handle

@@ -83,6 +83,11 @@ int gs_set_option(const char* name, int value);
  * parked hit in the kernel's contraction).  in_host[q*64 + lane] (q = 0..8), out_host[lane]: lane 2q of a row holds that
  * row's total of value q (q < 8), lane 1 its total of value 8. */
 int gs_debug_wave_reduce9(const float* in_host, float* out_host);
+/* Diagnostic: counters of the render kernels, all zero unless the library was built with -DGS_DIAG_COUNT_ACTIVE (a tuning
+ * build, tools/build_variant.sh): [0] forward hits — evaluated (tile entry, 8x8 pixel block) pairs —, [1] lanes of those hits that
+ * blend (pixel alive, alpha >= 1/255), [2] / [3] the same for the backward, [4] / [5] forward / backward pairs staged in front of
+ * the block test.  active / (64 * hits) is the useful-lane fraction of a hit.  reset != 0 zeroes them. */
+int gs_debug_counters(unsigned long long out[8], int reset);
 
 /* ------------------------------------------------------------------------------------------
  * Raw device-memory helpers (current HIP device).  They exist so that C / ctypes callers and the
@@ -220,6 +225,10 @@ int gs_trainer_apply(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs
  * launches' grids from the tile order of two steps ago; 0 never launches them; 1 always does, with grids that need no hint.
  * "debug_sort_grids" (default -1; a test hook): a value >= 0 replaces that hint by small_first | mid_grid << 16 (tiles): any
  * grids must produce the same lists.
+ * "exchange_overlap" (default 1): see gs_trainer_set_compact_exchange.
+ * "roctx" (default 0, or 1 when the environment holds GS_ROCTX=1 at gs_trainer_create): a roctx range named like
+ * gs_stage_name() is pushed around the launches of every stage of a step (librocprofiler-sdk-roctx is loaded on first use), so
+ * that `rocprofv3 --marker-trace --kernel-trace` attributes the kernels to the nine stages.
  * Changing "share_camera_passes" regroups the passes already set. */
 int gs_trainer_set_option(gs_trainer* trainer, const char* name, int value);
 

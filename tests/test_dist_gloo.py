@@ -144,3 +144,94 @@ def test_shard_views_partition():
             else:
                 sizes = [len(m) for m in shards]
                 assert max(sizes) - min(sizes) <= 1
+
+
+def _compact_worker(rank, world, port, q, n_cams):
+    """The compact exchange (gs_trainer_set_compact_exchange; csrc/k_splat_bwd.hip k_exchange_pack / k_sh_rebuild) restated
+    around the oracle's per-pass backward, per-pass form: every rank leaves the sums of the twelve non-SH planes over its
+    passes and the dL_dcolour record of each of its passes in its chunk of the gather buffer — slot (black ? cmax : 0) +
+    camera / world of rank camera % world —, the planes are all-reduced, the records all-gathered (in place), and every rank
+    rebuilds the SH planes from ALL records in the single-process order (white passes of cameras 0 .. C-1, then black)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+    import torch
+    import torch.distributed as dist
+
+    import gsplat_amd as gs
+    from oracle import pyoracle as orc
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P, M, D, W, H = 300, 4, 1, 64, 48
+    f32 = np.float32
+    s = gs.synth.random_splats(P, M, 11)
+    views = gs.camera.train_views(gs.camera.get_cameras(n_cams), W, H)
+    V = 2 * n_cams
+    S = f32(V)
+    truths = np.random.default_rng(5).integers(0, 2 ** 32, (V, W * H), dtype=np.uint32)
+    mine = gs.dist.shard_views(V, rank, world)
+    cmax = -(-n_cams // world)
+    slots = 2 * cmax
+    geo = np.zeros((12, P), f32)                        # loc 3 | scale 3 | opacity | rot 4 | var
+    rgb = np.zeros((world, slots, 3, P), f32)           # the gather buffer; this rank fills rgb[rank]
+    rast = {}
+    for v in range(V):                                   # every rank knows every camera: the forward state serves the rebuild's basis
+        b = views[v]
+        r = orc.Rasterizer(np.float32)
+        img, _ = r.forward(D, M, b[37:40], W, H, s["loc"], s["sh"], s["opac"], s["scale"], 1.0, s["rot"], b[0:16], b[16:32], b[32:35], float(b[35]), float(b[36]))
+        rast[v] = (r, img)
+    for v in mine:                                       # the rank's own passes, in its local order (white passes first)
+        r, img = rast[v]
+        g = r.backward(orc.image_int_to_loss(truths[v], img, W, H))
+        gm = g["dL_dmean3D"].reshape(P, 3)
+        geo[11] += np.sqrt((gm[:, 0] * gm[:, 0] + gm[:, 1] * gm[:, 1]) + gm[:, 2] * gm[:, 2]) / S
+        geo[0:3] += gm.T / S
+        geo[3:6] += g["dL_dscale"].reshape(P, 3).T / S
+        geo[6] += g["dL_dopacity"] / S
+        geo[7:11] += g["dL_drot"].reshape(P, 4).T / S
+        c, black = v % n_cams, v >= n_cams
+        assert c % world == rank
+        rgb[rank, (cmax if black else 0) + c // world] = g["dL_dcolor"].reshape(P, 3).T
+    tg, flat = torch.from_numpy(geo), torch.from_numpy(rgb.reshape(-1))
+    chunk = flat.numel() // world
+    dist.all_reduce(tg, op=dist.ReduceOp.SUM)
+    dist.all_gather_into_tensor(flat, flat[rank * chunk:(rank + 1) * chunk])   # in place, as dist.TorchCompactExchange does it
+    sh = np.zeros(3 * M * P, f32)
+    for v in range(V):                                   # the single-process accumulation order (src/Trainer.cu:311-314, :60-64)
+        c, black = v % n_cams, v >= n_cams
+        rec = rgb[c % world, (cmax if black else 0) + c // world]
+        sums9 = np.zeros((P, 9), f32)
+        sums9[:, 0:3] = rec.T
+        sh += orc.chain(rast[v][0], sums9)["dL_dsh"] / S
+    q.put((rank, mine, geo.copy(), sh))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_cams", [(8, 8),     # BASELINE cfg3's 8 cameras on 8 ranks
+                                           (8, 16),    # cfg4's 16 cameras: two per rank
+                                           (2, 3)])    # cameras % ranks != 0: rank 1 sends a zero record in its second slots
+def test_compact_exchange_rebuilds_the_single_process_sh_gradients(world, n_cams):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_compact_worker, args=(r, world, port, q, n_cams)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single = _single(n_cams)
+    P, M = 300, 4
+    sizes = [3 * P, 3 * M * P, 3 * P, P, 4 * P, P]
+    loc, sh, scale, opac, rot, var = np.split(single, np.cumsum(sizes)[:-1])
+    assert np.abs(sh).max() > 0
+    for rank, mine, geo, got_sh in res:
+        assert np.array_equal(got_sh.view(np.uint32), sh.view(np.uint32)), rank          # SH gradients: the single-process bits on every rank
+        assert np.array_equal(geo.view(np.uint32), res[0][2].view(np.uint32))            # identical reduced planes everywhere
+    geo = res[0][2]
+    for got, want in ((geo[0:3].T.reshape(-1), loc), (geo[3:6].T.reshape(-1), scale), (geo[6], opac), (geo[7:11].T.reshape(-1), rot), (geo[11], var)):
+        assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()                    # the same sums, re-associated by the all-reduce
+    import gsplat_amd as gs
+    assert gs.dist.exchange_wire_bytes("compact", 8, 8, 100000, 16) == 7 * 3 * 100000 * 4 + int(2 * 7 / 8 * 12 * 100000 * 4)
+    assert gs.dist.choose_exchange(8, 8, 16) == "compact" and gs.dist.choose_exchange(32, 8, 16) == "allreduce" and gs.dist.choose_exchange(4, 8, 16) == "allreduce"

@@ -24,7 +24,7 @@ def _run(extra):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("collective", ["torch", "rccl", "torch-sharded", "rccl-sharded"])
+@pytest.mark.parametrize("collective", ["torch", "rccl", "torch-sharded", "rccl-sharded", "torch-compact", "rccl-compact"])
 def test_collective_hook_runs_with_one_rank(collective):
     base = _run([])
     got = _run(["--force-dist", "--collective", collective])

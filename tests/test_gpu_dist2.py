@@ -131,6 +131,116 @@ def test_sharded_update_with_adam_and_densify_equals_the_allreduce_form():
     assert s0.size == a0.size and np.array_equal(s0.view(np.uint32), a0.view(np.uint32))
 
 
+def _grad_planes(tr, n_splats):
+    import ctypes as C
+    from gsplat_amd import capi
+    ptr, n = tr.grad_buffer()
+    tr.synchronize()
+    buf = np.empty(n, np.float32)
+    capi.check(capi.lib().gs_memcpy_d2h(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n * 4))
+    planes = 12 + 3 * M
+    return buf.reshape(planes, n // planes)[:, :n_splats].copy()
+
+
+def _compact_run(rank, world, hook_factory, overlap=1):
+    """One gradients-only step in the fused form, one in the per-pass form (what a densify step runs), then three training
+    steps of Adam, the third with densify: (gradient planes fused, gradient planes per pass, final model)."""
+    import gsplat_amd as gs
+    from gsplat_amd import capi
+    s, cams, fw, fb = _scene()
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = s["D"]
+    host.capacity = P + 500
+    tr = gs.Trainer(W, H)
+    tr.set_option("exchange_overlap", overlap)
+    tr.model = gs.ModelSplatsDevice(host)
+    tr.captureTruths(cams, fw, fb)
+    tr.shard(rank, world)
+    hook = hook_factory(tr, cams) if hook_factory else None
+    still = gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0)
+    tr.train(still)
+    g_fused = _grad_planes(tr, P)
+    tr.set_option("fuse_camera_passes", 0)
+    tr.train(still)
+    g_pass = _grad_planes(tr, P)
+    tr.set_option("fuse_camera_passes", 1)
+    proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=1e-3, lrSh=2e-3, lrScale=5e-4, lrOpacity=1e-3, lrRotation=1e-3,
+                      paramDensifyVariance=0.05, paramCullOpacity=0.15, paramSplitSize=0.06)
+    for k in range(4):
+        tr.train(proj, densify=(k == 2))
+    h = gs.ModelSplatsHost.fromDevice(tr.model)
+    n = h.count
+    model = np.concatenate([h.locations[:3 * n], h.shs[:3 * M * n], h.scales[:3 * n], h.opacities[:n], h.rotations[:4 * n]])
+    calls = dict(hook.calls) if hook is not None else None
+    tr.close()
+    del hook
+    return g_fused, g_pass, model, calls
+
+
+def _compact_worker(rank, world, port, q, overlap):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gsplat_amd import dist as gsdist
+    # a group of its own for the all-reduce, as bench.py gives it under nccl: the two collectives are in flight side by side
+    reduce_group = dist.new_group(backend="gloo")
+    out = _compact_run(rank, world, lambda tr, cams: gsdist.TorchCompactExchange(tr, rank, world, cams, reduce_group), overlap)
+    q.put((rank,) + out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compact_exchange_two_ranks_on_one_gpu():
+    """gs_trainer_set_compact_exchange with two processes on the GPU (gloo carries the two collectives): all-gather of the
+    cameras' dL_dRGB records + all-reduce of the twelve non-SH planes on the trainer's second stream, SH planes rebuilt on
+    every rank.  Checked against a single-process run of all four cameras:
+      * the SH gradient planes are the single-GPU step's BIT FOR BIT, in the fused form and in the per-pass form (a densify
+        step's) — no collective sums them;
+      * the twelve other planes are the same sums re-associated by the all-reduce (<= 2e-6 of the plane's scale), `var` zero
+        in the fused form and present in the per-pass form;
+      * the replicas are bit-identical after Adam steps with a densify step in the middle, with the all-reduce overlapped
+        (second stream + events) and with the two collectives issued one after the other — and both orders give the same bits,
+        which a missing dependency between the streams would not."""
+    import multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    ctx = mp.get_context("spawn")
+    results = {}
+    for overlap in (1, 0):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_compact_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        results[overlap] = res
+    sf, sp, smodel, _ = _compact_run(0, 1, None)
+    sh = slice(3, 3 + 3 * M)
+    geo = [0, 1, 2] + list(range(3 + 3 * M, 12 + 3 * M))
+    for overlap, res in results.items():
+        (_, f0, p0, m0, c0), (_, f1, p1, m1, c1) = res
+        assert c0 == c1 == {"all_gather": 6, "all_reduce": 6}, (c0, c1)
+        for got_f, got_p in ((f0, p0), (f1, p1)):
+            assert np.array_equal(got_f[sh].view(np.uint32), sf[sh].view(np.uint32))   # SH gradients: the single-GPU bits
+            assert np.array_equal(got_p[sh].view(np.uint32), sp[sh].view(np.uint32))
+            for got, want in ((got_f, sf), (got_p, sp)):
+                for pl in geo:
+                    assert np.abs(got[pl] - want[pl]).max() <= 2e-6 * np.abs(want[pl]).max() + 1e-30, pl
+            assert not got_f[-1].any() and got_p[-1].any() and np.abs(sf[sh]).max() > 0
+        assert np.array_equal(f0.view(np.uint32), f1.view(np.uint32)) and np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+        assert m0.size == m1.size and np.array_equal(m0.view(np.uint32), m1.view(np.uint32))            # replicas bit-identical
+        assert m0.size != (11 + 3 * M) * P                                                                   # densify changed the count
+    for k in (1, 2, 3):   # overlapped and serialised exchange: the same bits
+        assert np.array_equal(results[1][0][k].view(np.uint32), results[0][0][k].view(np.uint32))
+    moved = np.abs(smodel[:3 * 100] - results[1][0][3][:3 * 100]).max()
+    assert moved < 1e-2   # and the run stays next to the single-process one (Adam amplifies the re-associated sums: no bit claim here)
+
+
 def test_eight_way_view_sharding_sums_to_the_single_shard_gradients():
     """shard the 16 passes of a step over 8 ranks (2 passes = one camera each, as bench.py --gpus 8
     does), run every shard's accumulate on the one GPU in turn, sum the eight averaged-gradient buffers on the host
