@@ -63,6 +63,23 @@ def stage_bytes(stage, P, M, N, R, V):
     return 0
 
 
+def stage_form_bytes(stage, P, M, N, R, V, G):
+    """Compulsory bytes of the form that actually RAN: V passes in G camera groups.  Passes of one camera share projection,
+    lists, forward blend (final_T, n_contrib) and, on a step without densify, the backward's list walk and gradient rows; the
+    averaged-gradient planes are written once per step (SURVEY 8d counts a read-modify-write per view)."""
+    form = {
+        "preprocess": G * ((44 + 12 * M) + 75) * P,
+        "scan": G * 8 * P,
+        "scatter": G * (20 * P + 12 * R),
+        "tile_sort": G * 32 * R,
+        "render_forward": G * (40 * R + 8 * N) + V * 12 * N,
+        "render_backward": G * (40 * R + 44 * P) + V * 24 * N,
+        "splat_backward": G * ((44 + 12 * M) + 44 + 31) * P + (48 + 12 * M) * P,
+        "update": 7 * (44 + 12 * M) * P,
+    }
+    return form.get(stage, 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,7 +98,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and the collective hook even with one rank (plumbing test)")
     ap.add_argument("--no-stage-events", action="store_true", help="diagnostic only: time the steps without the per-stage HIP events (no roofline object)")
     ap.add_argument("--sh-fp16", action="store_true", help="trainer option sh_fp16: the projection reads a half-precision copy of the SH planes (BASELINE config 5)")
-    ap.add_argument("--long-steps", type=int, default=500, help="steps of the untimed-by-the-metric long run reported as `long_run` (0: skip)")
+    ap.add_argument("--long-steps", type=int, default=2000, help="steps of the untimed-by-the-metric long run reported as `long_run` (0: skip); the default keeps "
+                    "the GPU busy for ~2.5 s at cfg3, long enough for an external utilisation sampler to see the run")
     ap.add_argument("--views", type=int, default=0, help="diagnostic only: override the number of views per step (not the metric's config)")
     args = ap.parse_args()
 
@@ -219,6 +237,8 @@ def main():
     # only figure on record — clocks, caches and the run-ahead host queue have all settled by then
     capi.check(L.gs_trainer_set_profiling(tr.handle, 0))
     n_long = args.long_steps
+    if n_long > 0 and args.steps > 0:   # keep the long run within ~4 s whatever the configuration (cfg5: 7 ms per step)
+        n_long = max(min(n_long, int(4.0 / max(elapsed / args.steps, 1e-6))), min(n_long, 50))
     long_run = None
     if n_long > 0:
         sync_all()
@@ -302,6 +322,7 @@ def main():
         form_bytes = {"render_backward": n_groups * (40 * R_mean + 44 * P) + V_local * 24 * N,
                       "render_forward": n_groups * 40 * R_mean + V_local * 12 * N + n_groups * 8 * N}.get(dom, dom_bytes)
         step_bytes = sum(stage_bytes(k, P, M, N, R_mean, V_local) for k in kern) + (48 + 12 * M) * P
+        step_form_bytes = sum(stage_form_bytes(k, P, M, N, R_mean, V_local, n_groups) for k in kern)
         ms_per_step = elapsed / args.steps * 1e3
         # Counters of the dominant kernel (rocprofv3 --pmc passes of the same command, tools/pmc_pass.sh, committed as
         # profiles/pmc_latest.json).  They are only reported when they were collected from the kernel sources this run
@@ -376,7 +397,11 @@ def main():
                                       "that ran (camera passes share lists and rows): the smaller, stricter figure",
                          "step_algorithmic_GB": step_bytes / 1e9,
                          "step_achieved_GBs": step_bytes / (ms_per_step * 1e-3) / 1e9,
-                         "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "step_form_GB": step_form_bytes / 1e9,
+                         "step_frac_form": step_form_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "step_note": "step_frac prices SURVEY 8d's per-VIEW bytes x the views of the step although projection, lists, forward blend and "
+                                      "the backward ran once per CAMERA; step_frac_form prices the bytes of the form that ran, every stage: the stricter figure"},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
             "stages_note": "all-stage table: HIP events over %d extra steps run after the timed region (timing every stage costs ~3 us of stream time per event)" % min(args.steps, 10),
             "long_run": long_run,

@@ -34,6 +34,7 @@ struct Options {
     int long_sort = -1;  // k_tile_sort_long launch: -1 by the longest-list hint (default), 0 never (lists take the global-scratch path), 1 always
     int sort_grids = -1; // test hook: >= 0 replaces the device's hint for the sort grids: small_first | mid_grid << 16 (in tiles)
     int xchg_overlap = 1; // compact exchange: the all-reduce of the geometry planes runs on a second stream beside the all-gather (0: one after the other)
+    int reuse_masks = 1;  // the backward reuses the forward's per-(tile sub-block, wave) block ballots; 0: it runs the block test itself (same bits)
     int roctx = 0;        // roctx range around every stage of a step (rocprofv3 --marker-trace names them); default from the environment: GS_ROCTX=1
 };
 static Options g_defaults;
@@ -49,6 +50,7 @@ static bool set_option(Options& o, const char* name, int value) {
     if (strcmp(name, "debug_sort_grids") == 0) { o.sort_grids = value < 0 ? -1 : value; return true; }
     if (strcmp(name, "exchange_overlap") == 0) { o.xchg_overlap = value != 0; return true; }
     if (strcmp(name, "roctx") == 0) { o.roctx = value != 0; return true; }
+    if (strcmp(name, "reuse_hit_masks") == 0) { o.reuse_masks = value != 0; return true; }
     return false;
 }
 
@@ -350,8 +352,7 @@ extern "C" int gs_hyper_defaults(gs_hyper* h) {
 // =============================================================================================
 // model
 // =============================================================================================
-// clear_on != nullptr: the planes are cleared on that stream (asynchronously) instead of the null stream
-static int model_alloc(int capacity, int sh_degree, int sh_coeffs, int count, gs_model** out, hipStream_t* clear_on = nullptr) {
+static int model_alloc(int capacity, int sh_degree, int sh_coeffs, int count, gs_model** out) {
     gs_model* m = new gs_model();
     m->capacity = capacity; m->sh_degree = sh_degree; m->sh_coeffs = sh_coeffs; m->count = count;
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; set_error("hipGetDevice failed"); return GS_ERR_HIP; }
@@ -360,7 +361,7 @@ static int model_alloc(int capacity, int sh_degree, int sh_coeffs, int count, gs
     hipError_t e = hipMalloc((void**)&m->planes, bytes);
     if (e != hipSuccess) { delete m; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GS_ERR_OUT_OF_MEMORY; }
     m->planes_bytes = bytes;
-    e = clear_on ? hipMemsetAsync(m->planes, 0, bytes, *clear_on) : hipMemset(m->planes, 0, bytes);
+    e = hipMemset(m->planes, 0, bytes);
     if (e != hipSuccess) { (void)hipFree(m->planes); delete m; set_error("hipMemset failed: %s", hipGetErrorString(e)); return GS_ERR_HIP; }
     *out = m;
     return GS_OK;
@@ -632,6 +633,11 @@ extern "C" int gs_trainer_set_model(gs_trainer* t, gs_model* m) {
     t->model = m;
     t->adam_valid = false; t->adam_t = 0; t->accumulated = false;
     t->sh16_of = nullptr; t->steps_on_these_lists = 0;
+    // The densify pool (three spare plane sets, each sized for the model it last served + 50 %: ~1 GB at 1M splats, M = 16) is
+    // kept only while it fits the model in use: a smaller model gives the memory back (the next densify allocates afresh).
+    const size_t need = plane_buffer_floats(m->sh_coeffs, m->Pa) * sizeof(float);
+    for (DevBuf* b : { &t->spare_planes, &t->spare_m, &t->spare_v })
+        if (b->cap > 2 * need + (64u << 20)) b->release();
     return GS_OK;
 }
 extern "C" gs_model* gs_trainer_get_model(gs_trainer* t) { return t ? t->model : nullptr; }
@@ -784,6 +790,7 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
         }
         Scratch s = t->train.s;
         s.truth = t->truth.as<uint32_t>();
+        if (!t->opt.reuse_masks) s.hit_masks = nullptr;  // the forward stores no ballots, the backward tests the blocks itself
         if (t->opt.sh_fp16 && P > 0) {
             // the half-precision read copy: made here when it does not belong to these planes (new model, densify, a
             // sharded update that refreshed only this rank's chunk), otherwise kept current by the update kernel

@@ -177,6 +177,10 @@ int gs_trainer_destroy(gs_trainer* trainer);
  * (src/ui/UiFrame.cpp:157-158,173-174,261-262,448-449).  The trainer takes ownership of `model`
  * and destroys the previous one.  Optimizer state (Adam) is reset. */
 int gs_trainer_set_model(gs_trainer* trainer, gs_model* model);
+/* Memory note: after its first densify step a trainer keeps three spare plane sets (parameters and the two Adam moments, the
+ * sets the previous densify replaced, each with 50 % headroom: about 1 GB at 1M splats with M = 16) so that later densify
+ * steps neither allocate nor free; growing a spare does synchronise the device once.  gs_trainer_set_model returns the spares
+ * to the allocator when the new model is less than half their size. */
 /* public member Trainer::model, src/Trainer.cuh:50 (borrowed pointer; owned by the trainer). */
 gs_model* gs_trainer_get_model(gs_trainer* trainer);
 /* Replaces Trainer::captureTruths (src/Trainer.cu:218-250), whose OptiX renderer is out of scope:
@@ -225,6 +229,8 @@ int gs_trainer_apply(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs
  * launches' grids from the tile order of two steps ago; 0 never launches them; 1 always does, with grids that need no hint.
  * "debug_sort_grids" (default -1; a test hook): a value >= 0 replaces that hint by small_first | mid_grid << 16 (tiles): any
  * grids must produce the same lists.
+ * "reuse_hit_masks" (default 1): the backward reuses the block ballots the forward of the same camera stored (which entries of
+ * a tile list can reach which 8x8 pixel block) instead of running the block test again; 0 makes it test itself.  Bit-identical.
  * "exchange_overlap" (default 1): see gs_trainer_set_compact_exchange.
  * "roctx" (default 0, or 1 when the environment holds GS_ROCTX=1 at gs_trainer_create): a roctx range named like
  * gs_stage_name() is pushed around the launches of every stage of a step (librocprofiler-sdk-roctx is loaded on first use), so

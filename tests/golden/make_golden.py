@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/cfg1.npz from the CPU oracle (oracle/gs_oracle.cpp) at BASELINE cfg1 scale:
+"""Generates tests/golden/cfg1.npz (and seam_cases.npz, below) from the CPU oracle (oracle/gs_oracle.cpp) at BASELINE cfg1 scale:
 1k random-init splats (seed 0x5EED0001), one camera, white + black pass, 256x256, truth = quantised
 oracle render of the second splat set (seed + 1000, P/2 splats).
 
@@ -57,8 +57,50 @@ def build():
     return out, truths
 
 
+# The seam-level parity cases of tests/test_gpu_raster.py::CASES beyond cfg1 (ragged sizes, SH degree 0 / 2 / 3, 79 splat
+# blocks): fingerprints of the oracle's forward AND backward, small enough to commit, so that an edit of the oracle cannot
+# drift silently on the cases the GPU path is compared with.
+SEAM_CASES = [
+    # P,   M, D, W,   H,   seed
+    (800, 1, 0, 250, 130, 11),
+    (600, 9, 2, 96, 160, 12),
+    (500, 16, 3, 128, 128, 13),
+    (20000, 1, 0, 200, 72, 14),
+]
+
+
+def build_seam_cases():
+    out = {}
+    for n, (P, M, D, W, H, seed) in enumerate(SEAM_CASES):
+        s = gs.synth.random_splats(P, M, seed)
+        views = gs.camera.train_views(gs.camera.get_cameras(2), W, H)
+        b = views[1]                                   # the pass test_backward_parity takes: camera 1, white background
+        r = orc.Rasterizer(np.float32)
+        img, R = r.forward(D, M, b[37:40], W, H, s["loc"], s["sh"], s["opac"], s["scale"], 1.0, s["rot"], b[0:16], b[16:32], b[32:35],
+                           float(b[35]), float(b[36]))
+        dpix = np.random.default_rng(seed).uniform(-1, 1, (3, H, W)).astype(np.float32)
+        g = r.backward(dpix)
+        k = f"c{n}_"
+        out[k + "shape"] = np.array([P, M, D, W, H, seed], np.int64)
+        out[k + "num_rendered"] = R
+        for name in ("point_list", "ranges", "radii", "tiles_touched", "n_contrib"):
+            out[k + name + "_sha256"] = hashlib.sha256(r.get(name).tobytes()).hexdigest()
+        out[k + "image_mean"] = img.reshape(3, -1).mean(1)
+        out[k + "image_row"] = img[:, H // 2, :].copy()
+        out[k + "final_T_row"] = r.get("final_T").reshape(H, W)[H // 2].copy()
+        for name, stride in (("dL_dmean3D", 3), ("dL_dsh", 3 * M), ("dL_dscale", 3), ("dL_drot", 4), ("dL_dopacity", 1), ("dL_dcov3D", 6)):
+            a = g[name].reshape(P, stride)
+            out[k + name + "_head"] = a[:64].copy()                      # the first 64 splats, every component
+            out[k + name + "_abs_sum"] = np.abs(a.astype(np.float64)).sum(0)   # and the whole array's weight per component
+    return out
+
+
 if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
     out, _ = build()
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfg1.npz")
+    path = os.path.join(here, "cfg1.npz")
     np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+    path = os.path.join(here, "seam_cases.npz")
+    np.savez_compressed(path, **build_seam_cases())
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -52,3 +52,29 @@ def test_cfg1_matches_golden(orc):
         n_bad, worst = unexplained("avg_" + k, g[k], gold["avg_" + k], bud[k]["budget"], stride[k])
         assert n_bad == 0, (k, n_bad, worst)
     tr.close()
+
+
+def test_seam_cases_match_the_golden_fingerprints():
+    """The committed fingerprints of the seam cases beyond cfg1 (tests/golden/seam_cases.npz): lists, ranges, radii and tile
+    counts bit-exact by SHA-256, one image row and one final-T row to 1e-4 where no threshold decision is within reach."""
+    gold = np.load(os.path.join(HERE, "golden", "seam_cases.npz"))
+    n = 0
+    while f"c{n}_shape" in gold.files:
+        P, M, D, W, H, seed = (int(x) for x in gold[f"c{n}_shape"])
+        s = gs.synth.random_splats(P, M, seed)
+        views = gs.camera.train_views(gs.camera.get_cameras(2), W, H)
+        sr = SeamRaster()
+        img, R = sr.forward(s, D, M, view_parts(views[1]), W, H)
+        k = f"c{n}_"
+        assert R == int(gold[k + "num_rendered"])
+        assert hashlib.sha256(sr.field("binning", "point_list", np.uint32).tobytes()).hexdigest() == str(gold[k + "point_list_sha256"])
+        assert hashlib.sha256(sr.field("image", "ranges", np.uint32).tobytes()).hexdigest() == str(gold[k + "ranges_sha256"])
+        assert hashlib.sha256(sr.field("geometry", "tiles_touched", np.uint32).tobytes()).hexdigest() == str(gold[k + "tiles_touched_sha256"])
+        agree = sr.field("image", "n_contrib", np.uint32)
+        if hashlib.sha256(agree.tobytes()).hexdigest() == str(gold[k + "n_contrib_sha256"]):   # no decision flipped anywhere: rows comparable as they are
+            for c in range(3):
+                assert_close_rel(f"case {n} image row[{c}]", img[c, H // 2], gold[k + "image_row"][c], rtol=1e-4, floor=1e-3)
+            assert_close_rel(f"case {n} final_T row", sr.field("image", "final_T", np.float32).reshape(H, W)[H // 2], gold[k + "final_T_row"], rtol=1e-4, floor=1e-4)
+        assert np.abs(img.reshape(3, -1).mean(1) - gold[k + "image_mean"]).max() <= 1e-4
+        n += 1
+    assert n == 4

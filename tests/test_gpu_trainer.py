@@ -450,6 +450,41 @@ def test_camera_pass_sharing_is_bit_identical(orc):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def test_backward_own_block_test_equals_the_reused_ballots(orc):
+    """The backward normally reuses the block ballots the forward of the same camera stored (trainer option "reuse_hit_masks",
+    default on); with the option off it runs the block test itself — the branch the rasterizer-seam form of an older layout
+    took.  Both must give the same bits, in the fused-pair step and in the per-pass form, incl. a scene with long lists."""
+    for P, spread in ((2500, 1.0), (3000, 0.05)):
+        W, H, M, n_cams = (128, 96, 4, 2) if spread == 1.0 else (32, 32, 1, 1)
+        res = []
+        for reuse in (1, 0):
+            s = gs.synth.random_splats(P, M, 777)
+            s["loc"] = (s["loc"] * spread).astype(np.float32)
+            if spread != 1.0:
+                s["opac"] = (s["opac"] * 0.05).astype(np.float32)
+            cams = gs.camera.get_cameras(n_cams, 10.0, 20.0 if spread != 1.0 else 60.0)
+            rng = np.random.default_rng(12)
+            fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+            fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+            host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+            host.shDegree = s["D"]
+            tr = gs.Trainer(W, H)
+            tr.set_option("reuse_hit_masks", reuse)
+            tr.model = gs.ModelSplatsDevice(host)
+            tr.captureTruths(cams, fw, fb)
+            st = tr.accumulate(stats=True)
+            g_pass = _read_grads(tr, P, M)
+            tr.train(gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0))
+            g_fused = _read_grads(tr, P, M)
+            res.append((st.num_rendered, st.max_tile_list, g_pass, g_fused))
+            tr.close()
+        assert res[0][:2] == res[1][:2] and (spread == 1.0 or res[0][1] > 512)
+        for a, b in ((res[0][2], res[1][2]), (res[0][3], res[1][3])):
+            for k in a:
+                assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (P, k)
+        assert np.abs(res[0][3]["loc"]).max() > 0
+
+
 def test_arena_overflow_grows_and_replays(orc):
     """A binning arena that is too small is detected on the device, grown on the host and the step replayed before
     the update is applied: results equal the run with an ample arena, and the statistics report the regrow."""

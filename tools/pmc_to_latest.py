@@ -17,7 +17,8 @@ from source_stamp import source_stamp  # noqa: E402
 src, dst = sys.argv[1], sys.argv[2]
 s = json.load(open(src))
 stage_of = {"gs::k_render_bwd_pair": "render_backward", "gs::k_render_bwd1": "render_backward_per_pass", "gs::k_render_fwd": "render_forward",
-            "gs::k_tile_build_sort": "tile_sort", "void gs::k_preprocess<3, false>": "preprocess", "void gs::k_splat_bwd_view<3>": "splat_backward",
+            "gs::k_tile_build_sort": "tile_sort", "void gs::k_preprocess<3, false>": "preprocess", "void gs::k_splat_bwd_view<3, false>": "splat_backward", "void gs::k_splat_bwd_reduce<3>": "splat_backward_reduce",
+            "void gs::k_tile_scatter<true, 256>": "tile_scatter", "void gs::k_tile_count<256>": "tile_count",
             "gs::k_coarse_scatter": "scatter", "gs::k_update": "update"}
 out = {"_stamp": {"source_sha256": source_stamp(), "command": "tools/pmc_pass.sh (rocprofv3 --pmc, one pass per counter group) around `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`; "
                   "per kernel the LARGEST dispatch (the 16-view launch)"}}
