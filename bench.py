@@ -101,6 +101,12 @@ def main():
     ap.add_argument("--long-steps", type=int, default=2000, help="steps of the untimed-by-the-metric long run reported as `long_run` (0: skip); the default keeps "
                     "the GPU busy for ~2.5 s at cfg3, long enough for an external utilisation sampler to see the run")
     ap.add_argument("--views", type=int, default=0, help="diagnostic only: override the number of views per step (not the metric's config)")
+    ap.add_argument("--prewarm-seconds", type=float, default=3.0,
+                    help="untimed: run the same training steps for about this long BEFORE the W warm-up steps, so that the timed region measures the "
+                         "steady state a training run lives in (an MI355X that has been idle needs seconds of this bursty load — a 1.2 ms step of a dozen short "
+                         "kernels — to reach its sustained clocks: 734 steps/s in the first 50 steps after setup, 827 after 1.5 s, 870 after 3 s, 875-890 "
+                         "from 6 s on; a step of 7 ms, cfg5, shows no such ramp); 0 switches it off.  The cold window is measured first and reported "
+                         "beside it (`cold_start`, `prewarm` in the JSON line)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,6 +207,42 @@ def main():
         dist.all_gather_object(digests, digest)
         return digests
 
+    # ---- the cold-start window: W warm-up steps + K timed steps right after setup, as rounds 1-3 measured the metric ----
+    cold_start = None
+    if args.prewarm_seconds > 0 and args.steps > 0:
+        for _ in range(args.warmup):
+            tr.train(proj, densify=False)
+        sync_all()
+        t_c = time.perf_counter()
+        for _ in range(args.steps):
+            tr.train(proj, densify=False)
+        sync_all()
+        cold_s = time.perf_counter() - t_c
+        if use_dist:
+            tc = torch.tensor([cold_s], dtype=torch.float64)
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            cold_s = float(tc[0])
+        cold_start = {"value": args.steps / cold_s, "unit": "steps/s", "steps": args.steps, "ms_per_step": cold_s / args.steps * 1e3,
+                      "note": "the same W warm-up + K timed steps run right after setup, BEFORE the pre-warm: a device that has been idle; what rounds 1-3 reported as the metric"}
+    # ---- pre-warm (untimed, by wall time): bring the device to its sustained clocks ----
+    prewarm = None
+    if args.prewarm_seconds > 0:
+        sync_all()
+        t_p, n_p = time.perf_counter(), 0
+        while True:
+            for _ in range(20):
+                tr.train(proj, densify=False)
+            n_p += 20
+            tr.synchronize()
+            go_on = time.perf_counter() - t_p < args.prewarm_seconds
+            if use_dist:   # every rank runs the same number of steps (a collective sits inside each): rank 0 decides
+                flag = torch.tensor([1 if go_on else 0], dtype=torch.int32)
+                dist.broadcast(flag, src=0)
+                go_on = bool(flag[0])
+            if not go_on:
+                break
+        prewarm = {"steps": n_p, "seconds": round(time.perf_counter() - t_p, 3),
+                   "note": "untimed steps of the same workload run before the W warm-up steps (--prewarm-seconds): the timed region then measures sustained clocks"}
     # ---- warm-up (untimed), then EXACTLY K timed steps ----
     st = None
     for _ in range(args.warmup):
@@ -404,6 +446,8 @@ def main():
                                       "the backward ran once per CAMERA; step_frac_form prices the bytes of the form that ran, every stage: the stricter figure"},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
             "stages_note": "all-stage table: HIP events over %d extra steps run after the timed region (timing every stage costs ~3 us of stream time per event)" % min(args.steps, 10),
+            "cold_start": cold_start,
+            "prewarm": prewarm,
             "long_run": long_run,
             "per_pass_form": per_pass,
             "densify_step": None if densify_ms is None else {"ms": round(densify_ms, 3), "count_before": st_d.count_before, "count_after": st_d.count_after,

@@ -77,7 +77,9 @@ __device__ inline void unscaled_conic(const float4& A, const float4& B, float& c
 // per evaluated (entry, 8x8 block) pair — a "hit" —, how many of the wave's 64 lanes do useful work: the pixel is still
 // blending and the pair passes the alpha >= 1/255 test.  The hit is branch-free, so EXEC-based hardware counters cannot see
 // this.  [0] forward hits, [1] forward active lanes, [2] backward hits, [3] backward active lanes, [4] / [5] forward / backward
-// staged (entry, block) pairs before the block test (what a kernel without the exact block test would evaluate).
+// staged (entry, block) pairs before the block test (what a kernel without the exact block test would evaluate); [6] / [7]
+// backward only: the iterations the same rounds would take if hits were packed by 8x4 half / by 4x4 quadrant (sum over
+// rounds of the largest per-half / per-quadrant hit count) — the ceiling of any finer-grained scheme.
 __device__ unsigned long long g_diag_counters[8];
 int debug_counters(unsigned long long out[8], bool reset) {
     GS_HIP(hipDeviceSynchronize());
@@ -457,7 +459,8 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
     }
 
 #ifdef GS_DIAG_COUNT_ACTIVE
-    unsigned long long diag_hits = 0, diag_active = 0, diag_staged = 0;
+    unsigned long long diag_hits = 0, diag_active = 0, diag_staged = 0, diag_pack2 = 0, diag_pack4 = 0;
+    unsigned diag_half[2] = { 0, 0 }, diag_quad[4] = { 0, 0, 0, 0 };
 #endif
     float T = T_final;
     float arp = 0.0f;  // accum_rec . dL_dpixel, already blended with the previously visited entry
@@ -542,7 +545,15 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
                 const float alpha0 = fminf(ALPHA_MAX, Bc.y * G0);
                 const bool act = (pos < last_contributor) & (power <= 0.0f) & (alpha0 >= ALPHA_MIN);
 #ifdef GS_DIAG_COUNT_ACTIVE
-                diag_hits++; diag_active += (unsigned long long)__popcll(__ballot(act));
+                {
+                    const unsigned long long am = __ballot(act);
+                    diag_hits++; diag_active += (unsigned long long)__popcll(am);
+                    // what packing entries at a finer granularity could reclaim: hits that reach the upper / lower 8x4 half and each of
+                    // the four 4x4 quadrants of the block (lane = 8 y + x)
+                    diag_half[0] += (am & 0x00000000FFFFFFFFull) != 0; diag_half[1] += (am & 0xFFFFFFFF00000000ull) != 0;
+                    diag_quad[0] += (am & 0x000000000F0F0F0Full) != 0; diag_quad[1] += (am & 0x00000000F0F0F0F0ull) != 0;
+                    diag_quad[2] += (am & 0x0F0F0F0F00000000ull) != 0; diag_quad[3] += (am & 0xF0F0F0F000000000ull) != 0;
+                }
 #endif
                 const float G = act ? G0 : 0.0f, alpha = act ? alpha0 : 0.0f;
                 const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);  // exactly 1 for an inactive lane
@@ -569,7 +580,14 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
         }
         if (lane == 0) sTouched[wave] = touched;
 #ifdef GS_DIAG_COUNT_ACTIVE
-        if (r == 0 && lane == 0) { atomicAdd(&g_diag_counters[2], diag_hits); atomicAdd(&g_diag_counters[3], diag_active); atomicAdd(&g_diag_counters[5], diag_staged); }
+        // iterations of a round if its hits were packed two (8x4 halves) / four (4x4 quadrants) entries to a wave iteration
+        diag_pack2 += max(diag_half[0], diag_half[1]);
+        diag_pack4 += max(max(diag_quad[0], diag_quad[1]), max(diag_quad[2], diag_quad[3]));
+        diag_half[0] = diag_half[1] = 0; diag_quad[0] = diag_quad[1] = diag_quad[2] = diag_quad[3] = 0;
+        if (r == 0 && lane == 0) {
+            atomicAdd(&g_diag_counters[2], diag_hits); atomicAdd(&g_diag_counters[3], diag_active); atomicAdd(&g_diag_counters[5], diag_staged);
+            atomicAdd(&g_diag_counters[6], diag_pack2); atomicAdd(&g_diag_counters[7], diag_pack4);
+        }
 #endif
         __syncthreads();
         if (wave < 3 && ROUND - 1 - lane < cnt) {

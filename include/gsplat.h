@@ -86,7 +86,8 @@ int gs_debug_wave_reduce9(const float* in_host, float* out_host);
 /* Diagnostic: counters of the render kernels, all zero unless the library was built with -DGS_DIAG_COUNT_ACTIVE (a tuning
  * build, tools/build_variant.sh): [0] forward hits — evaluated (tile entry, 8x8 pixel block) pairs —, [1] lanes of those hits that
  * blend (pixel alive, alpha >= 1/255), [2] / [3] the same for the backward, [4] / [5] forward / backward pairs staged in front of
- * the block test.  active / (64 * hits) is the useful-lane fraction of a hit.  reset != 0 zeroes them. */
+ * the block test, [6] / [7] backward iterations if hits were packed by 8x4 half / 4x4 quadrant.  active / (64 * hits) is the
+ * useful-lane fraction of a hit.  reset != 0 zeroes them. */
 int gs_debug_counters(unsigned long long out[8], int reset);
 
 /* ------------------------------------------------------------------------------------------

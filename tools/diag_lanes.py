@@ -53,7 +53,11 @@ out = {"config": args.config, "splats": P, "views": 2 * n_cams, "width": W, "hei
        "forward": {"staged_pairs": c[4], "hits": c[0], "active_lanes": c[1], "hit_fraction_of_staged": c[0] / max(c[4], 1),
                    "useful_lane_fraction_of_a_hit": c[1] / (64.0 * c[0])},
        "backward": {"staged_pairs": c[5], "hits": c[2], "active_lanes": c[3], "hit_fraction_of_staged": c[2] / max(c[5], 1),
-                    "useful_lane_fraction_of_a_hit": c[3] / (64.0 * max(c[2], 1))},
+                    "useful_lane_fraction_of_a_hit": c[3] / (64.0 * max(c[2], 1)),
+                    "iterations_if_packed_by_8x4_half": c[6], "iterations_if_packed_by_4x4_quadrant": c[7],
+                    "packing_ceiling": {"8x4": c[6] / max(c[2], 1), "4x4": c[7] / max(c[2], 1),
+                                        "note": "iterations relative to today's hits if two / four entries shared a wave iteration (per 64-entry round: the largest "
+                                                "per-half / per-quadrant hit count); every packed iteration would read its entries' records with per-lane LDS addresses"}},
        "note": "hit = evaluated (tile entry, 8x8 block) pair; staged = pairs in front of the exact block test; useful lane = pixel alive and alpha >= 1/255"}
 print(json.dumps(out))
 tr.close()
