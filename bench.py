@@ -101,6 +101,16 @@ def main():
     ap.add_argument("--long-steps", type=int, default=2000, help="steps of the untimed-by-the-metric long run reported as `long_run` (0: skip); the default keeps "
                     "the GPU busy for ~2.5 s at cfg3, long enough for an external utilisation sampler to see the run")
     ap.add_argument("--views", type=int, default=0, help="diagnostic only: override the number of views per step (not the metric's config)")
+    ap.add_argument("--exchange-overlap", type=int, default=0,
+                    help="*-compact only: 1 runs the all-reduce of the twelve non-SH planes on the trainer's second stream and a communicator of its own, "
+                         "beside the all-gather; 0 (default) issues the two collectives one after the other on one communicator — the form with "
+                         "nothing concurrent in it, for a measurement that has never had an 8-GPU node to rehearse on")
+    ap.add_argument("--dist-backend", default="cpu:gloo,cuda:nccl",
+                    help="torch.distributed backend; the default carries device tensors over nccl (= RCCL).  'gloo' is for REHEARSALS of the multi-rank path "
+                         "on a box with one GPU (RCCL refuses two ranks on one device): tests/test_gpu_dist2.py runs two ranks of this script that way")
+    ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (default: LOCAL_RANK); rehearsals on one GPU pass 0")
+    ap.add_argument("--no-verify-exchange", action="store_true",
+                    help="skip the check of the data-parallel step against an unsharded step on rank 0 before the warm-up (N > 1)")
     ap.add_argument("--prewarm-seconds", type=float, default=3.0,
                     help="untimed: run the same training steps for about this long BEFORE the W warm-up steps, so that the timed region measures the "
                          "steady state a training run lives in (an MI355X that has been idle needs seconds of this bursty load — a 1.2 ms step of a dozen short "
@@ -127,8 +137,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        device = local_rank if args.device < 0 else args.device
+        torch.cuda.set_device(device)
+        if "nccl" in args.dist_backend:
+            dist.init_process_group(backend=args.dist_backend, device_id=torch.device("cuda", device), rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
 
     import gsplat_amd as gs
     from gsplat_amd import capi
@@ -154,7 +168,9 @@ def main():
     tr.model = gs.ModelSplatsDevice(thost)
     mine = gs.dist.shard_views(V_total, rank, world)
     framesW, framesB = [None] * n_cams, [None] * n_cams
-    for v in mine:
+    verify = use_dist and world > 1 and not args.no_verify_exchange
+    # rank 0 also renders the other ranks' truth images when the exchange is verified against an unsharded step (below)
+    for v in (range(V_total) if (verify and rank == 0) else mine):
         cam = cams[v % n_cams]
         white = v < n_cams
         fb = tr.render(W, H, 1.0, cam, background=(1.0, 1.0, 1.0) if white else (0.0, 0.0, 0.0)).reshape(-1)
@@ -182,8 +198,10 @@ def main():
             collective_note = f"auto -> {collective}"
         if collective.endswith("compact") and n_cams < world:
             collective, collective_note = "torch", f"{collective} needs at least one camera per rank ({n_cams} cameras, {world} ranks): all-reduce instead"
-        # the all-reduce of the compact exchange runs beside its all-gather: a process group (communicator) of its own
-        reduce_group = dist.new_group(backend="nccl") if (collective == "torch-compact" and world > 1) else None
+        # with --exchange-overlap the all-reduce of the compact exchange runs beside its all-gather: a process group (communicator) of its own
+        overlap = bool(args.exchange_overlap) and collective.endswith("compact")
+        tr.set_option("exchange_overlap", 1 if overlap else 0)
+        reduce_group = dist.new_group(backend="nccl" if "nccl" in args.dist_backend else args.dist_backend) if (collective == "torch-compact" and world > 1 and overlap) else None
         hook = {"torch": lambda: gsdist.TorchAllReduce(tr), "rccl": lambda: gsdist.NativeRcclComm(tr, rank, world),
                 "torch-sharded": lambda: gsdist.TorchShardedUpdate(tr, rank, world),
                 "rccl-sharded": lambda: gsdist.NativeRcclComm(tr, rank, world, sharded=True),
@@ -207,6 +225,49 @@ def main():
         dist.all_gather_object(digests, digest)
         return digests
 
+    # ---- N > 1: the data-parallel step checked on THIS hardware against an unsharded step, before anything is timed ----
+    # One gradients-only step (learning rates 0) through the installed exchange; rank 0 runs the same iteration unsharded on a second
+    # trainer and compares the averaged-gradient planes: SH planes bit for bit under the compact exchange (no collective sums them),
+    # everything to 2e-5 of the plane's scale (the collective re-associates the pass sums).  A mismatch falls back to the
+    # all-reduce through torch.distributed, the form with the least machinery, and says so in the JSON line.
+    exchange_check = None
+    if verify:
+        def grad_planes(trainer):
+            ptr, n = trainer.grad_buffer()
+            trainer.synchronize()
+            buf = np.empty(n, np.float32)
+            capi.check(L.gs_memcpy_d2h(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n * 4))
+            return buf.reshape(12 + 3 * M, -1)[:, :P]
+
+        def check_once():
+            still = gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0)
+            tr.train(still, densify=False)
+            res = None
+            if rank == 0:
+                ref = gs.Trainer(W, H)
+                if args.sh_fp16:
+                    ref.set_option("sh_fp16", 1)
+                ref.model = gs.ModelSplatsDevice(host)
+                ref.captureTruths(cams, framesW, framesB)
+                ref.train(still, densify=False)
+                g_ref, g_dp = grad_planes(ref), grad_planes(tr)
+                ref.close()
+                scale = np.abs(g_ref).max(1) + 1e-30
+                dev = float((np.abs(g_dp - g_ref).max(1) / scale).max())
+                sh_same = bool(np.array_equal(g_dp[3:3 + 3 * M].view(np.uint32), g_ref[3:3 + 3 * M].view(np.uint32)))
+                res = {"max_plane_deviation": dev, "sh_planes_bit_identical_to_unsharded_step": sh_same,
+                       "ok": bool(dev <= 2e-5 and np.isfinite(g_dp).all() and np.abs(g_ref).max() > 0)}
+            box = [res]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        exchange_check = dict(check_once(), collective=collective)
+        if not exchange_check["ok"] and collective != "torch":
+            collective_note = f"{collective} failed the check against the unsharded step ({exchange_check}): fell back to the torch all-reduce"
+            capi.check(L.gs_trainer_set_compact_exchange(tr.handle, None, None, None, 0, 1, 0, None))
+            capi.check(L.gs_trainer_set_sharded_update(tr.handle, None, None, None, 0, 1))
+            collective = "torch"
+            hook = gsdist.TorchAllReduce(tr)
+            exchange_check = dict(check_once(), collective=collective, after_fallback=True)
     # ---- the cold-start window: W warm-up steps + K timed steps right after setup, as rounds 1-3 measured the metric ----
     cold_start = None
     if args.prewarm_seconds > 0 and args.steps > 0:
@@ -421,6 +482,7 @@ def main():
                                        "rccl-compact": "rccl all-gather of %d dL_dRGB records of %d fp32 + all-reduce of %d fp32 (twelve non-SH planes), side by side" % (n_cams, 3 * P, 12 * P)}[collective]
                                       if use_dist else "none"),
                        "collective_note": collective_note,
+                       "exchange_checked_against_unsharded_step": exchange_check,
                        "wire_bytes_received_per_rank_per_step": ({f: gsdist.exchange_wire_bytes(f, n_cams, world, P, M) for f in ("allreduce", "sharded", "compact")}
                                                                   if use_dist else None),
                        "replicas_identical_after_run": replicas_identical,

@@ -18,7 +18,7 @@ def _run(extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "2", "--steps", "3", "--warmup", "1",
-                          "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline", "--prewarm-seconds", "0", "--long-steps", "0"] + extra, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     return json.loads(line)

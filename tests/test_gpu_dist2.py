@@ -241,6 +241,34 @@ def test_compact_exchange_two_ranks_on_one_gpu():
     assert moved < 1e-2   # and the run stays next to the single-process one (Adam amplifies the re-associated sums: no bit claim here)
 
 
+@pytest.mark.parametrize("extra", [[], ["--collective", "torch-compact", "--exchange-overlap", "1"], ["--collective", "torch-sharded"]])
+def test_bench_two_rank_rehearsal_on_one_gpu(extra):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), rehearsed on the one GPU with
+    the gloo backend (RCCL refuses two ranks on one device: tools/try_nccl_two_ranks.py): camera sharding, the exchange chosen
+    by --collective auto (cfg2 has M = 1: the all-reduce; the explicit runs take the compact exchange and the sharded update),
+    the check of the data-parallel step against an unsharded step on rank 0, pre-warm loop, timed region, replica digests."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "2", "--steps", "5", "--warmup", "2",
+           "--dist-backend", "gloo", "--device", "0", "--prewarm-seconds", "0.3", "--long-steps", "20", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and cfg["views_per_gpu"] == 4 and cfg["replicas_identical_after_run"] is True
+    chk = cfg["exchange_checked_against_unsharded_step"]
+    assert chk["ok"] and chk["max_plane_deviation"] <= 2e-5 and "after_fallback" not in chk, chk
+    want = {0: "torch all-reduce", 4: "torch all-gather of 4 dL_dRGB records", 2: "torch reduce-scatter"}[len(extra)]
+    assert cfg["collective"].startswith(want), cfg["collective"]
+    if len(extra) == 4:
+        assert chk["sh_planes_bit_identical_to_unsharded_step"] is True
+    assert d["cold_start"]["value"] > 0 and d["prewarm"]["steps"] >= 20 and d["value"] > 0
+    wb = cfg["wire_bytes_received_per_rank_per_step"]
+    assert wb["allreduce"] == (12 + 3) * 10000 * 4 and wb["compact"] == 2 * 3 * 10000 * 4 + 12 * 10000 * 4
+
+
 def test_eight_way_view_sharding_sums_to_the_single_shard_gradients():
     """shard the 16 passes of a step over 8 ranks (2 passes = one camera each, as bench.py --gpus 8
     does), run every shard's accumulate on the one GPU in turn, sum the eight averaged-gradient buffers on the host

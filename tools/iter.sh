@@ -11,7 +11,7 @@ d = json.load(open("gpurun_out/${tag}_bench.json"))
 print(round(d["value"], 1), "steps/s", round(d["ms_per_step"], 4), "ms", d["stages_ms_per_launch"])
 PY
 if [ "$2" = "pmc" ]; then
-  BENCH_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --long-steps 0" tools/pmc_pass.sh gpurun_out/${tag}_pmc \
+  BENCH_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --long-steps 0 --prewarm-seconds 0" tools/pmc_pass.sh gpurun_out/${tag}_pmc \
     "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
     "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU" > gpurun_out/${tag}_pmc.txt 2>&1
   grep -E "k_render_bwd_pair|k_render_fwd" gpurun_out/${tag}_pmc.txt

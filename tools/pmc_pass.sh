@@ -7,7 +7,7 @@ set -e
 out=$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-args=${BENCH_ARGS:---steps 2 --warmup 1 --no-cpu-baseline}
+args=${BENCH_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --long-steps 0 --prewarm-seconds 0}
 i=0
 for grp in "$@"; do
     i=$((i + 1))
