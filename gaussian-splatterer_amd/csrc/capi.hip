@@ -87,6 +87,7 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
     d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
     d.sgx = (d.gx + STILE - 1) / STILE; d.sgy = (d.gy + STILE - 1) / STILE; d.NST = d.sgx * d.sgy;
     d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = cull < 0 ? g_defaults.cull : cull; d.long_sort = 1; d.mid_sort = 1; d.small_first = 0; d.mid_grid = 0;
+    d.epoch = 1;
     return d;
 }
 
@@ -142,7 +143,8 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
 }
 
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, hmask, color, finalT, ncontrib, scan_tmp, sgrads, shjac;
+    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, rowmark, hmask, color, finalT, ncontrib, scan_tmp, sgrads, shjac;
+    const void* rowmark_cleared = nullptr;  // the allocation of `rowmark` that has been zeroed (a new one holds stale bytes: the caller clears it and restarts the epochs)
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
     Scratch s{};
@@ -180,6 +182,7 @@ struct ScratchSet {
         GS_TRY(plist.ensure(v * Rcap * 4));
         GS_TRY(slist.ensure(v * Rcap * 4));
         GS_TRY(G.ensure(v * Rcap * G_STRIDE * 4));
+        GS_TRY(rowmark.ensure(want_splat_grads ? 64 + v * Rcap + 64 : 128));  // [64 zero bytes: Scratch::zero_row][marks][slack for the marks read one trip ahead]
         GS_TRY(hmask.ensure(want_splat_grads ? v * hit_mask_words(Rcap, T) * 4 * sizeof(unsigned long long) : 8));
         GS_TRY(color.ensure(v * 3 * N * 4));
         GS_TRY(finalT.ensure(v * N * 4));
@@ -211,6 +214,8 @@ struct ScratchSet {
         s.point_list = plist.as<uint32_t>();
         s.slot_list = slist.as<uint32_t>();
         s.G = G.as<float>();
+        s.zero_row = rowmark.as<float>();
+        s.row_epoch = rowmark.as<uint8_t>() + 64;
         s.hit_masks = want_splat_grads ? hmask.as<unsigned long long>() : nullptr;  // only a trainer runs a backward behind the forward
         s.out_color = color.as<float>();
         s.final_T = finalT.as<float>();
@@ -220,7 +225,7 @@ struct ScratchSet {
         return GS_OK;
     }
     void release() {
-        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &wghist, &colscan, &coarse_count, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &hmask, &color,
+        for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &wghist, &colscan, &coarse_count, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &rowmark, &hmask, &color,
                            &finalT, &ncontrib, &scan_tmp, &sgrads, &shjac })
             b->release();
     }
@@ -478,6 +483,7 @@ struct gs_trainer {
     const void* views_on_device = nullptr;  // where the current view block was last uploaded (null: must upload)
     bool stats_stale = false;        // `last` lacks the device-side numbers (loss, list lengths) of the newest step
     uint32_t Rcap = 0;
+    int row_epoch = 0;               // mark of the newest launch's gradient rows (1 .. 255; Scratch::row_epoch), advanced per accumulate attempt
     gs_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
     gs_collective_fn shard_rs = nullptr, shard_ag = nullptr;  // sharded update (gs_trainer_set_sharded_update)
@@ -788,6 +794,13 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
             d.small_first = std::min(d.T, t->opt.sort_grids & 0xFFFF);
             d.mid_grid = std::max(1, std::min(d.T, t->opt.sort_grids >> 16));
         }
+        // the marks of this attempt's gradient rows: a fresh epoch; all marks are cleared when the epochs wrap or the buffer is new
+        if (t->row_epoch >= 255 || t->train.rowmark_cleared != t->train.rowmark.p) {
+            GS_HIP(hipMemsetAsync(t->train.rowmark.p, 0, t->train.rowmark.cap, t->stream));
+            t->train.rowmark_cleared = t->train.rowmark.p;
+            t->row_epoch = 0;
+        }
+        d.epoch = ++t->row_epoch;
         Scratch s = t->train.s;
         s.truth = t->truth.as<uint32_t>();
         if (!t->opt.reuse_masks) s.hit_masks = nullptr;  // the forward stores no ballots, the backward tests the blocks itself
@@ -1334,7 +1347,7 @@ ImageLayout image_layout(int W, int H) {
     L.total = o;
     return L;
 }
-struct BinLayout { size_t clist, cdepth, ids, plist, slist, G, hmask, total; uint32_t Rcap; };
+struct BinLayout { size_t clist, cdepth, ids, plist, slist, G, hmask, marks, total; uint32_t Rcap; };
 BinLayout bin_layout(int R, int T) {
     BinLayout L; L.Rcap = (uint32_t)std::max(R, 1);
     size_t o = 0;
@@ -1345,6 +1358,7 @@ BinLayout bin_layout(int R, int T) {
     L.slist = o; o = al(o + (size_t)L.Rcap * 4);
     L.G = o; o = al(o + (size_t)L.Rcap * G_STRIDE * 4);
     L.hmask = o; o = al(o + hit_mask_words(L.Rcap, T) * 4 * sizeof(unsigned long long));  // (appended: the offsets above are part of the seam)
+    L.marks = o; o = al(o + 64 + (size_t)L.Rcap + 64);  // 64 zero bytes (Scratch::zero_row), then which slots hold a gradient row (Scratch::row_epoch)
     L.total = o;
     return L;
 }
@@ -1373,6 +1387,8 @@ Scratch seam_scratch(char* geom, const GeomLayout& g, char* img, const ImageLayo
         s.slot_list = reinterpret_cast<uint32_t*>(bin + b->slist);
         s.G = reinterpret_cast<float*>(bin + b->G);
         s.hit_masks = reinterpret_cast<unsigned long long*>(bin + b->hmask);
+        s.zero_row = reinterpret_cast<const float*>(bin + b->marks);
+        s.row_epoch = reinterpret_cast<uint8_t*>(bin + b->marks) + 64;
     }
     return s;
 }
@@ -1468,6 +1484,7 @@ extern "C" int gs_rasterize_forward(gs_alloc_fn geometry_alloc, void* geometry_u
     s = seam_scratch(geom, gl, img, il, bin, &bl);
     s.out_color = out_color;
     d.Rcap = bl.Rcap;
+    GS_HIP(hipMemsetAsync(bin + bl.marks, 0, 64 + (size_t)bl.Rcap + 64, st));  // the caller's chunk is uninitialised; the backward marks its rows with epoch 1
     GS_TRY(stage_bin_render(d, s, st));  // P == 0: empty lists, background image
     GS_TRY(launch_ranges(d, s, reinterpret_cast<uint32_t*>(img + il.ranges), st));
     GS_HIP(hipStreamSynchronize(st));

@@ -95,6 +95,7 @@ struct Dims {
     int small_first;  // first position of the tile order the short-list sorter's grid covers: short lists in front of it (there
                       //    are few: the order is longest first) are sorted by k_tile_sort_mid.  0: its grid covers the whole order
     int mid_grid;     // workgroups per camera of k_tile_sort_mid (0: a default); it walks on in strides when the head is longer
+    int epoch;        // 1 .. 255: the mark of this launch's gradient rows in Scratch::row_epoch
 };
 
 // Device pointers of the scratch.  Arrays marked [G] are per geometry group (camera), [V] per pass.
@@ -123,8 +124,12 @@ struct Scratch {
     uint32_t* point_list;      // [V][Rcap]  sorted splat ids
     uint32_t* slot_list;       // [V][Rcap]  sorted slots
     float* G;                  // [V][Rcap][G_STRIDE]
+    uint8_t* row_epoch;        // [V][Rcap]  a gradient row exists this step iff its byte equals Dims::epoch: the backward writes rows (and
+                               //            marks them) only for entries some pixel block evaluated; everything else is an implicit zero row
+                               //            that is neither written nor read (a dense scene: 84 % of all rows)
     unsigned long long* hit_masks;  // [G][hit_mask_words(Rcap, T)][4]  per (tile, 64-entry sub-block, wave): which entries can reach the
                                // wave's 8x8 block — the forward's ballots, reused by the backward (null: the backward tests again)
+    const float* zero_row;     // sixteen zero floats in front of row_epoch's allocation: what k_splat_bwd_view reads in place of an absent row
     float* splat_grads;        // [V][Pa][16]  per-(view,splat) backward records (trainer only)
     float* sh_jac;             // [G][Pa][12]  d colour / d view direction (9 used), written by the projection (trainer only, else null)
     const uint16_t* sh16;      // [3M][Pa] IEEE half read copy of the SH planes (trainer option "sh_fp16"), or null: read the fp32 planes

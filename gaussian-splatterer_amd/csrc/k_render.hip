@@ -386,6 +386,7 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
     const uint32_t* __restrict__ slist = s.slot_list + (size_t)g * d.Rcap + start;
     const GeomRec* __restrict__ geom = s.geom + (size_t)g * d.Pa;
     float* const Gout = s.G + (size_t)vin[0] * d.Rcap * G_STRIDE;
+    uint8_t* const Gmark = s.row_epoch + (size_t)vin[0] * d.Rcap;
     const unsigned long long* const hm = s.hit_masks ? s.hit_masks + ((size_t)g * hit_mask_words(d.Rcap, d.T) + (start >> 6) + (uint32_t)tile) * 4 : nullptr;
 
     // per-pixel state
@@ -452,11 +453,10 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
         s.loss[(size_t)vin[tid] * d.T + tile] = (sLoss[tid][0] + sLoss[tid][1]) + (sLoss[tid][2] + sLoss[tid][3]);
     if (n == 0) return;
     const int rounds = (max_last + ROUND - 1) / ROUND;
-    // entries no pixel reaches still own a gradient row: zero it
-    for (int e = rounds * ROUND + tid; e < n; e += WG) {
-        Row3* row = reinterpret_cast<Row3*>(Gout + (size_t)slist[e] * G_STRIDE);
-        row[0] = Row3{ 0, 0, 0 }; row[1] = Row3{ 0, 0, 0 }; row[2] = Row3{ 0, 0, 0 };
-    }
+    // Entries no pixel reaches have an all-zero gradient row.  Such rows are neither written here nor read by the per-splat
+    // kernel: a row exists iff its mark (row_epoch[slot]) equals this launch's epoch, and only the flush below sets marks.
+    // (Through round 3 every entry got its row: in a dense scene — 1100 entries per tile of which the pixels saturate after
+    // ~170 — 84 % of the rows were zeros, 2.2 GB written here and read again by k_splat_bwd_view.)
 
 #ifdef GS_DIAG_COUNT_ACTIVE
     unsigned long long diag_hits = 0, diag_active = 0, diag_staged = 0, diag_pack2 = 0, diag_pack4 = 0;
@@ -590,7 +590,9 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
         }
 #endif
         __syncthreads();
-        if (wave < 3 && ROUND - 1 - lane < cnt) {
+        // a slot no wave evaluated this round (no block of the tile can reach alpha >= 1/255 there) keeps its implicit zero row
+        const bool any_hit = (((sTouched[0] | sTouched[1]) | (sTouched[2] | sTouched[3])) >> lane) & 1ull;
+        if (wave < 3 && ROUND - 1 - lane < cnt && any_hit) {
             // moments -> the reference's nine sums (dx = mean2D.x - pixel.x as upstream):
             //   dL_dmean2D.x = -0.5 W op (conA * S[u dx] + conB * S[u dy]),  .y = -0.5 H op (conC * S[u dy] + conB * S[u dx])
             //   dL_dconic    = -0.5 op (S[u dx dx], S[u dx dy], S[u dy dy]),  dL_dopacity = S[u]
@@ -623,6 +625,7 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
 #endif
 #ifndef GS_DIAG_NO_ROWS  // timing experiment: the kernel without its gradient-row stores
             row[wave] = out;
+            if (wave == 0) Gmark[sSlot[lane]] = (uint8_t)d.epoch;
 #endif
         }
     }

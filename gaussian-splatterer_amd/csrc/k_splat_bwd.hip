@@ -192,28 +192,63 @@ __device__ inline void splat_backward_core(const gs_view& vp, int W, int H, cons
     }
 }
 
-// Sum the nine pixel-stage partials of splat i over its `tiles` slots, ascending slot order.
-__device__ inline void gather_rows(const float* __restrict__ Gv, uint32_t first, uint32_t tiles, float sum[9]) {
+// Sum the nine pixel-stage partials of splat i over its `tiles` slots, ascending slot order.  A slot holds a row only if its mark
+// equals the launch's epoch (k_render.hip: the backward writes and marks rows for evaluated entries only); the others are
+// implicit zero rows.  The marks are fetched one trip ahead of the rows they guard.  The first trip cannot know its marks
+// before it asks for its rows: it requests marks and rows together (slots behind the splat's last one are redirected to
+// `zero` by selecting the ADDRESS) and selects afterwards — the only absent rows ever read, at most GS_GATHER_ROWS per splat;
+// cfg3's splats touch ~7 tiles, so most of their rows are in this trip and none of them waits for a mark.
+__device__ inline void gather_rows(const float* __restrict__ Gv, const uint8_t* __restrict__ marks, uint32_t epoch, const float* __restrict__ zero,
+                                   uint32_t first, uint32_t tiles, float sum[9]) {
 #pragma unroll
     for (int q = 0; q < 9; q++) sum[q] = 0.0f;
     const Row3* row = reinterpret_cast<const Row3*>(Gv + (size_t)first * G_STRIDE);
-    uint32_t k = 0;
-    // four rows in flight per trip (the loop is latency-bound: a splat touches ~7 tiles); the adds keep slot order
-    for (; k + 4 <= tiles; k += 4, row += 12) {
-        Row3 r[12];
+    const Row3* zrow = reinterpret_cast<const Row3*>(zero);
+    const uint8_t* mk = marks + first;
+    // GS_GATHER_ROWS rows in flight per trip (the loop is latency-bound: a splat touches ~7 tiles); the adds keep slot order
+#ifndef GS_GATHER_ROWS
+#define GS_GATHER_ROWS 4  // tuning hook (tools/build_variant.sh)
+#endif
+    constexpr int GR = GS_GATHER_ROWS;
+    auto add_rows = [&](const Row3 (&r)[3 * GR]) {   // adding the zeros of an absent row changes nothing: the sums start at +0 and never become -0
 #pragma unroll
-        for (int j = 0; j < 12; j++) r[j] = row[j];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < GR; j++) {
             sum[0] += r[3 * j].a; sum[1] += r[3 * j].b; sum[2] += r[3 * j].c;
             sum[3] += r[3 * j + 1].a; sum[4] += r[3 * j + 1].b; sum[5] += r[3 * j + 1].c;
             sum[6] += r[3 * j + 2].a; sum[7] += r[3 * j + 2].b; sum[8] += r[3 * j + 2].c;
         }
+    };
+    uint8_t m[GR], m_next[GR];
+    Row3 r[3 * GR];
+    // trip 0: marks, rows and the next trip's marks are all requested at once
+#pragma unroll
+    for (int j = 0; j < GR; j++) {
+        const bool in = (uint32_t)j < tiles;
+        m[j] = in ? mk[j] : (uint8_t)0;
+        const Row3* src = in ? row + 3 * j : zrow;
+        r[3 * j] = src[0]; r[3 * j + 1] = src[1]; r[3 * j + 2] = src[2];
+        m_next[j] = (uint32_t)(GR + j) < tiles ? mk[GR + j] : (uint8_t)0;
     }
-    for (; k < tiles; k++, row += 3) {
-        const Row3 r0 = row[0], r1 = row[1], r2 = row[2];
-        sum[0] += r0.a; sum[1] += r0.b; sum[2] += r0.c; sum[3] += r1.a; sum[4] += r1.b; sum[5] += r1.c;
-        sum[6] += r2.a; sum[7] += r2.b; sum[8] += r2.c;
+#pragma unroll
+    for (int j = 0; j < GR; j++) {
+        const bool have = (uint32_t)m[j] == epoch;   // (a slot behind the splat's last one reads as mark 0: never an epoch)
+#pragma unroll
+        for (int q = 0; q < 3; q++) { r[3 * j + q].a = have ? r[3 * j + q].a : 0.0f; r[3 * j + q].b = have ? r[3 * j + q].b : 0.0f; r[3 * j + q].c = have ? r[3 * j + q].c : 0.0f; }
+    }
+    add_rows(r);
+    row += 3 * GR;
+    for (uint32_t k = GR; k < tiles; k += GR, row += 3 * GR) {
+#pragma unroll
+        for (int j = 0; j < GR; j++) { m[j] = m_next[j]; m_next[j] = k + GR + j < tiles ? mk[k + GR + j] : (uint8_t)0; }
+        // from the second trip on the marks are known before the rows are asked for: an absent row is not requested at all (a
+        // dense scene — 84 % of the rows absent — is bound by the number of requests, which reading `zero` instead would keep)
+#pragma unroll
+        for (int j = 0; j < GR; j++) {
+            const Row3 z{ 0.0f, 0.0f, 0.0f };
+            r[3 * j] = z; r[3 * j + 1] = z; r[3 * j + 2] = z;
+            if ((uint32_t)m[j] == epoch) { r[3 * j] = row[3 * j]; r[3 * j + 1] = row[3 * j + 1]; r[3 * j + 2] = row[3 * j + 2]; }
+        }
+        add_rows(r);
     }
 }
 
@@ -350,7 +385,7 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __re
     for (int c = 0; c < 4; c++) q[c] = params[pl.rot(c) * st + i];
     const uint32_t first = s.point_offsets[(size_t)g * st + i] - tiles;
     float sum[9];
-    gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, first, tiles, sum);
+    gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, s.row_epoch + (size_t)v * d.Rcap, (uint32_t)d.epoch, s.zero_row, first, tiles, sum);
     SplatOut<D> o;
     float dRGB[3];
     // d colour / d direction was evaluated by the projection (same camera for every pass of the group): 9 floats
@@ -538,7 +573,7 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_seam(Dims d, const float* __re
     const uint32_t tiles = s.tiles_touched[i];
     const uint32_t first = s.point_offsets[i] - tiles;
     float sum[9];
-    gather_rows(s.G, first, tiles, sum);
+    gather_rows(s.G, s.row_epoch, (uint32_t)d.epoch, s.zero_row, first, tiles, sum);
     float dcolor[3];
     for (int c = 0; c < 3; c++) { dcolor[c] = g.dL_dcolor[3 * (size_t)i + c] + sum[c]; g.dL_dcolor[3 * (size_t)i + c] = dcolor[c]; }
     const float g2x = g.dL_dmean2D[3 * (size_t)i] + sum[3], g2y = g.dL_dmean2D[3 * (size_t)i + 1] + sum[4];
