@@ -14,4 +14,9 @@ python bench.py --config 5 --views 8 --steps 20 --warmup 3 --no-cpu-baseline > $
 python bench.py --config 5 --views 8 --steps 20 --warmup 3 --no-cpu-baseline --sh-fp16 > $out/diag_config5views8_shfp16.json 2>> $out/diag.err
 for v in 2 4 8; do python bench.py --views $v --steps $((600 / v)) --no-cpu-baseline > $out/diag_views$v.json 2>> $out/diag.err; done
 python bench.py --steps 30 --no-cpu-baseline --force-dist --collective torch-sharded --long-steps 0 > $out/diag_forcedist_torch_sharded.json 2>> $out/diag.err
+python bench.py --steps 30 --no-cpu-baseline --force-dist --collective torch-compact --long-steps 0 > $out/diag_forcedist_torch_compact.json 2>> $out/diag.err
+# roctx stage ranges (trainer option "roctx" via GS_ROCTX=1): marker + kernel trace of a short run, no counters in the same run
+( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && GS_ROCTX=1 rocprofv3 --marker-trace --kernel-trace --stats -d $out/roctx_raw -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --long-steps 0 --prewarm-seconds 0 > $out/roctx_bench.json 2> $out/roctx.err; f=$(find $out/roctx_raw -name "*marker*stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $out/roctx_marker_stats.csv; find $out/roctx_raw -name "*marker_api_trace.csv" | head -1 | xargs -r head -40 > $out/roctx_marker_trace_head.csv; rm -rf $out/roctx_raw )
+# useful-lane fraction of a hit (needs tools/_variants/lib_lanes.so: tools/build_variant.sh lanes k_render.hip -DGS_DIAG_COUNT_ACTIVE)
+if [ -f tools/_variants/lib_lanes.so ]; then for c in 2 3; do GSPLAT_MI355_LIB=$PWD/tools/_variants/lib_lanes.so python tools/diag_lanes.py --config $c > $out/lanes_config$c.json 2>> $out/diag.err; done; GSPLAT_MI355_LIB=$PWD/tools/_variants/lib_lanes.so python tools/diag_lanes.py --config 5 --views 8 --steps 2 > $out/lanes_config5views8.json 2>> $out/diag.err; fi
 ls -la $out
