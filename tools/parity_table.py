@@ -7,7 +7,7 @@ import re
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-lines = open(src, errors="replace").read().splitlines()
+lines = [l.lstrip(".") for l in open(src, errors="replace").read().splitlines()]   # pytest's progress dots share the line with the first print of a test
 groups = [
     ("Whole step against the oracle (tests/test_gpu_trainer.py::test_step_sgd_matches_oracle, tests/test_gpu_fullsize.py::test_cfg5_per_rank_load_with_fp16_sh): "
      "every averaged-gradient entry — unexplained = outside `1e-4 of sum|term| carried through the chain + decision-flip allowance`; "
