@@ -302,8 +302,14 @@ def main():
                 go_on = bool(flag[0])
             if not go_on:
                 break
+        # the pre-warm steps TRAINED the model (thousands of Adam steps: splats move and shrink, num_rendered drifts by several per
+        # cent): the timed region measures the metric's own workload, random-init splats, so the model is put back (same bits on
+        # every rank; this also resets the optimizer state) — the device stays warm across the few milliseconds this takes
+        tr.synchronize()
+        tr.model = gs.ModelSplatsDevice(host)
         prewarm = {"steps": n_p, "seconds": round(time.perf_counter() - t_p, 3),
-                   "note": "untimed steps of the same workload run before the W warm-up steps (--prewarm-seconds): the timed region then measures sustained clocks"}
+                   "note": "untimed steps of the same workload run before the W warm-up steps (--prewarm-seconds) to reach sustained clocks; the model is reset "
+                           "to the random-init splats afterwards, so the timed region runs the metric's own workload"}
     # ---- warm-up (untimed), then EXACTLY K timed steps ----
     st = None
     for _ in range(args.warmup):
@@ -355,7 +361,7 @@ def main():
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
             long_s = float(tl[0])
         long_run = {"value": n_long / long_s, "unit": "steps/s", "steps": n_long, "ms_per_step": long_s / n_long * 1e3,
-                    "note": "the same steps run after the timed region, no HIP events; not the metric"}
+                    "note": "the steps that follow the timed region, no HIP events; not the metric (the model trains on: over thousands of steps num_rendered drifts)"}
     # untimed: every stage, a few steps
     capi.check(L.gs_trainer_set_profiling(tr.handle, 1))
     for _ in range(min(args.steps, 10)):
