@@ -111,12 +111,12 @@ def main():
     ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (default: LOCAL_RANK); rehearsals on one GPU pass 0")
     ap.add_argument("--no-verify-exchange", action="store_true",
                     help="skip the check of the data-parallel step against an unsharded step on rank 0 before the warm-up (N > 1)")
-    ap.add_argument("--prewarm-seconds", type=float, default=3.0,
-                    help="untimed: run the same training steps for about this long BEFORE the W warm-up steps, so that the timed region measures the "
-                         "steady state a training run lives in (an MI355X that has been idle needs seconds of this bursty load — a 1.2 ms step of a dozen short "
-                         "kernels — to reach its sustained clocks: 734 steps/s in the first 50 steps after setup, 827 after 1.5 s, 870 after 3 s, 875-890 "
-                         "from 6 s on; a step of 7 ms, cfg5, shows no such ramp); 0 switches it off.  The cold window is measured first and reported "
-                         "beside it (`cold_start`, `prewarm` in the JSON line)")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.0,
+                    help="diagnostic: run the same training steps untimed for about this long before the W warm-up steps, then put the model back to the "
+                         "random-init splats and time the K steps (`cold_start` / `prewarm` in the JSON line hold the window before and the pre-warm).  "
+                         "Measured on the MI355X: clocks matter little (724 steps/s right after setup, 737 after 3 s of load).  What DOES make later steps "
+                         "faster is training itself — thousands of Adam steps shrink num_rendered by several per cent (`long_run`) — which is why a pre-warm "
+                         "without the reset would measure another workload (841-890 steps/s)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -350,10 +350,14 @@ def main():
         n_long = max(min(n_long, int(4.0 / max(elapsed / args.steps, 1e-6))), min(n_long, 50))
     long_run = None
     if n_long > 0:
+        # learning rates 0 for these steps: the same kernels and the same bytes (the update runs, the Adam moments move), but the model
+        # stays the metric's workload — with the real learning rates thousands of steps TRAIN it (num_rendered falls by several per cent
+        # and the steps get faster: 803 instead of 740 steps/s over 2000 steps), which is not what this figure is for
+        proj_still = gs.Project(updateRule=proj.updateRule, lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0)
         sync_all()
         t_l = time.perf_counter()
         for _ in range(n_long):
-            tr.train(proj, densify=False)
+            tr.train(proj_still, densify=False)
         sync_all()
         long_s = time.perf_counter() - t_l
         if use_dist:
@@ -361,7 +365,8 @@ def main():
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
             long_s = float(tl[0])
         long_run = {"value": n_long / long_s, "unit": "steps/s", "steps": n_long, "ms_per_step": long_s / n_long * 1e3,
-                    "note": "the steps that follow the timed region, no HIP events; not the metric (the model trains on: over thousands of steps num_rendered drifts)"}
+                    "note": "the same step run this many times after the timed region with all learning rates 0 (same kernels and bytes, the model stays "
+                            "the metric's workload), no HIP events; not the metric"}
     # untimed: every stage, a few steps
     capi.check(L.gs_trainer_set_profiling(tr.handle, 1))
     for _ in range(min(args.steps, 10)):
