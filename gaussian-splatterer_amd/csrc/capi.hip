@@ -34,6 +34,7 @@ struct Options {
     int long_sort = -1;  // k_tile_sort_long launch: -1 by the longest-list hint (default), 0 never (lists take the global-scratch path), 1 always
     int sort_grids = -1; // test hook: >= 0 replaces the device's hint for the sort grids: small_first | mid_grid << 16 (in tiles)
     int xchg_overlap = 1; // compact exchange: the all-reduce of the geometry planes runs on a second stream beside the all-gather (0: one after the other)
+    int row_marks = -1;   // gradient rows only for evaluated entries (row_epoch marks): -1 by the longest-list hint (on from 1024 entries), 0 never, 1 always
     int reuse_masks = 1;  // the backward reuses the forward's per-(tile sub-block, wave) block ballots; 0: it runs the block test itself (same bits)
     int roctx = 0;        // roctx range around every stage of a step (rocprofv3 --marker-trace names them); default from the environment: GS_ROCTX=1
 };
@@ -51,6 +52,7 @@ static bool set_option(Options& o, const char* name, int value) {
     if (strcmp(name, "exchange_overlap") == 0) { o.xchg_overlap = value != 0; return true; }
     if (strcmp(name, "roctx") == 0) { o.roctx = value != 0; return true; }
     if (strcmp(name, "reuse_hit_masks") == 0) { o.reuse_masks = value != 0; return true; }
+    if (strcmp(name, "row_marks") == 0) { o.row_marks = value < 0 ? -1 : (value != 0); return true; }
     return false;
 }
 
@@ -794,13 +796,25 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
             d.small_first = std::min(d.T, t->opt.sort_grids & 0xFFFF);
             d.mid_grid = std::max(1, std::min(d.T, t->opt.sort_grids >> 16));
         }
-        // the marks of this attempt's gradient rows: a fresh epoch; all marks are cleared when the epochs wrap or the buffer is new
-        if (t->row_epoch >= 255 || t->train.rowmark_cleared != t->train.rowmark.p) {
-            GS_HIP(hipMemsetAsync(t->train.rowmark.p, 0, t->train.rowmark.cap, t->stream));
-            t->train.rowmark_cleared = t->train.rowmark.p;
-            t->row_epoch = 0;
+        // Row marks: in a scene with long tile lists most entries lie behind their tile's last contributor and own an all-zero
+        // gradient row — with marks such rows are neither written nor read (cfg5: 84 % of them).  Where lists are short nearly
+        // every row exists and the marks only cost (cfg3: +20 us in k_splat_bwd_view), so the trainer decides by the longest
+        // list of two steps ago, like the sort launches above; either way the gradients are the same bits.
+        bool marks = t->opt.row_marks > 0;
+        if (t->opt.row_marks < 0 && t->steps_on_these_lists >= 2) {
+            uint32_t longest = 0;
+            for (int g = 0; g < t->VG; g++) longest = std::max(longest, t->h_flags[g * 4 + 1]);
+            marks = longest >= 1024u;
         }
-        d.epoch = ++t->row_epoch;
+        d.epoch = 0;
+        if (marks) {  // a fresh epoch per attempt; all marks are cleared when the epochs wrap or the buffer is new
+            if (t->row_epoch >= 255 || t->train.rowmark_cleared != t->train.rowmark.p) {
+                GS_HIP(hipMemsetAsync(t->train.rowmark.p, 0, t->train.rowmark.cap, t->stream));
+                t->train.rowmark_cleared = t->train.rowmark.p;
+                t->row_epoch = 0;
+            }
+            d.epoch = ++t->row_epoch;
+        }
         Scratch s = t->train.s;
         s.truth = t->truth.as<uint32_t>();
         if (!t->opt.reuse_masks) s.hit_masks = nullptr;  // the forward stores no ballots, the backward tests the blocks itself

@@ -453,10 +453,18 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
         s.loss[(size_t)vin[tid] * d.T + tile] = (sLoss[tid][0] + sLoss[tid][1]) + (sLoss[tid][2] + sLoss[tid][3]);
     if (n == 0) return;
     const int rounds = (max_last + ROUND - 1) / ROUND;
-    // Entries no pixel reaches have an all-zero gradient row.  Such rows are neither written here nor read by the per-splat
-    // kernel: a row exists iff its mark (row_epoch[slot]) equals this launch's epoch, and only the flush below sets marks.
-    // (Through round 3 every entry got its row: in a dense scene — 1100 entries per tile of which the pixels saturate after
-    // ~170 — 84 % of the rows were zeros, 2.2 GB written here and read again by k_splat_bwd_view.)
+    // Entries no pixel reaches have an all-zero gradient row.  With row marks (d.epoch != 0) such rows are neither written here
+    // nor read by the per-splat kernel: a row exists iff its mark (row_epoch[slot]) equals this launch's epoch, and only the
+    // flush below sets marks.  (Through round 3 every entry got its row: in a dense scene — 1100 entries per tile of which the
+    // pixels saturate after ~170 — 84 % of the rows were zeros, 2.2 GB written here and read again by k_splat_bwd_view.)
+    // Without marks (d.epoch == 0: scenes with short lists, where nearly every row exists and the marks would only cost) every
+    // entry owns a row, as before.
+    const bool marks = d.epoch != 0;
+    if (!marks)
+        for (int e = rounds * ROUND + tid; e < n; e += WG) {
+            Row3* row = reinterpret_cast<Row3*>(Gout + (size_t)slist[e] * G_STRIDE);
+            row[0] = Row3{ 0, 0, 0 }; row[1] = Row3{ 0, 0, 0 }; row[2] = Row3{ 0, 0, 0 };
+        }
 
 #ifdef GS_DIAG_COUNT_ACTIVE
     unsigned long long diag_hits = 0, diag_active = 0, diag_staged = 0, diag_pack2 = 0, diag_pack4 = 0;
@@ -591,7 +599,7 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
 #endif
         __syncthreads();
         // a slot no wave evaluated this round (no block of the tile can reach alpha >= 1/255 there) keeps its implicit zero row
-        const bool any_hit = (((sTouched[0] | sTouched[1]) | (sTouched[2] | sTouched[3])) >> lane) & 1ull;
+        const bool any_hit = !marks || ((((sTouched[0] | sTouched[1]) | (sTouched[2] | sTouched[3])) >> lane) & 1ull);
         if (wave < 3 && ROUND - 1 - lane < cnt && any_hit) {
             // moments -> the reference's nine sums (dx = mean2D.x - pixel.x as upstream):
             //   dL_dmean2D.x = -0.5 W op (conA * S[u dx] + conB * S[u dy]),  .y = -0.5 H op (conC * S[u dy] + conB * S[u dx])
@@ -625,7 +633,7 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
 #endif
 #ifndef GS_DIAG_NO_ROWS  // timing experiment: the kernel without its gradient-row stores
             row[wave] = out;
-            if (wave == 0) Gmark[sSlot[lane]] = (uint8_t)d.epoch;
+            if (wave == 0 && marks) Gmark[sSlot[lane]] = (uint8_t)d.epoch;
 #endif
         }
     }

@@ -192,7 +192,8 @@ __device__ inline void splat_backward_core(const gs_view& vp, int W, int H, cons
     }
 }
 
-// Sum the nine pixel-stage partials of splat i over its `tiles` slots, ascending slot order.  A slot holds a row only if its mark
+// Sum the nine pixel-stage partials of splat i over its `tiles` slots, ascending slot order.  With row marks (epoch != 0; the
+// trainer switches them on for scenes with long tile lists, the seam always) a slot holds a row only if its mark
 // equals the launch's epoch (k_render.hip: the backward writes and marks rows for evaluated entries only); the others are
 // implicit zero rows.  The marks are fetched one trip ahead of the rows they guard.  The first trip cannot know its marks
 // before it asks for its rows: it requests marks and rows together (slots behind the splat's last one are redirected to
@@ -218,8 +219,22 @@ __device__ inline void gather_rows(const float* __restrict__ Gv, const uint8_t* 
             sum[6] += r[3 * j + 2].a; sum[7] += r[3 * j + 2].b; sum[8] += r[3 * j + 2].c;
         }
     };
-    uint8_t m[GR], m_next[GR];
     Row3 r[3 * GR];
+    if (epoch == 0) {   // no marks this launch (short lists: nearly every row exists): every slot holds a row
+        uint32_t k = 0;
+        for (; k + GR <= tiles; k += GR, row += 3 * GR) {
+#pragma unroll
+            for (int j = 0; j < 3 * GR; j++) r[j] = row[j];
+            add_rows(r);
+        }
+        for (; k < tiles; k++, row += 3) {
+            const Row3 r0 = row[0], r1 = row[1], r2 = row[2];
+            sum[0] += r0.a; sum[1] += r0.b; sum[2] += r0.c; sum[3] += r1.a; sum[4] += r1.b; sum[5] += r1.c;
+            sum[6] += r2.a; sum[7] += r2.b; sum[8] += r2.c;
+        }
+        return;
+    }
+    uint8_t m[GR], m_next[GR];
     // trip 0: marks, rows and the next trip's marks are all requested at once
 #pragma unroll
     for (int j = 0; j < GR; j++) {

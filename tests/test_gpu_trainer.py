@@ -485,6 +485,46 @@ def test_backward_own_block_test_equals_the_reused_ballots(orc):
         assert np.abs(res[0][3]["loc"]).max() > 0
 
 
+def test_row_marks_switch_is_bit_identical(orc):
+    """Trainer option "row_marks": with marks the backward writes (and the per-splat kernel reads) a gradient row only for
+    entries some pixel block evaluated, all other rows are implicit zeros; without, every entry owns a row.  Same bits either
+    way — ordinary scene and long lists, fused-pair step and per-pass form — and the automatic choice (by the longest list of
+    two steps ago) changes nothing either."""
+    for P, spread in ((2500, 1.0), (3000, 0.05)):
+        W, H, M, n_cams = (128, 96, 4, 2) if spread == 1.0 else (32, 32, 1, 1)
+        res = []
+        for marks in (1, 0, -1):
+            s = gs.synth.random_splats(P, M, 778)
+            s["loc"] = (s["loc"] * spread).astype(np.float32)
+            if spread != 1.0:
+                s["opac"] = (s["opac"] * 0.4).astype(np.float32)     # opaque enough that the pixels saturate well inside the lists
+            cams = gs.camera.get_cameras(n_cams, 10.0, 20.0 if spread != 1.0 else 60.0)
+            rng = np.random.default_rng(13)
+            fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+            fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+            host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+            host.shDegree = s["D"]
+            tr = gs.Trainer(W, H)
+            tr.set_option("row_marks", marks)
+            tr.model = gs.ModelSplatsDevice(host)
+            tr.captureTruths(cams, fw, fb)
+            still = gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0)
+            out = []
+            for k in range(4):          # the automatic choice looks two steps back: steps 0-1 run without marks, 2-3 by the hint
+                st = tr.train(still, stats=True)
+                out.append(_read_grads(tr, P, M))
+            tr.accumulate()
+            out.append(_read_grads(tr, P, M))
+            res.append((st.num_rendered, st.max_tile_list, out))
+            tr.close()
+        assert res[0][:2] == res[1][:2] == res[2][:2] and (spread == 1.0 or res[0][1] > 1024)
+        for other in (res[1], res[2]):
+            for a, b in zip(res[0][2], other[2]):
+                for k in a:
+                    assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (P, k)
+        assert np.abs(res[0][2][0]["loc"]).max() > 0 and res[0][2][4]["var"].any()
+
+
 def test_arena_overflow_grows_and_replays(orc):
     """A binning arena that is too small is detected on the device, grown on the host and the step replayed before
     the update is applied: results equal the run with an ample arena, and the statistics report the regrow."""
