@@ -363,8 +363,16 @@ __device__ inline float* exchange_rgb(const Exchange& x, int rank, int slot, siz
 
 // SINGLE + x.geo != null (compact exchange): the geometry sums go to the exchange's twelve planes and the record's dL_dRGB to
 // its slot 0 of this rank's chunk of the gather buffer; no SH plane is touched (k_sh_rebuild writes them after the exchange).
+#ifndef GS_SBV_WAVES
+#define GS_SBV_WAVES 0  // occupancy target of k_splat_bwd_view, waves per SIMD (tuning hook, tools/build_variant.sh; 0: the compiler's choice)
+#endif
+#if GS_SBV_WAVES > 0
+#define GS_SBV_ATTR __attribute__((amdgpu_waves_per_eu(GS_SBV_WAVES, GS_SBV_WAVES)))
+#else
+#define GS_SBV_ATTR
+#endif
 template <int D, bool SINGLE>
-__global__ __launch_bounds__(WG) void k_splat_bwd_view(Dims d, const float* __restrict__ params, Scratch s, float4* __restrict__ rec_out,
+__global__ __launch_bounds__(WG) GS_SBV_ATTR void k_splat_bwd_view(Dims d, const float* __restrict__ params, Scratch s, float4* __restrict__ rec_out,
                                                        const int* __restrict__ items, int n_pairs, int fused, float samples,
                                                        float* __restrict__ grad, Exchange x) {
     const int i = blockIdx.x * WG + threadIdx.x;
