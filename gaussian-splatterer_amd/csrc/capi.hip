@@ -1029,8 +1029,8 @@ static int shard_call(gs_trainer* t, gs_collective_fn fn, float* buf, size_t n, 
 // gradient of a splat is rank one (basis(view direction)[M] x dL_dRGB[3], src/Trainer.cu:51-76 as k_splat_bwd_reduce rebuilds
 // it): instead of all-reducing (12 + 3M) P floats the ranks all-gather their records' dL_dRGB (3 floats per record and splat)
 // and all-reduce the twelve other planes; every rank then rebuilds the SH planes from ALL records in the single-GPU order.
-//   main stream:    ... per-splat backward + pack -> [all-gather dL_dRGB] ---------------> wait -> k_sh_rebuild -> update
-//   second stream:                     wait(packed) -> [all-reduce geometry planes] -> (reduced)
+//   main stream:    ... per-splat backward + pack -> [all-gather dL_dRGB] -> k_sh_rebuild (SH planes) -> wait -> (other planes) -> update
+//   second stream:                     wait(packed) -> [all-reduce of the twelve other planes] ---------> (reduced)
 // cfg3 on 8 ranks: 8.4 + 8.4 MB received per rank instead of the 42 MB a ring all-reduce of 24 MB moves; the SH gradients
 // are the single-GPU step's bit for bit (the collective sums only the geometry planes).
 static int step_compact_exchange(gs_trainer* t, const gs_hyper* h, int densify, gs_step_stats* stats) {
@@ -1068,8 +1068,7 @@ static int step_compact_exchange(gs_trainer* t, const gs_hyper* h, int densify, 
         if (rc != 0) { set_error("all-reduce (geometry planes) hook failed with %d", rc); return GS_ERR_COLLECTIVE; }
         rc = t->xchg_gather(x.rgb, (size_t)G * x.slots * 3 * Pa, (void*)t->stream, t->xchg_user);
         if (rc != 0) { set_error("all-gather (dL_dRGB records) hook failed with %d", rc); return GS_ERR_COLLECTIVE; }
-        if (overlap) GS_HIP(hipStreamWaitEvent(t->stream, t->ev_reduced, 0));
-        else {
+        if (!overlap) {
             rc = t->xchg_reduce(x.geo, 12 * Pa, (void*)t->stream, t->xchg_user);
             if (rc != 0) { set_error("all-reduce (geometry planes) hook failed with %d", rc); return GS_ERR_COLLECTIVE; }
         }
@@ -1078,7 +1077,15 @@ static int step_compact_exchange(gs_trainer* t, const gs_hyper* h, int densify, 
         Dims d;
         GS_TRY(trainer_dims(t, &d));
         prof_stage_begin(t, 6, 8);
-        GS_TRY(launch_sh_rebuild(d, m->planes, x, t->xcampos.as<float>(), C_, per_pass, (float)t->total_samples, t->grad.as<float>(), t->stream));
+        if (overlap) {
+            // the SH planes need the gathered records only: they are rebuilt while the all-reduce is still under way on the second
+            // stream; the twelve other planes follow behind its event
+            GS_TRY(launch_sh_rebuild(d, m->planes, x, t->xcampos.as<float>(), C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 1, t->stream));
+            GS_HIP(hipStreamWaitEvent(t->stream, t->ev_reduced, 0));
+            GS_TRY(launch_sh_rebuild(d, m->planes, x, t->xcampos.as<float>(), C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 2, t->stream));
+        } else {
+            GS_TRY(launch_sh_rebuild(d, m->planes, x, t->xcampos.as<float>(), C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 3, t->stream));
+        }
         prof_stage_end(t, 6);
         GS_TRY(debug_check(t, 6));
     }

@@ -181,8 +181,9 @@ struct Exchange {
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad_planes, const int* items,
                               int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st, const Exchange* x = nullptr);
 // after the exchange: every averaged-gradient plane from the reduced geometry planes and the gathered dL_dRGB (campos: [n_cameras][3], device)
+// parts: 1 = the SH planes (from the gathered records), 2 = the twelve other planes (from the reduced sums), 3 = both
 int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, const float* campos, int n_cameras, bool per_pass, float samples,
-                      float* grad_planes, hipStream_t st);
+                      float* grad_planes, int parts, hipStream_t st);
 // Seam form: one view, reference-shaped AoS outputs with the reference's += / = discipline.
 struct SeamGrads { float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot; };
 int launch_splat_backward_seam(const Dims& d, const float* params, const Scratch& s, const SeamGrads& g, hipStream_t st);

@@ -500,30 +500,42 @@ __global__ __launch_bounds__(WG) void k_exchange_pack(Dims d, Scratch s, float s
 // src/Trainer.cu:311-314), each with its own camera's view direction: avg_sh += (basis x dL_dRGB) / S, the very operations of
 // GradAcc::add — the SH gradients are the single-GPU step's bit for bit, whatever order the collective summed in.
 // Camera c of the iteration lives on rank c % world as that rank's local camera c / world.
+// parts: bit 0 = the SH planes (needs the gathered records only), bit 1 = the twelve other planes (needs the all-reduce only):
+// with the two collectives side by side the SH planes are rebuilt while the all-reduce is still under way.
 template <int D>
 __global__ __launch_bounds__(WG) void k_sh_rebuild(Dims d, const float* __restrict__ params, Exchange x, const float* __restrict__ campos,
-                                                   int n_cameras, int per_pass, float samples, float* __restrict__ grad) {
+                                                   int n_cameras, int per_pass, float samples, float* __restrict__ grad, int parts) {
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
-    const float mx = params[pl.loc(0) * st + i], my = params[pl.loc(1) * st + i], mz = params[pl.loc(2) * st + i];
-    GradAcc<D> acc;
-    const int n_rec = per_pass ? 2 * n_cameras : n_cameras;
-    for (int k = 0; k < n_rec; k++) {
-        const int c = k < n_cameras ? k : k - n_cameras;
-        const int slot = (k < n_cameras ? 0 : x.slots / 2) + c / x.world;
-        const float* rgb = exchange_rgb(x, c % x.world, slot, st);
-        const float dRGB[3] = { rgb[i], rgb[st + i], rgb[2 * st + i] };
-        acc.add_sh(dRGB, samples, mx, my, mz, campos + 3 * c);
+    if (parts & 1) {
+        const float mx = params[pl.loc(0) * st + i], my = params[pl.loc(1) * st + i], mz = params[pl.loc(2) * st + i];
+        GradAcc<D> acc;
+        const int n_rec = per_pass ? 2 * n_cameras : n_cameras;
+        for (int k = 0; k < n_rec; k++) {
+            const int c = k < n_cameras ? k : k - n_cameras;
+            const int slot = (k < n_cameras ? 0 : x.slots / 2) + c / x.world;
+            const float* rgb = exchange_rgb(x, c % x.world, slot, st);
+            const float dRGB[3] = { rgb[i], rgb[st + i], rgb[2 * st + i] };
+            acc.add_sh(dRGB, samples, mx, my, mz, campos + 3 * c);
+        }
+        constexpr int NC = GradAcc<D>::NC;
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = acc.aSh[k][c];
+        for (int k = NC; k < d.M; k++)
+            for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = 0.0f;
     }
+    if (parts & 2) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) { acc.aLoc[c] = x.geo[c * st + i]; acc.aScale[c] = x.geo[(3 + c) * st + i]; }
-    acc.aOpac = x.geo[6 * st + i];
+        for (int c = 0; c < 3; c++) { grad[pl.loc(c) * st + i] = x.geo[c * st + i]; grad[pl.scale(c) * st + i] = x.geo[(3 + c) * st + i]; }
+        grad[pl.opac() * st + i] = x.geo[6 * st + i];
 #pragma unroll
-    for (int c = 0; c < 4; c++) acc.aRot[c] = x.geo[(7 + c) * st + i];
-    acc.var = x.geo[11 * st + i];
-    acc.store(grad, pl, st, i, d.M, false);
+        for (int c = 0; c < 4; c++) grad[pl.rot(c) * st + i] = x.geo[(7 + c) * st + i];
+        grad[pl.var() * st + i] = x.geo[11 * st + i];
+    }
 }
 
 // x != null: the compact exchange's rank side (the rank holds whole cameras: n1 == 0); grad is not written
@@ -559,15 +571,15 @@ int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch&
 }
 
 int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, const float* campos, int n_cameras, bool per_pass, float samples,
-                      float* grad, hipStream_t stream) {
+                      float* grad, int parts, hipStream_t stream) {
     if (d.P == 0) return GS_OK;
     const dim3 grid((d.P + WG - 1) / WG);
     const int pp = per_pass ? 1 : 0;
     switch (d.D) {
-        case 0: hipLaunchKernelGGL(k_sh_rebuild<0>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad); break;
-        case 1: hipLaunchKernelGGL(k_sh_rebuild<1>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad); break;
-        case 2: hipLaunchKernelGGL(k_sh_rebuild<2>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad); break;
-        default: hipLaunchKernelGGL(k_sh_rebuild<3>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad); break;
+        case 0: hipLaunchKernelGGL(k_sh_rebuild<0>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad, parts); break;
+        case 1: hipLaunchKernelGGL(k_sh_rebuild<1>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad, parts); break;
+        case 2: hipLaunchKernelGGL(k_sh_rebuild<2>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad, parts); break;
+        default: hipLaunchKernelGGL(k_sh_rebuild<3>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad, parts); break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

@@ -4,6 +4,7 @@
 // go to another one, which the test compares bit-for-bit with the Python mirror's run.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "gsplat_shim.hpp"
@@ -57,6 +58,43 @@ int main(int argc, char** argv) {
         fwrite(back.opacities, 4, (size_t)back.count, o);
         fwrite(frame.data(), 4, frame.size(), o);
         fclose(o);
+        // Checkpoint / resume of an Adam run through the shim (gs_trainer_adam_state / gs_trainer_set_adam_state), and the camera
+        // every render caller of the reference builds (Camera::getPreviewCamera(*project), src/ui/UiPanelViewOutput.cpp:52-60)
+        {
+            Trainer a(W, H);
+            a.updateRule = GS_UPDATE_ADAM;
+            delete a.model;
+            a.model = new ModelSplatsDevice(host);
+            a.captureTruths(cameras, fw, fb);
+            Project pa;
+            pa.lrLocation = 1e-3f; pa.lrSh = 2e-3f;
+            std::vector<float> m1, m2;
+            if (a.adamState(m1, m2) != 0 || !m1.empty()) return 7;      // no Adam step yet
+            for (int s = 0; s < 2; s++) a.train(pa, false);
+            ModelSplatsHost saved(*a.model);
+            const int taken = a.adamState(m1, m2);
+            if (taken != 2 || m1.size() != m2.size() || m1.empty()) return 7;
+            for (int s = 0; s < 2; s++) a.train(pa, false);
+            ModelSplatsHost straight(*a.model);
+            Trainer b(W, H);
+            b.updateRule = GS_UPDATE_ADAM;
+            delete b.model;
+            b.model = new ModelSplatsDevice(saved);
+            b.captureTruths(cameras, fw, fb);
+            b.setAdamState(m1, m2, taken);
+            Project pb = pa;
+            for (int s = 0; s < 2; s++) b.train(pb, false);
+            ModelSplatsHost resumed(*b.model);
+            if (resumed.count != straight.count || memcmp(resumed.locations, straight.locations, 12 * (size_t)straight.count) != 0 ||
+                memcmp(resumed.shs, straight.shs, 12 * (size_t)M * straight.count) != 0) return 8;    // bit for bit
+            Project pv;
+            pv.previewTimer = 1.0f;
+            std::vector<uint32_t> pf((size_t)W * H);
+            b.render(pf.data(), W, H, pv.previewSplatScale, Camera::getPreviewCamera(pv));
+            size_t lit = 0;
+            for (uint32_t px : pf) lit += (px & 0xFFFFFFu) != 0;
+            if (lit == 0) return 9;                                      // the free camera at distance 10 sees the scene
+        }
     } catch (const std::exception& e) {
         fprintf(stderr, "shim_step: %s\n", e.what());
         return 1;
