@@ -116,3 +116,55 @@ def loadSettings(path, project=None):
         else:
             setattr(project, k, j[k])
     return project
+
+
+def saveCheckpoint(path, model, moment1=None, moment2=None, adam_steps=0, project=None):
+    """A lossless checkpoint of a run — what the reference's two files cannot hold: `.gobj` rounds every float to 6 significant
+    digits (src/ui/UiFrame.cpp:333-358) and knows no optimizer state (its update rule has none).  One `.npz`:
+    the five fp32 arrays of `model` (a ModelSplatsHost) bit for bit with its capacity / SH fields, the two Adam moments and the
+    step counter as Trainer.adam_state() returns them (optional), and the Project as its settings.json text (optional).
+    numpy's own loader reads it back without executing anything (allow_pickle stays False)."""
+    M, n = model.shCoeffs, model.count
+    arrays = dict(locations=np.asarray(model.locations[:3 * n], np.float32), shs=np.asarray(model.shs[:3 * M * n], np.float32),
+                  scales=np.asarray(model.scales[:3 * n], np.float32), opacities=np.asarray(model.opacities[:n], np.float32),
+                  rotations=np.asarray(model.rotations[:4 * n], np.float32),
+                  meta=np.array([model.capacity, model.shDegree, M, n, int(adam_steps)], np.int64))
+    if moment1 is not None:
+        arrays["adam_moment1"] = np.asarray(moment1, np.float32)
+        arrays["adam_moment2"] = np.asarray(moment2, np.float32)
+    if project is not None:
+        d = dataclasses.asdict(project)
+        for k in ("updateRule", "adamBeta1", "adamBeta2", "adamEps", "quatLayout"):   # build-side fields travel too, under their own key
+            arrays.setdefault("extras_" + k, np.array([d.pop(k)], np.float64))
+        arrays["settings_json"] = np.frombuffer(json.dumps(d).encode(), np.uint8)
+    np.savez(path, **arrays)
+
+
+def loadCheckpoint(path, project=None):
+    """-> (ModelSplatsHost, moment1 | None, moment2 | None, adam_steps, Project | None); the counterpart of saveCheckpoint.
+    Resume: `trainer.model = ModelSplatsDevice(host); trainer.set_adam_state(m1, m2, steps)` continues the run bit for bit
+    (tests/test_gpu_trainer.py::test_adam_state_restore_resumes_bit_exact)."""
+    z = np.load(path, allow_pickle=False)
+    cap, deg, M, n, steps = (int(x) for x in z["meta"])
+    host = ModelSplatsHost(cap, deg, M)
+    host.locations[:3 * n] = z["locations"]; host.shs[:3 * M * n] = z["shs"]; host.scales[:3 * n] = z["scales"]
+    host.opacities[:n] = z["opacities"]; host.rotations[:4 * n] = z["rotations"]
+    host.count = n
+    m1 = z["adam_moment1"] if "adam_moment1" in z.files else None
+    m2 = z["adam_moment2"] if "adam_moment2" in z.files else None
+    proj = None
+    if "settings_json" in z.files:
+        d = json.loads(bytes(z["settings_json"]).decode())
+        proj = project or Project()
+        for k, v in d.items():
+            if k in ("sphere1", "sphere2"):
+                setattr(proj, k, CameraSphere(**v))
+            elif hasattr(proj, k):
+                setattr(proj, k, v)
+        for k in ("updateRule", "quatLayout"):
+            if "extras_" + k in z.files:
+                setattr(proj, k, int(z["extras_" + k][0]))
+        for k in ("adamBeta1", "adamBeta2", "adamEps"):
+            if "extras_" + k in z.files:
+                setattr(proj, k, float(z["extras_" + k][0]))
+    return host, m1, m2, steps, proj

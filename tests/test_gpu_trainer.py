@@ -330,7 +330,7 @@ def test_adam_state_survives_densify(orc, quat):
     assert all(a != b for a, b in counts)
 
 
-def test_adam_state_restore_resumes_bit_exact(orc):
+def test_adam_state_restore_resumes_bit_exact(orc, tmp_path):
     """Checkpoint / resume of an Adam run (gs_trainer_set_adam_state; SURVEY section 5: "Adam m,v would need to be added to any
     checkpoint"): three steps -> model + moments + step counter saved -> a NEW trainer restored from them -> three more steps
     equal six uninterrupted steps bit for bit (parameters and both moments).  Without the restore the resumed run differs."""
@@ -343,6 +343,9 @@ def test_adam_state_restore_resumes_bit_exact(orc):
     saved_model = gs.ModelSplatsHost.fromDevice(tr.model)
     m1, m2, steps = tr.adam_state()
     assert steps == 3 and m1.size == m2.size == (11 + 3 * M) * ((P + 63) // 64 * 64) and np.abs(m1).max() > 0
+    # through a file: the lossless checkpoint of io.py (the reference's .gobj keeps 6 significant digits and no optimizer state)
+    gs.io.saveCheckpoint(tmp_path / "run.npz", saved_model, m1, m2, steps, proj)
+    saved_model, m1, m2, steps, _ = gs.io.loadCheckpoint(tmp_path / "run.npz")
     for _ in range(3):
         tr.train(proj)
     straight, (sm1, sm2, ssteps) = _download(tr), tr.adam_state()

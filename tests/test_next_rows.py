@@ -206,3 +206,26 @@ def test_cpp_extras_header_and_gobj_interop(tmp_path):
     assert h.count == r.count == 4
     for name, w in (("locations", 3), ("scales", 3), ("opacities", 1), ("rotations", 4)):
         assert np.allclose(getattr(h, name)[:w * 4], getattr(r, name)[:w * 4], rtol=2e-5, atol=2e-6), name
+
+
+def test_lossless_checkpoint_round_trip(tmp_path):
+    """io.saveCheckpoint / loadCheckpoint: model bit for bit (the .gobj text format keeps 6 significant digits), the Adam moments
+    and step counter, the Project incl. the build-side update-rule fields; loaded with allow_pickle=False."""
+    P, M = 70, 4
+    s = gs.synth.random_splats(P, M, 19)
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    rng = np.random.default_rng(2)
+    m1 = rng.standard_normal((11 + 3 * M) * 128).astype(np.float32)
+    m2 = np.abs(rng.standard_normal((11 + 3 * M) * 128)).astype(np.float32)
+    p = gs.Project.initProject()
+    p.lrSh, p.iterations, p.sphere1.rotX, p.updateRule, p.adamEps = 0.25, 1234, 77.0, 1, 1e-12
+    gs.io.saveCheckpoint(tmp_path / "run.npz", host, m1, m2, 1234, p)
+    back, b1, b2, steps, q = gs.io.loadCheckpoint(tmp_path / "run.npz")
+    assert (back.count, back.capacity, back.shCoeffs, back.shDegree, steps) == (P, host.capacity, M, host.shDegree, 1234)
+    for name, w in (("locations", 3), ("shs", 3 * M), ("scales", 3), ("opacities", 1), ("rotations", 4)):
+        assert np.array_equal(np.asarray(getattr(back, name)[:w * P]).view(np.uint32), np.asarray(getattr(host, name)[:w * P]).view(np.uint32)), name
+    assert np.array_equal(b1.view(np.uint32), m1.view(np.uint32)) and np.array_equal(b2.view(np.uint32), m2.view(np.uint32))
+    assert (q.lrSh, q.iterations, q.sphere1.rotX, q.sphere2.count, q.updateRule, q.adamEps) == (0.25, 1234, 77.0, 0, 1, 1e-12)
+    gs.io.saveCheckpoint(tmp_path / "bare.npz", host)          # no optimizer state, no project
+    back2, n1, n2, steps2, q2 = gs.io.loadCheckpoint(tmp_path / "bare.npz")
+    assert n1 is None and n2 is None and steps2 == 0 and q2 is None and back2.count == P
