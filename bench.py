@@ -111,12 +111,13 @@ def main():
     ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (default: LOCAL_RANK); rehearsals on one GPU pass 0")
     ap.add_argument("--no-verify-exchange", action="store_true",
                     help="skip the check of the data-parallel step against an unsharded step on rank 0 before the warm-up (N > 1)")
-    ap.add_argument("--prewarm-seconds", type=float, default=0.0,
-                    help="diagnostic: run the same training steps untimed for about this long before the W warm-up steps, then put the model back to the "
-                         "random-init splats and time the K steps (`cold_start` / `prewarm` in the JSON line hold the window before and the pre-warm).  "
-                         "Measured on the MI355X: clocks matter little (724 steps/s right after setup, 737 after 3 s of load).  What DOES make later steps "
-                         "faster is training itself — thousands of Adam steps shrink num_rendered by several per cent (`long_run`) — which is why a pre-warm "
-                         "without the reset would measure another workload (841-890 steps/s)")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.0,
+                    help="run the same training steps untimed for about this long before the W warm-up steps, then put the model back to the random-init "
+                         "splats (the pre-warm steps train it) and time the K steps: the timed region then sees the clocks a training run lives at.  An "
+                         "MI355X that sat idle through the Python setup runs its first tens of steps 2-7 %% slower (box to box: 692 against 739 steps/s "
+                         "for 20 against 2000 steps).  The window WITHOUT the pre-warm is measured first and reported beside it (`cold_start`, `prewarm` in the "
+                         "JSON line); 0 switches the pre-warm off.  NOT a workload change: without the reset a pre-warm would measure a model that has "
+                         "trained (num_rendered falls by several per cent over thousands of steps: 841-890 steps/s) — that mistake is on record in DESIGN.md 6")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
