@@ -528,6 +528,38 @@ def test_row_marks_switch_is_bit_identical(orc):
         assert np.abs(res[0][2][0]["loc"]).max() > 0 and res[0][2][4]["var"].any()
 
 
+def test_row_mark_epochs_wrap_without_a_trace():
+    """The row marks are one byte per slot holding the epoch (1 .. 255) of the launch that wrote the row; after 255 accumulate
+    attempts the epochs start over and every mark is cleared first, or a mark left by the launch of 255 attempts ago would pass for
+    a row of this one.  600 training steps with marks (two wraps; densify steps in between re-index the model and regrow
+    nothing here) must leave the very model the mark-free run leaves."""
+    P, M, W, H = 600, 1, 48, 48
+    res = []
+    for marks in (1, 0):
+        s = gs.synth.random_splats(P, M, 4321)
+        s["loc"] = (s["loc"] * 0.3).astype(np.float32)
+        cams = gs.camera.get_cameras(2, 10.0, 30.0)
+        rng = np.random.default_rng(7)
+        fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+        fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in cams]
+        host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+        host.shDegree = s["D"]
+        host.capacity = 2 * P
+        tr = gs.Trainer(W, H)
+        tr.set_option("row_marks", marks)
+        tr.model = gs.ModelSplatsDevice(host)
+        tr.captureTruths(cams, fw, fb)
+        proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=2e-4, lrSh=1e-3, lrScale=1e-4, lrOpacity=1e-3, lrRotation=1e-4,
+                          paramDensifyVariance=0.2, paramCullOpacity=0.05)
+        for k in range(600):
+            tr.train(proj, densify=(k % 250 == 249))
+        res.append(_download(tr))
+        tr.close()
+    assert res[0]["count"] == res[1]["count"]
+    for k in ("loc", "sh", "scale", "opac", "rot"):
+        assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
+
+
 def test_arena_overflow_grows_and_replays(orc):
     """A binning arena that is too small is detected on the device, grown on the host and the step replayed before
     the update is applied: results equal the run with an ample arena, and the statistics report the regrow."""
