@@ -222,9 +222,7 @@ def main():
         hm = gs.ModelSplatsHost.fromDevice(tr.model)
         digest = hashlib.sha256(b"".join(np.ascontiguousarray(a[:k * hm.count]).tobytes() for a, k in
                                          ((hm.locations, 3), (hm.shs, 3 * hm.shCoeffs), (hm.scales, 3), (hm.opacities, 1), (hm.rotations, 4)))).hexdigest()
-        digests = [None] * world
-        dist.all_gather_object(digests, digest)
-        return digests
+        return gsdist.all_gather_bytes(digest.encode(), 64)   # CPU tensors: gloo under the mixed backend
 
     # ---- N > 1: the data-parallel step checked on THIS hardware against an unsharded step, before anything is timed ----
     # One gradients-only step (learning rates 0) through the installed exchange; rank 0 runs the same iteration unsharded on a second
@@ -258,9 +256,7 @@ def main():
                 sh_same = bool(np.array_equal(g_dp[3:3 + 3 * M].view(np.uint32), g_ref[3:3 + 3 * M].view(np.uint32)))
                 res = {"max_plane_deviation": dev, "sh_planes_bit_identical_to_unsharded_step": sh_same,
                        "ok": bool(dev <= 2e-5 and np.isfinite(g_dp).all() and np.abs(g_ref).max() > 0)}
-            box = [res]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
+            return json.loads(gsdist.broadcast_bytes(json.dumps(res).encode() if rank == 0 else b"", src=0).decode())
         exchange_check = dict(check_once(), collective=collective)
         if not exchange_check["ok"] and collective != "torch":
             collective_note = f"{collective} failed the check against the unsharded step ({exchange_check}): fell back to the torch all-reduce"

@@ -39,6 +39,34 @@ def allreduce_sum_numpy(arr):
     return arr
 
 
+def broadcast_bytes(data, src=0, max_len=1 << 16):
+    """`data` (bytes on `src`, ignored elsewhere) to every rank, as a fixed-size CPU tensor: with a "cpu:gloo,cuda:nccl" group a CPU
+    tensor travels over gloo, whatever device the object collectives would have picked."""
+    import torch
+    import torch.distributed as dist
+    buf = torch.zeros(max_len + 8, dtype=torch.uint8)
+    if dist.get_rank() == src:
+        raw = bytes(data)
+        if len(raw) > max_len:
+            raise ValueError(f"broadcast_bytes: {len(raw)} bytes exceed {max_len}")
+        buf[:8] = torch.frombuffer(bytearray(len(raw).to_bytes(8, "little")), dtype=torch.uint8)
+        buf[8:8 + len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    dist.broadcast(buf, src=src)
+    n = int.from_bytes(bytes(buf[:8].tolist()), "little")
+    return bytes(buf[8:8 + n].tolist())
+
+
+def all_gather_bytes(data, width=64):
+    """One fixed-width byte string per rank (e.g. a digest), gathered over CPU tensors."""
+    import torch
+    import torch.distributed as dist
+    raw = bytes(data)[:width].ljust(width, b"\0")
+    mine = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    out = [torch.zeros(width, dtype=torch.uint8) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [bytes(t.tolist()) for t in out]
+
+
 class _DevPtr:
     """Minimal __cuda_array_interface__ carrier so torch can alias a raw device pointer (no copy)."""
 
@@ -259,9 +287,8 @@ class NativeRcclComm:
         if rank == 0:
             capi.check(L.gs_comm_unique_id(ident))
         if world > 1:
-            box = [bytes(ident.raw) if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            C.memmove(ident, box[0], capi.GS_COMM_ID_BYTES)
+            got = broadcast_bytes(bytes(ident.raw) if rank == 0 else b"", src=0, max_len=capi.GS_COMM_ID_BYTES)
+            C.memmove(ident, got, capi.GS_COMM_ID_BYTES)
         handle = C.c_void_p()
         capi.check(L.gs_comm_create(ident, rank, world, C.byref(handle)))
         return handle
