@@ -240,7 +240,18 @@ def main():
 
         def check_once():
             still = gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0)
-            tr.train(still, densify=False)
+            # a collective that REFUSES its arguments does so on every rank alike (the hook reports it, the step returns
+            # GS_ERR_COLLECTIVE): that is a verdict like any other, the ranks agree on it and move on to the fall-back
+            failed = None
+            try:
+                tr.train(still, densify=False)
+                tr.synchronize()
+            except capi.GsError as e:
+                failed = str(e)
+            flags = torch.tensor([0 if failed is None else 1], dtype=torch.int32)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            if int(flags[0]):
+                return {"ok": False, "step_failed_on_some_rank": failed or "on another rank"}
             res = None
             if rank == 0:
                 ref = gs.Trainer(W, H)
