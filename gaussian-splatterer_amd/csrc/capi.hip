@@ -1065,14 +1065,17 @@ static int step_compact_exchange(gs_trainer* t, const gs_hyper* h, int densify, 
             rc = t->xchg_reduce(x.geo, 12 * Pa, (void*)t->stream2, t->xchg_user);
             if (rc == 0) GS_HIP(hipEventRecord(t->ev_reduced, t->stream2));
         }
-        if (rc != 0) { set_error("all-reduce (geometry planes) hook failed with %d", rc); return GS_ERR_COLLECTIVE; }
-        rc = t->xchg_gather(x.rgb, (size_t)G * x.slots * 3 * Pa, (void*)t->stream, t->xchg_user);
-        if (rc != 0) { set_error("all-gather (dL_dRGB records) hook failed with %d", rc); return GS_ERR_COLLECTIVE; }
-        if (!overlap) {
+        const char* failed = rc != 0 ? "all-reduce (geometry planes)" : nullptr;
+        if (!failed) {
+            rc = t->xchg_gather(x.rgb, (size_t)G * x.slots * 3 * Pa, (void*)t->stream, t->xchg_user);
+            if (rc != 0) failed = "all-gather (dL_dRGB records)";
+        }
+        if (!failed && !overlap) {
             rc = t->xchg_reduce(x.geo, 12 * Pa, (void*)t->stream, t->xchg_user);
-            if (rc != 0) { set_error("all-reduce (geometry planes) hook failed with %d", rc); return GS_ERR_COLLECTIVE; }
+            if (rc != 0) failed = "all-reduce (geometry planes)";
         }
         prof_stage_end(t, 8);
+        if (failed) { set_error("%s hook failed with %d", failed, rc); return GS_ERR_COLLECTIVE; }
         GS_TRY(debug_check(t, 8));
         Dims d;
         GS_TRY(trainer_dims(t, &d));
