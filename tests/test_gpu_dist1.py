@@ -80,6 +80,25 @@ def test_failing_collective_hooks_end_the_step_cleanly():
         assert e.value.status == capi.GS_ERR_COLLECTIVE and what in str(e.value), str(e.value)
     capi.check(L.gs_trainer_set_sharded_update(tr.handle, None, None, None, 0, 1))
     tr.train(proj)
+    # the compact exchange: whichever of its two collectives fails is named; with the overlap the all-reduce is issued first
+    campos = np.ascontiguousarray([c.location for c in cams], np.float32)
+    for overlap in (1, 0):
+        tr.set_option("exchange_overlap", overlap)
+        for ag, ar, what in ((cb, ok, "all-gather (dL_dRGB records) hook failed"), (ok, cb, "all-reduce (geometry planes) hook failed")):
+            capi.check(L.gs_trainer_set_compact_exchange(tr.handle, C.cast(ag, C.c_void_p), C.cast(ar, C.c_void_p), None, 0, 1, 1,
+                                                         campos.ctypes.data_as(C.c_void_p)))
+            with pytest.raises(capi.GsError) as e:
+                tr.train(proj)
+            assert e.value.status == capi.GS_ERR_COLLECTIVE and what in str(e.value), str(e.value)
+    capi.check(L.gs_trainer_set_compact_exchange(tr.handle, C.cast(ok, C.c_void_p), C.cast(ok, C.c_void_p), None, 0, 1, 1, campos.ctypes.data_as(C.c_void_p)))
+    tr.train(proj)          # one rank: the exchange is the identity and the step goes through
+    with pytest.raises(capi.GsError) as e:   # the layout contract is checked: two cameras announced, one camera's passes set
+        capi.check(L.gs_trainer_set_compact_exchange(tr.handle, C.cast(ok, C.c_void_p), C.cast(ok, C.c_void_p), None, 0, 1, 2,
+                                                     np.zeros(6, np.float32).ctypes.data_as(C.c_void_p)))
+        tr.train(proj)
+    assert e.value.status == capi.GS_ERR_INVALID_ARGUMENT and "compact exchange" in str(e.value)
+    capi.check(L.gs_trainer_set_compact_exchange(tr.handle, None, None, None, 0, 1, 0, None))
+    tr.train(proj)
     # the library's own communicator with one rank: attach, step, then destroy — and destroy again after detaching
     ident = (C.c_char * capi.GS_COMM_ID_BYTES)()
     capi.check(L.gs_comm_unique_id(ident))
