@@ -34,7 +34,7 @@ struct Options {
     int long_sort = -1;  // k_tile_sort_long launch: -1 by the longest-list hint (default), 0 never (lists take the global-scratch path), 1 always
     int sort_grids = -1; // test hook: >= 0 replaces the device's hint for the sort grids: small_first | mid_grid << 16 (in tiles)
     int xchg_overlap = 1; // compact exchange: the all-reduce of the geometry planes runs on a second stream beside the all-gather (0: one after the other)
-    int row_marks = -1;   // gradient rows only for evaluated entries (row_epoch marks): -1 by the longest-list hint (on from 1024 entries), 0 never, 1 always
+    int row_marks = -1;   // gradient rows only for evaluated entries (row_epoch marks): -1 per camera by its longest tile list (from 1024 entries), 0 never, 1 always
     int reuse_masks = 1;  // the backward reuses the forward's per-(tile sub-block, wave) block ballots; 0: it runs the block test itself (same bits)
     int roctx = 0;        // roctx range around every stage of a step (rocprofv3 --marker-trace names them); default from the environment: GS_ROCTX=1
 };
@@ -89,7 +89,7 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
     d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
     d.sgx = (d.gx + STILE - 1) / STILE; d.sgy = (d.gy + STILE - 1) / STILE; d.NST = d.sgx * d.sgy;
     d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = cull < 0 ? g_defaults.cull : cull; d.long_sort = 1; d.mid_sort = 1; d.small_first = 0; d.mid_grid = 0;
-    d.epoch = 1;
+    d.epoch = 1; d.marks_min_list = 0;
     return d;
 }
 
@@ -798,16 +798,12 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
         }
         // Row marks: in a scene with long tile lists most entries lie behind their tile's last contributor and own an all-zero
         // gradient row — with marks such rows are neither written nor read (cfg5: 84 % of them).  Where lists are short nearly
-        // every row exists and the marks only cost (cfg3: +20 us in k_splat_bwd_view), so the trainer decides by the longest
-        // list of two steps ago, like the sort launches above; either way the gradients are the same bits.
-        bool marks = t->opt.row_marks > 0;
-        if (t->opt.row_marks < 0 && t->steps_on_these_lists >= 2) {
-            uint32_t longest = 0;
-            for (int g = 0; g < t->VG; g++) longest = std::max(longest, t->h_flags[g * 4 + 1]);
-            marks = longest >= 1024u;
-        }
-        d.epoch = 0;
-        if (marks) {  // a fresh epoch per attempt; all marks are cleared when the epochs wrap or the buffer is new
+        // every row exists and the marks only cost (cfg3: +20 us in k_splat_bwd_view).  The kernels decide per camera from the
+        // longest tile list of THIS step (the tile scan writes it before the backward runs; uses_row_marks): marks from 1024
+        // entries on.  Either way the gradients are the same bits.  The host only supplies a fresh epoch per attempt and clears
+        // all marks when the epochs wrap or the buffer is new.
+        d.epoch = 0; d.marks_min_list = t->opt.row_marks < 0 ? 1024u : 0u;
+        if (t->opt.row_marks != 0) {
             if (t->row_epoch >= 255 || t->train.rowmark_cleared != t->train.rowmark.p) {
                 GS_HIP(hipMemsetAsync(t->train.rowmark.p, 0, t->train.rowmark.cap, t->stream));
                 t->train.rowmark_cleared = t->train.rowmark.p;

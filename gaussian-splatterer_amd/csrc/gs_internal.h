@@ -95,8 +95,12 @@ struct Dims {
     int small_first;  // first position of the tile order the short-list sorter's grid covers: short lists in front of it (there
                       //    are few: the order is longest first) are sorted by k_tile_sort_mid.  0: its grid covers the whole order
     int mid_grid;     // workgroups per camera of k_tile_sort_mid (0: a default); it walks on in strides when the head is longer
-    int epoch;        // 1 .. 255: the mark of this launch's gradient rows in Scratch::row_epoch
+    int epoch;        // 1 .. 255: the mark of this launch's gradient rows in Scratch::row_epoch; 0: no row marks (every entry owns a row)
+    uint32_t marks_min_list;  // with epoch != 0: a camera uses row marks iff its longest tile list (flags[g * 4 + 1], written by the tile
+                              // scan of the same step) has at least this many entries — the backward and the per-splat kernel read the same
+                              // word, so they agree; 0: always
 };
+
 
 // Device pointers of the scratch.  Arrays marked [G] are per geometry group (camera), [V] per pass.
 struct Scratch {
@@ -142,6 +146,9 @@ struct Scratch {
     float* loss;               // [V][T] per-tile sum of residual^2 (only when truth != null); launch_loss_sum folds it
     float* loss_total;         // [V]
 };
+
+// Does geometry group g use row marks in this launch?  (k_render.hip writes them, k_splat_bwd.hip reads them.)
+__device__ inline bool uses_row_marks(const Dims& d, const Scratch& s, int g) { return d.epoch != 0 && s.flags[g * 4 + 1] >= d.marks_min_list; }
 
 // ---------------------------------------------------------------------------------------------
 // kernel launchers (one translation unit each)

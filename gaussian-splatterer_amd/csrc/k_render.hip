@@ -457,9 +457,9 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
     // nor read by the per-splat kernel: a row exists iff its mark (row_epoch[slot]) equals this launch's epoch, and only the
     // flush below sets marks.  (Through round 3 every entry got its row: in a dense scene — 1100 entries per tile of which the
     // pixels saturate after ~170 — 84 % of the rows were zeros, 2.2 GB written here and read again by k_splat_bwd_view.)
-    // Without marks (d.epoch == 0: scenes with short lists, where nearly every row exists and the marks would only cost) every
-    // entry owns a row, as before.
-    const bool marks = d.epoch != 0;
+    // Without marks (cameras whose longest tile list is short: nearly every row exists and the marks would only cost; the
+    // decision is taken per camera from the tile scan of this very step, gs_internal.h uses_row_marks) every entry owns a row.
+    const bool marks = uses_row_marks(d, s, g);
     if (!marks)
         for (int e = rounds * ROUND + tid; e < n; e += WG) {
             Row3* row = reinterpret_cast<Row3*>(Gout + (size_t)slist[e] * G_STRIDE);

@@ -192,8 +192,8 @@ __device__ inline void splat_backward_core(const gs_view& vp, int W, int H, cons
     }
 }
 
-// Sum the nine pixel-stage partials of splat i over its `tiles` slots, ascending slot order.  With row marks (epoch != 0; the
-// trainer switches them on for scenes with long tile lists, the seam always) a slot holds a row only if its mark
+// Sum the nine pixel-stage partials of splat i over its `tiles` slots, ascending slot order.  With row marks (epoch != 0: cameras
+// with long tile lists, uses_row_marks; the seam always) a slot holds a row only if its mark
 // equals the launch's epoch (k_render.hip: the backward writes and marks rows for evaluated entries only); the others are
 // implicit zero rows.  The marks are fetched one trip ahead of the rows they guard.  The first trip cannot know its marks
 // before it asks for its rows: it requests marks and rows together (slots behind the splat's last one are redirected to
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(WG) GS_SBV_ATTR void k_splat_bwd_view(Dims d, const
     for (int c = 0; c < 4; c++) q[c] = params[pl.rot(c) * st + i];
     const uint32_t first = s.point_offsets[(size_t)g * st + i] - tiles;
     float sum[9];
-    gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, s.row_epoch + (size_t)v * d.Rcap, (uint32_t)d.epoch, s.zero_row, first, tiles, sum);
+    gather_rows(s.G + (size_t)v * d.Rcap * G_STRIDE, s.row_epoch + (size_t)v * d.Rcap, uses_row_marks(d, s, g) ? (uint32_t)d.epoch : 0u, s.zero_row, first, tiles, sum);
     SplatOut<D> o;
     float dRGB[3];
     // d colour / d direction was evaluated by the projection (same camera for every pass of the group): 9 floats
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_seam(Dims d, const float* __re
     const uint32_t tiles = s.tiles_touched[i];
     const uint32_t first = s.point_offsets[i] - tiles;
     float sum[9];
-    gather_rows(s.G, s.row_epoch, (uint32_t)d.epoch, s.zero_row, first, tiles, sum);
+    gather_rows(s.G, s.row_epoch, uses_row_marks(d, s, 0) ? (uint32_t)d.epoch : 0u, s.zero_row, first, tiles, sum);
     float dcolor[3];
     for (int c = 0; c < 3; c++) { dcolor[c] = g.dL_dcolor[3 * (size_t)i + c] + sum[c]; g.dL_dcolor[3 * (size_t)i + c] = dcolor[c]; }
     const float g2x = g.dL_dmean2D[3 * (size_t)i] + sum[3], g2y = g.dL_dmean2D[3 * (size_t)i + 1] + sum[4];

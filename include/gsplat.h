@@ -233,8 +233,8 @@ int gs_trainer_apply(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs
  * "row_marks" (default -1): the backward leaves one gradient row per (tile entry, camera) for the per-splat kernel.  With marks
  * (1) a row is written, marked and later read only for an entry some 8x8 pixel block evaluated; all others — everything behind a
  * tile's last contributor: 84 % of the rows of a dense scene — are implicit zeros.  Without (0) every entry owns a row, which is
- * cheaper where lists are short and nearly every row exists.  -1 decides by the longest tile list of two steps ago (marks
- * from 1024 entries on).  Bit-identical gradients either way.
+ * cheaper where lists are short and nearly every row exists.  -1 decides per camera and step by the camera's longest tile list
+ * (marks from 1024 entries on; the kernels read it from the tile scan of the same step).  Bit-identical gradients either way.
  * "reuse_hit_masks" (default 1): the backward reuses the block ballots the forward of the same camera stored (which entries of
  * a tile list can reach which 8x8 pixel block) instead of running the block test again; 0 makes it test itself.  Bit-identical.
  * "exchange_overlap" (default 1): see gs_trainer_set_compact_exchange.

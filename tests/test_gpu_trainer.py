@@ -491,8 +491,8 @@ def test_backward_own_block_test_equals_the_reused_ballots(orc):
 def test_row_marks_switch_is_bit_identical(orc):
     """Trainer option "row_marks": with marks the backward writes (and the per-splat kernel reads) a gradient row only for
     entries some pixel block evaluated, all other rows are implicit zeros; without, every entry owns a row.  Same bits either
-    way — ordinary scene and long lists, fused-pair step and per-pass form — and the automatic choice (by the longest list of
-    two steps ago) changes nothing either."""
+    way — ordinary scene and long lists, fused-pair step and per-pass form — and the automatic choice (per camera, by its longest
+    tile list of the same step) changes nothing either."""
     for P, spread in ((2500, 1.0), (3000, 0.05)):
         W, H, M, n_cams = (128, 96, 4, 2) if spread == 1.0 else (32, 32, 1, 1)
         res = []
@@ -513,7 +513,7 @@ def test_row_marks_switch_is_bit_identical(orc):
             tr.captureTruths(cams, fw, fb)
             still = gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0)
             out = []
-            for k in range(4):          # the automatic choice looks two steps back: steps 0-1 run without marks, 2-3 by the hint
+            for k in range(4):
                 st = tr.train(still, stats=True)
                 out.append(_read_grads(tr, P, M))
             tr.accumulate()
