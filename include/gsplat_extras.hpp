@@ -12,6 +12,7 @@
 //   SplatRecord     one splat's five attribute groups, the unit every field initialiser emits
 //   lattice / mono / triangles   generators of SplatRecords; makeField() pushes them into a ModelSplatsHost
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdlib>
@@ -23,6 +24,7 @@
 #include <ostream>
 #include <sstream>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "gsplat_shim.hpp"
@@ -262,5 +264,62 @@ inline std::unique_ptr<ModelSplatsHost> initFieldModel(const std::string& objPat
     if (!file) throw std::runtime_error("Failed to load model file at \"" + objPath + "\"!");
     return initFieldModel(file, quatXYZW);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The caller of the path: the "Auto Train" loop of UiFrame::update (src/ui/UiFrame.cpp:266-298) without the GUI — at most
+// AUTO_TRAIN_BUDGET = 100 iterations per second (src/Config.h:10; the budget never accumulates beyond one iteration), truth
+// re-capture with randomly re-rotated camera spheres every `intervalCapture` iterations (UiPanelToolsTruth::onButtonRandomRotate
+// / onButtonCapture, src/ui/tools/UiPanelToolsTruth.cpp:186-197), densify every `intervalDensify` iterations.
+// TrainerT needs train(ProjectT&, bool) and captureTruths(cameras, framesWhite, framesBlack) (gsplat_shim::Trainer has both);
+// the truth renderer stays the caller's (the reference's is OptiX): capture(cameras, framesWhite, framesBlack) fills one RGBA8
+// image per camera and background.  random01: a uniform [0, 1) source (the reference calls rand() / RAND_MAX).
+template <class TrainerT, class ProjectT>
+class AutoTrainer {
+public:
+    using Frames = std::vector<std::vector<uint32_t>>;
+    using Capture = std::function<void(const std::vector<Camera>&, Frames& white, Frames& black)>;
+    static constexpr float kBudgetPerSecond = 100.0f;  // AUTO_TRAIN_BUDGET
+    bool autoTraining = true;
+    float autoTrainingBudget = 0.0f;
+
+    AutoTrainer(TrainerT& trainerArg, ProjectT& projectArg, Capture captureArg, std::function<float()> random01 = {})
+        : trainer(trainerArg), project(projectArg), capture(std::move(captureArg)),
+          random(random01 ? std::move(random01) : std::function<float()>([] { return (float)std::rand() / ((float)RAND_MAX + 1.0f); })) {}
+
+    void randomRotate() {  // src/ui/tools/UiPanelToolsTruth.cpp:192-197
+        project.sphere1.rotX = random() * 360.0f; project.sphere1.rotY = random() * 360.0f;
+        project.sphere2.rotX = random() * 360.0f; project.sphere2.rotY = random() * 360.0f;
+    }
+    void captureTruths() {  // :186-190 -> Trainer::captureTruths with the project's cameras
+        const std::vector<Camera> cameras = Camera::getCameras(project);
+        Frames white, black;
+        capture(cameras, white, black);
+        trainer.captureTruths(cameras, white, black);
+    }
+    // one iteration: the body of `if(autoTrainingBudget >= 1.0f)` (src/ui/UiFrame.cpp:279-296); returns {captured, densified}
+    std::pair<bool, bool> step() {
+        const bool cap = project.intervalCapture > 0 && project.iterations % project.intervalCapture == 0;
+        const bool densify = project.intervalDensify > 0 && project.iterations % project.intervalDensify == 0;
+        if (cap) { randomRotate(); captureTruths(); }
+        trainer.train(project, densify);
+        return { cap, densify };
+    }
+    // UiFrame::update (:266-298), called from the host's idle loop with the seconds since the last call; true when an iteration ran
+    bool update(float delta) {
+        project.previewTimer += delta;
+        if (!autoTraining) return false;
+        autoTrainingBudget = std::min(1.0f, autoTrainingBudget + delta * kBudgetPerSecond);
+        if (autoTrainingBudget < 1.0f) return false;
+        autoTrainingBudget = 0.0f;
+        step();
+        return true;
+    }
+
+private:
+    TrainerT& trainer;
+    ProjectT& project;
+    Capture capture;
+    std::function<float()> random;
+};
 
 }  // namespace gsplat_shim

@@ -66,6 +66,32 @@ int main(int argc, char** argv) {
         fclose(f);
         if (!past_end) return 9;
     }
+    {   // the auto-train loop (UiFrame::update, src/ui/UiFrame.cpp:266-298) against a trainer that only counts
+        struct Counting {
+            int trains = 0, densifies = 0, captures = 0, cameras = 0;
+            void train(Project& p, bool densify) { p.iterations++; trains++; densifies += densify; }
+            void captureTruths(const std::vector<Camera>& c, const std::vector<std::vector<uint32_t>>& w, const std::vector<std::vector<uint32_t>>& b) {
+                captures++; cameras = (int)c.size();
+                if (w.size() != c.size() || b.size() != c.size()) std::abort();
+            }
+        } counting;
+        Project pr;
+        pr.sphere1.count = 3; pr.sphere2.count = 0; pr.intervalCapture = 4; pr.intervalDensify = 6;
+        unsigned lcg = 12345u;
+        AutoTrainer<Counting, Project> loop(counting, pr,
+            [](const std::vector<Camera>& cams, AutoTrainer<Counting, Project>::Frames& w, AutoTrainer<Counting, Project>::Frames& b) { w.assign(cams.size(), {}); b.assign(cams.size(), {}); },
+            [&lcg] { lcg = lcg * 1664525u + 1013904223u; return (float)(lcg >> 8) / 16777216.0f; });
+        int ran = 0;
+        for (int tick = 0; tick < 400; tick++) ran += loop.update(0.0125f);      // idle events 12.5 ms apart: one iteration per event
+        if (ran != 400 || pr.iterations != 400 || counting.trains != 400) return 10;
+        if (counting.densifies != 67 || counting.captures != 100 || counting.cameras != 3) return 10;   // iterations 0, 6, ... 396 and 0, 4, ... 396
+        if (!(pr.sphere1.rotX >= 0.0f && pr.sphere1.rotX < 360.0f) || pr.sphere1.rotX == 0.0f) return 10;
+        ran = 0;
+        for (int tick = 0; tick < 1000; tick++) ran += loop.update(0.001f);       // events 1 ms apart: the budget allows one iteration per ten
+        if (ran < 95 || ran > 100) return 11;
+        loop.autoTraining = false;
+        if (loop.update(1.0f) || pr.previewTimer < 6.9f) return 11;                // the preview timer runs on (5 s + 1 s + 1 s)
+    }
     printf("extras ok\n");
     return 0;
 }
