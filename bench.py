@@ -553,9 +553,13 @@ def cpu_baseline(gs, s, cams, framesW, framesB, P, M, D, W, H, n_cams, n_views):
     V_total = 2 * n_cams
     pick = [0, n_cams][:n_views] if n_views <= 2 else list(range(min(n_views, V_total)))
     truths = np.concatenate([(framesW[v] if v < n_cams else framesB[v - n_cams]) for v in pick])
-    t0 = time.perf_counter()
-    o = orc.train_views(P, D, M, W, H, s["loc"], s["sh"], s["scale"], s["opac"], s["rot"], views[pick], truths, float(V_total))
-    t_views = time.perf_counter() - t0
+    # repeated until about ten seconds of CPU work are on the clock (at most five times); the FASTEST repetition is the baseline
+    t_all, reps, t_views = time.perf_counter(), 0, float("inf")
+    while reps < 5 and (reps == 0 or time.perf_counter() - t_all < 10.0):
+        t0 = time.perf_counter()
+        o = orc.train_views(P, D, M, W, H, s["loc"], s["sh"], s["scale"], s["opac"], s["rot"], views[pick], truths, float(V_total))
+        t_views = min(t_views, time.perf_counter() - t0)
+        reps += 1
     p = {k: s[k].copy() for k in ("loc", "sh", "scale", "opac", "rot")}
     m = np.zeros((11 + 3 * M) * P, np.float32)
     v = np.zeros_like(m)
@@ -564,8 +568,10 @@ def cpu_baseline(gs, s, cams, framesW, framesB, P, M, D, W, H, n_cams, n_views):
     t_upd = time.perf_counter() - t0
     step_s = t_views / len(pick) * V_total + t_upd
     return {"value": 1.0 / step_s, "unit": "steps/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"{len(pick)} of {V_total} passes of the same workload timed ({t_views:.2f} s) and scaled x{V_total / len(pick):g}, "
-                      f"Adam update timed in full ({t_upd:.3f} s); CPU restatement of the reference semantics (oracle/), OpenMP"}
+            "sample": f"{len(pick)} of {V_total} passes of the same workload timed ({t_views:.2f} s, fastest of {reps} repetitions) and scaled x{V_total / len(pick):g}, "
+                      f"Adam update timed in full ({t_upd:.3f} s); CPU restatement of the reference semantics (oracle/), OpenMP with one thread per CPU "
+                      f"this process may use ({orc.usable_cpus()} by affinity and cgroup quota; the host shows {os.cpu_count()} hardware threads — with one OpenMP "
+                      f"thread for each of those, which rounds 1-3 ran, the same sample takes about three times as long)"}
 
 
 if __name__ == "__main__":

@@ -30,12 +30,32 @@ def build(force=False):
     return _LIB_PATH
 
 
+def usable_cpus():
+    """CPUs this process may use: the affinity mask, cut to the cgroup's CPU quota (cpu.max of cgroup v2, cfs_quota of v1)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
         _lib = C.CDLL(_LIB_PATH)
+        if "OMP_NUM_THREADS" not in os.environ:      # the user's word stands; otherwise one thread per CPU the process may use
+            _lib.orc_set_num_threads(C.c_int(usable_cpus()))
         _lib.orc_state_new.restype = C.c_void_p
         _lib.orc_state_free.argtypes = [C.c_void_p]
         _lib.orc_get.restype = C.c_long
