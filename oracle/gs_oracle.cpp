@@ -409,13 +409,82 @@ inline void pixel_backward(const ViewState<R>& g, uint32_t beg, uint32_t end, R 
     }
 }
 
+// Conditioning of one pixel's nine terms, in units of 2^-24 (first-order forward error analysis, all in double).  Three places
+// of the blend subtract products that can be orders of magnitude larger than their difference:
+//   * the exponent  power = -(a dx^2 + c dy^2)/2 - b dx dy  (m = |a| dx^2/2 + |c| dy^2/2 + |b dx dy| >> |power| for a big splat seen far
+//     along its long axis): ANY fp32 evaluation order, the reference's included, carries ~m ulps of relative error in G = exp(power) and
+//     in alpha; through T = prod(1 - alpha) and the colour recurrence that error reaches the terms of every other entry of the pixel;
+//   * dG/dmean = -G (a dx + b dy), -G (c dy + b dx): the two products cancel along the same axis;
+//   * dL/dalpha = T sum_c (colour_c - accum_c) dL/dpixel_c - T_final / (1 - alpha) (bg . dL/dpixel).
+// An implementation that applies per-splat constants after summing over pixels (a . sum(u dx) + b . sum(u dy) instead of
+// sum(u (a dx + b dy))) has the same bound with a different draw, which 1e-4 of sum|term| — terms AFTER the cancellation — cannot
+// see.  emit(k, q, c): |error of term q of entry k| <~ c x 2^-24; the tests allow a small multiple of it (cond9).
+template <class R, class Emit>
+inline void pixel_cond(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx, R pixfy, R T_final, uint32_t last_contributor,
+                       const R* bg, const R dpx[3], R ddelx_dx, R ddely_dy, Emit emit) {
+    struct E { uint32_t k; double dx, dy, G, alpha, m, rho, a, b, c, op, col[3]; };
+    std::vector<E> ent;   // back to front, as the backward visits them
+    uint32_t contributor = end - beg;
+    for (uint32_t k = end; k-- > beg;) {
+        contributor--;
+        if (contributor >= last_contributor) continue;
+        const uint32_t id = g.point_list[k];
+        const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+        const R* co = &g.conic_opacity[4 * (size_t)id];
+        const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        if (power > R(0.0)) continue;
+        const R G = std::exp(power);
+        const R alpha = std::min(R(0.99), co[3] * G);
+        if (alpha < R(1.0) / R(255.0)) continue;
+        const double m = 0.5 * (std::fabs((double)co[0]) * dx * dx + std::fabs((double)co[2]) * dy * dy) + std::fabs((double)co[1] * dx * dy);
+        ent.push_back({ k, (double)dx, (double)dy, (double)G, (double)alpha, m, alpha < R(0.99) ? m : 0.0, (double)co[0], (double)co[1], (double)co[2],
+                        (double)co[3], { (double)g.rgb[3 * (size_t)id], (double)g.rgb[3 * (size_t)id + 1], (double)g.rgb[3 * (size_t)id + 2] } });
+    }
+    const size_t n = ent.size();
+    if (!n) return;
+    // relative error of T in front of entry j: sum over the entries in front of it of rho alpha / (1 - alpha)
+    std::vector<double> front(n, 0.0);
+    double run = 0.0;
+    for (size_t j = n; j-- > 0;) { front[j] = run; run += ent[j].rho * ent[j].alpha / (1.0 - ent[j].alpha); }
+    const double front_all = run;
+    double Tt = (double)T_final, accum[3] = { 0, 0, 0 }, dacc[3] = { 0, 0, 0 }, last_col[3] = { 0, 0, 0 }, last_alpha = 0, last_rho = 0;
+    double bg_dot = 0;
+    for (int c = 0; c < 3; c++) bg_dot += (double)bg[c] * (double)dpx[c];
+    for (size_t j = 0; j < n; j++) {
+        const E& e = ent[j];
+        Tt = Tt / (1.0 - e.alpha);
+        double dLda = 0, dLda_err = 0;
+        for (int c = 0; c < 3; c++) {
+            const double prev = accum[c];
+            accum[c] = last_alpha * last_col[c] + (1.0 - last_alpha) * prev;
+            dacc[c] = last_alpha * last_rho * std::fabs(last_col[c] - prev) + (1.0 - last_alpha) * dacc[c];
+            last_col[c] = e.col[c];
+            dLda += (e.col[c] - accum[c]) * (double)dpx[c];
+            dLda_err += std::fabs((double)dpx[c]) * (std::fabs(e.col[c] - accum[c]) * (front[j] + 1.0) + dacc[c]);
+            emit(e.k, c, std::fabs(e.alpha * Tt * (double)dpx[c]) * (e.rho + front[j]));
+        }
+        dLda *= Tt; dLda_err *= Tt;
+        last_alpha = e.alpha; last_rho = e.rho;
+        const double bgpart = (-(double)T_final / (1.0 - e.alpha)) * bg_dot;
+        dLda += bgpart; dLda_err += std::fabs(bgpart) * (front_all + 1.0);
+        const double through = std::fabs(dLda) * e.m + dLda_err;       // G carries m ulps whether or not alpha is clipped
+        const double gdx = e.G * e.dx, gdy = e.G * e.dy;
+        emit(e.k, 3, e.op * (std::fabs(gdx * e.a) + std::fabs(gdy * e.b)) * (double)ddelx_dx * (through + std::fabs(dLda)));
+        emit(e.k, 4, e.op * (std::fabs(gdy * e.c) + std::fabs(gdx * e.b)) * (double)ddely_dy * (through + std::fabs(dLda)));
+        emit(e.k, 5, e.op * 0.5 * std::fabs(gdx * e.dx) * through);
+        emit(e.k, 6, e.op * 0.5 * std::fabs(gdx * e.dy) * through);
+        emit(e.k, 7, e.op * 0.5 * std::fabs(gdy * e.dy) * through);
+        emit(e.k, 8, e.G * through);
+    }
+}
+
 template <class R>
 void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const Grads<R>& o, double* abs9, double* flip9 = nullptr,
-                     float flip_margin = 0.0f) {
+                     float flip_margin = 0.0f, double* cond9 = nullptr) {
     const int W = g.W, H = g.H, P = g.P;
     const size_t N = (size_t)W * H;
     const size_t Rn = g.point_list.size();
-    std::vector<double> part(Rn * 9, 0.0), partabs(abs9 ? Rn * 9 : 0, 0.0), partflip(flip9 ? Rn * 9 : 0, 0.0);
+    std::vector<double> part(Rn * 9, 0.0), partabs(abs9 ? Rn * 9 : 0, 0.0), partflip(flip9 ? Rn * 9 : 0, 0.0), partcond(cond9 ? Rn * 9 : 0, 0.0);
     const int T = g.gx * g.gy;
     const R ddelx_dx = R(0.5) * R(W), ddely_dy = R(0.5) * R(H);
 #pragma omp parallel for schedule(dynamic, 4)
@@ -435,6 +504,9 @@ void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const
                                       part[(size_t)k * 9 + q] += (double)term;
                                       if (abs9) partabs[(size_t)k * 9 + q] += std::fabs((double)term);
                                   });
+                if (cond9)
+                    pixel_cond<R>(g, beg, end, pixfx, pixfy, g.final_T[pix], g.n_contrib[pix], bg, dpx, ddelx_dx, ddely_dy,
+                                  [&](uint32_t k, int q, double c) { partcond[(size_t)k * 9 + q] += c; });
                 if (!flip9 || !(g.margin[pix] < flip_margin)) continue;
                 // this pixel holds at least one pair within flip_margin of a threshold: one re-run per such pair
                 frag.clear();
@@ -458,11 +530,13 @@ void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const
     std::vector<double> acc((size_t)P * 9, 0.0);
     if (abs9) std::fill(abs9, abs9 + (size_t)P * 9, 0.0);
     if (flip9) std::fill(flip9, flip9 + (size_t)P * 9, 0.0);
+    if (cond9) std::fill(cond9, cond9 + (size_t)P * 9, 0.0);
     for (size_t k = 0; k < Rn; k++) {
         const uint32_t id = g.point_list[k];
         for (int q = 0; q < 9; q++) acc[(size_t)id * 9 + q] += part[k * 9 + q];
         if (abs9) for (int q = 0; q < 9; q++) abs9[(size_t)id * 9 + q] += partabs[k * 9 + q];
         if (flip9) for (int q = 0; q < 9; q++) flip9[(size_t)id * 9 + q] += partflip[k * 9 + q];
+        if (cond9) for (int q = 0; q < 9; q++) cond9[(size_t)id * 9 + q] += partcond[k * 9 + q];
     }
     for (int i = 0; i < P; i++) {
         const double* a = &acc[(size_t)i * 9];
@@ -658,12 +732,20 @@ void preprocess_backward(const ViewState<R>& g, int D, int M, const R* means, co
 // reported decision depth-first enumerates the admissible blends of the pixel (orc_check_pixels_f32): a foreign result
 // has to equal ONE of them — colour, final T and last contributor — instead of being excluded from the comparison.
 struct ForcedDecision { uint32_t k; int kind; bool value; };  // kind 1: skip (alpha test), 2: stop (T test)
-template <class R> struct PixelLeaf { R T, C[3]; uint32_t last; };
+template <class R> struct PixelLeaf { R T, C[3]; uint32_t last; R tolT, tolC[3]; };
 // returns true when the run completed (leaf filled); false when it stopped at an unforced fragile decision (*branch, with its
 // nominal value)
 template <class R>
 inline bool pixel_run(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx, R pixfy, const std::vector<ForcedDecision>& forced,
-                      float alpha_margin, float T_margin, PixelLeaf<R>& leaf, ForcedDecision* branch) {
+                      float alpha_margin, float T_margin, PixelLeaf<R>& leaf, ForcedDecision* branch, float exp_cond = 0.0f) {
+    // exp_cond > 0: the conditioning of the exponent.  power = -(a dx^2 + c dy^2)/2 - b dx dy is a sum of three products that
+    // cancel for a splat seen far along its long axis (|a| dx^2 / 2 + |c| dy^2 / 2 + |b dx dy| = m >> |power|): every fp32 evaluation
+    // order, the reference's included, carries ~2^-24 m of absolute error in the power, i.e. a RELATIVE error of that size in alpha.
+    // An implementation may deviate by exp_cond x 2^-24 m_i in alpha_i (none where alpha is clipped to 0.99); carried to first
+    // order through the blend that is tolC / tolT of the leaf:  dC = sum_i rho_i alpha_i |c_i T_i - S_i / (1 - alpha_i)|
+    // (S_i: what lies behind entry i),  dT = T sum_i rho_i alpha_i / (1 - alpha_i).
+    struct Term { R alpha, T, c[3], rho; };
+    std::vector<Term> terms;
     R Tt = R(1.0), C[3] = { 0, 0, 0 };
     uint32_t contributor = 0, last = 0;
     auto forced_value = [&](uint32_t k, int kind, bool& v) {
@@ -692,11 +774,27 @@ inline bool pixel_run(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx
         }
         if (stop) break;
         for (int c = 0; c < 3; c++) C[c] += g.rgb[3 * (size_t)id + c] * alpha * Tt;
+        if (exp_cond > 0.0f) {
+            const R m = R(0.5) * (std::fabs(co[0]) * dx * dx + std::fabs(co[2]) * dy * dy) + std::fabs(co[1] * dx * dy);
+            terms.push_back({ alpha, Tt, { g.rgb[3 * (size_t)id], g.rgb[3 * (size_t)id + 1], g.rgb[3 * (size_t)id + 2] },
+                              alpha < R(0.99) ? R(exp_cond) * R(5.9604644775390625e-08) * m : R(0) });
+        }
         Tt = test_T;
         last = contributor;
     }
     leaf.T = Tt; leaf.last = last;
-    for (int c = 0; c < 3; c++) leaf.C[c] = C[c];
+    leaf.tolT = 0;
+    for (int c = 0; c < 3; c++) { leaf.C[c] = C[c]; leaf.tolC[c] = 0; }
+    R behind[3] = { 0, 0, 0 };
+    for (size_t i = terms.size(); i-- > 0;) {
+        const Term& t = terms[i];
+        leaf.tolT += t.rho * t.alpha / (R(1.0) - t.alpha);
+        for (int c = 0; c < 3; c++) {
+            leaf.tolC[c] += t.rho * t.alpha * std::fabs(t.c[c] * t.T - behind[c] / (R(1.0) - t.alpha));
+            behind[c] += t.c[c] * t.alpha * t.T;
+        }
+    }
+    leaf.tolT *= Tt;
     return true;
 }
 
@@ -715,8 +813,8 @@ int forward_impl(State<R>* st, int P, int D, int M, const R* bg, int W, int H, c
 template <class R>
 void backward_impl(State<R>* st, int D, int M, const R* bg, const R* means, const R* shs, const R* scales, R mod,
                    const R* rots, const R* view, const R* proj, const R* campos, R tanx, R tany, const R* dL_dpix,
-                   const Grads<R>& o, double* abs9, double* flip9 = nullptr, float flip_margin = 0.0f) {
-    render_backward<R>(st->v, bg, dL_dpix, o, abs9, flip9, flip_margin);
+                   const Grads<R>& o, double* abs9, double* flip9 = nullptr, float flip_margin = 0.0f, double* cond9 = nullptr) {
+    render_backward<R>(st->v, bg, dL_dpix, o, abs9, flip9, flip_margin, cond9);
     preprocess_backward<R>(st->v, D, M, means, scales, mod, rots, shs, view, proj, campos, tanx, tany, o);
 }
 
@@ -804,6 +902,15 @@ void orc_backward_f32_flip(orc_state* s, int D, int M, const float* bg, const fl
     Grads<float> o{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
     backward_impl<float>(&s->f, D, M, bg, means, shs, scales, mod, rots, view, proj, campos, tanx, tany, dL_dpix, o, abs9, flip9, flip_margin);
 }
+// The same, plus cond9[P][9]: the conditioning of every sum in units of 2^-24 (pixel_cond).
+void orc_backward_f32_cond(orc_state* s, int D, int M, const float* bg, const float* means, const float* shs,
+                           const float* scales, float mod, const float* rots, const float* view, const float* proj,
+                           const float* campos, float tanx, float tany, const float* dL_dpix, float* dL_dmean2D,
+                           float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                           float* dL_dsh, float* dL_dscale, float* dL_drot, double* abs9, double* flip9, float flip_margin, double* cond9) {
+    Grads<float> o{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
+    backward_impl<float>(&s->f, D, M, bg, means, shs, scales, mod, rots, view, proj, campos, tanx, tany, dL_dpix, o, abs9, flip9, flip_margin, cond9);
+}
 // The per-splat half of the backward alone (upstream's computeCov2DCUDA + preprocessCUDA backward)
 // on caller-supplied pixel-stage sums: sums9[P][9] = dL_dcolor(3), dL_dmean2D(2), dL_dconic x/y/w(3), dL_dopacity(1).
 // The chain is LINEAR in those sums for a fixed scene, so the parity tests can carry a per-splat tolerance on the
@@ -831,11 +938,11 @@ void orc_chain_f32(orc_state* s, int D, int M, const float* means, const float* 
 //   2  equals NO admissible blend
 //   3  undecided: more than max_leaves blends without a match
 // leaves[pix] = blends examined (1: the pixel holds no fragile decision).  "Equals": last contributor identical,
-// |T - T'| <= rtol max(|T'|, floor_T), |C - C'| <= rtol max(|C'|, floor_C) per channel.  Returns the number of pixels
-// with status >= 2.
+// |T - T'| <= rtol max(|T'|, floor_T), |C - C'| <= rtol max(|C'|, floor_C) per channel — plus, with exp_cond > 0, the leaf's
+// tolT / tolC (the conditioning of the exponent, see pixel_run).  Returns the number of pixels with status >= 2.
 int orc_check_pixels_f32(orc_state* s, const float* bg, const float* got_color, const float* got_T, const uint32_t* got_last,
                          float alpha_margin, float T_margin, float rtol, float floor_T, float floor_C, int max_leaves,
-                         int32_t* status, int32_t* leaves) {
+                         int32_t* status, int32_t* leaves, float exp_cond) {
     const ViewState<float>& g = s->f.v;
     const int W = g.W, H = g.H;
     const size_t N = (size_t)W * H;
@@ -851,10 +958,10 @@ int orc_check_pixels_f32(orc_state* s, const float* bg, const float* got_color, 
                 const size_t pix = (size_t)py * W + px;
                 auto matches = [&](const PixelLeaf<float>& l) {
                     if (l.last != got_last[pix]) return false;
-                    if (!(std::fabs(got_T[pix] - l.T) <= rtol * std::max(std::fabs(l.T), floor_T))) return false;
+                    if (!(std::fabs(got_T[pix] - l.T) <= rtol * std::max(std::fabs(l.T), floor_T) + l.tolT)) return false;
                     for (int c = 0; c < 3; c++) {
                         const float want = l.C[c] + l.T * bg[c];
-                        if (!(std::fabs(got_color[c * N + pix] - want) <= rtol * std::max(std::fabs(want), floor_C))) return false;
+                        if (!(std::fabs(got_color[c * N + pix] - want) <= rtol * std::max(std::fabs(want), floor_C) + l.tolC[c] + l.tolT * std::fabs(bg[c]))) return false;
                     }
                     return true;
                 };
@@ -867,7 +974,7 @@ int orc_check_pixels_f32(orc_state* s, const float* bg, const float* got_color, 
                     stack.pop_back();
                     PixelLeaf<float> leaf;
                     ForcedDecision br;
-                    if (pixel_run<float>(g, beg, end, (float)px, (float)py, forced, alpha_margin, T_margin, leaf, &br)) {
+                    if (pixel_run<float>(g, beg, end, (float)px, (float)py, forced, alpha_margin, T_margin, leaf, &br, exp_cond)) {
                         n_leaves++;
                         // the nominal blend is the leaf reached by taking the nominal value at every branch: explored first
                         if (matches(leaf)) { st = first ? 0 : 1; break; }

@@ -131,10 +131,12 @@ class Rasterizer:
             raise KeyError(name)
         return buf[:n].view(dt).copy()
 
-    def backward(self, dL_dpix, want_abs=False, flip_margin=None):
+    def backward(self, dL_dpix, want_abs=False, flip_margin=None, want_cond=False):
         """flip_margin (fp32 only): also return g["flip9"][P, 9], the admissible deviation of an implementation that
         takes the other branch at every blend decision within that relative margin of its threshold (gs_oracle.cpp,
-        render_backward)."""
+        render_backward).  want_cond (with flip_margin): also g["cond9"][P, 9], the conditioning of every sum in units of
+        2^-24 (gs_oracle.cpp, pixel_cond): what the cancellations inside the exponent, dG/dmean and dL/dalpha cost ANY fp32
+        evaluation order."""
         a = self.args
         dt = self.dt
         P, M = self.P, a["M"]
@@ -147,6 +149,11 @@ class Rasterizer:
             flip9 = np.zeros(9 * P, np.float64) if flip_margin is not None else None
             fn = lib().orc_backward_f32 if flip_margin is None else lib().orc_backward_f32_flip
             extra = () if flip_margin is None else (_p(flip9, f64p), C.c_float(flip_margin))
+            cond9 = None
+            if want_cond:
+                assert flip_margin is not None
+                cond9 = np.zeros(9 * P, np.float64)
+                fn, extra = lib().orc_backward_f32_cond, extra + (_p(cond9, f64p),)
             fn(self.h, C.c_int(a["D"]), C.c_int(M), _p(a["bg"], f32p), _p(a["means"], f32p),
                                    _p(a["shs"], f32p), _p(a["scales"], f32p), C.c_float(a["mod"]),
                                    _p(a["rots"], f32p), _p(a["view"], f32p), _p(a["proj"], f32p),
@@ -155,6 +162,8 @@ class Rasterizer:
                                    _p(g["dL_dopacity"], f32p), _p(g["dL_dcolor"], f32p), _p(g["dL_dmean3D"], f32p),
                                    _p(g["dL_dcov3D"], f32p), _p(g["dL_dsh"], f32p), _p(g["dL_dscale"], f32p),
                                    _p(g["dL_drot"], f32p), _p(abs9, f64p), *extra)
+            if cond9 is not None:
+                g["cond9"] = cond9.reshape(P, 9)
             if abs9 is not None:
                 g["abs9"] = abs9.reshape(P, 9)
             if flip9 is not None:
@@ -171,10 +180,12 @@ class Rasterizer:
         return g
 
 
-def check_pixels(r, got_color, got_T, got_last, alpha_margin=1e-4, T_margin=1e-4, rtol=1e-4, floor_T=1e-4, floor_C=1e-3, max_leaves=4096):
+def check_pixels(r, got_color, got_T, got_last, alpha_margin=1e-4, T_margin=1e-4, rtol=1e-4, floor_T=1e-4, floor_C=1e-3, max_leaves=4096, exp_cond=0.0):
     """Every pixel of another implementation's forward output against the ADMISSIBLE blends of Rasterizer `r`'s last
     forward (gs_oracle.cpp, orc_check_pixels_f32): the nominal blend, or the blend with fragile decisions — pairs within
     alpha_margin / T_margin (relative) of the alpha = 1/255 / T = 1e-4 thresholds — taken the other way.
+    exp_cond > 0 widens the comparison by the conditioning of the exponent: alpha_i may deviate by exp_cond * 2^-24 * m_i relative,
+    m_i = (|a| dx^2 + |c| dy^2) / 2 + |b dx dy| (the magnitudes the power's three products cancel from), carried through the blend.
     Returns (status int32[N]: 0 nominal, 1 another admissible blend, 2 none, 3 undecided; leaves int32[N])."""
     a = r.args
     assert r.dt == np.float32
@@ -187,7 +198,7 @@ def check_pixels(r, got_color, got_T, got_last, alpha_margin=1e-4, T_margin=1e-4
     leaves = np.zeros(N, np.int32)
     lib().orc_check_pixels_f32(r.h, _p(a["bg"], f32p), _p(col, f32p), _p(gT, f32p), _p(gl, u32p), C.c_float(alpha_margin),
                                C.c_float(T_margin), C.c_float(rtol), C.c_float(floor_T), C.c_float(floor_C), C.c_int(max_leaves),
-                               _p(status, i32p), _p(leaves, i32p))
+                               _p(status, i32p), _p(leaves, i32p), C.c_float(exp_cond))
     return status, leaves
 
 

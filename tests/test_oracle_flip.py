@@ -5,6 +5,7 @@ agree within 1e-4 * sum|term| + flip9(margin) for EVERY splat once the margin co
 must be what closes the gap (in the dense scene some splats are out of budget without it)."""
 import numpy as np
 
+import gsplat_amd as gs
 from util import make_scene, view_parts
 
 NINE = {"dL_dcolor": ([0, 1, 2], 3, [0, 1, 2]), "dL_dmean2D": ([3, 4], 3, [0, 1]), "dL_dconic": ([5, 6, 7], 4, [0, 1, 3]),
@@ -140,3 +141,49 @@ def test_pixel_check_accepts_admissible_blends_and_nothing_else(orc):
     # a wide margin makes many decisions fragile: the trees grow, the verdict on the oracle's own result does not change
     st4, leaves4 = orc.check_pixels(r32, out32, fT, nc, alpha_margin=0.05, T_margin=0.05)
     assert not st4.any()
+
+
+def test_pixel_check_exponent_conditioning(orc):
+    """exp_cond of orc.check_pixels: one big needle splat seen far along its long axis — the three products of its exponent cancel by
+    three orders of magnitude — blended over a black background by an independent numpy pixel loop that evaluates the SAME exponent
+    in a different fp32 order (Horner form with the conic pre-scaled, what a GPU kernel would do).  The two fp32 orders differ by more
+    than 1e-4 relative in alpha at some pixels: refused without the term, admissible with exp_cond = 4, and an error eight times
+    the conditioning bound is refused with it."""
+    f = np.float32
+    W = H = 48
+    cam = gs.camera.Camera((0.0, 0.0, 10.0), (0.0, 0.0, 0.0), 60.0)
+    views = gs.camera.train_views([cam], W, H)
+    vp = view_parts(views[1])     # the black pass
+    s = dict(loc=np.array([9.0, 6.0, 0.0], f), scale=np.array([6.0, 0.05, 0.05], f), rot=np.array([0.9239, 0.0, 0.0, 0.3827], f),
+             opac=np.array([0.9], f), sh=np.array([1.0, 0.5, 0.2], f))
+    r = orc.Rasterizer(f)
+    out, R = r.forward(0, 1, vp["bg"], W, H, s["loc"], s["sh"], s["opac"], s["scale"], 1.0, s["rot"], vp["view"], vp["proj"], vp["campos"], vp["tanx"], vp["tany"])
+    assert R > 0
+    m2, co, rgb = r.get("means2D").reshape(-1, 2)[0], r.get("conic_opacity").reshape(-1, 4)[0], r.get("rgb").reshape(-1, 3)[0]
+    fT, last = r.get("final_T"), r.get("n_contrib")
+    ys, xs = np.mgrid[0:H, 0:W]
+    dx, dy = (m2[0] - xs.astype(f)).astype(f), (m2[1] - ys.astype(f)).astype(f)
+    power = (f(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy).astype(f)            # the reference's order
+    a2, b2, c2 = f(-0.5) * co[0], -co[1], f(-0.5) * co[2]
+    other = (dy * (dy * c2) + dx * (dy * b2 + dx * a2)).astype(f)                                     # another fp32 order of the same polynomial
+    mag = 0.5 * (abs(co[0]) * dx * dx + abs(co[2]) * dy * dy) + np.abs(co[1] * dx * dy)
+    blended = (last.reshape(H, W) == 1)
+    assert blended.sum() > 50 and (mag[blended] / np.abs(power[blended])).max() > 300       # the cancellation this test is about
+    def image(pw):
+        alpha = np.minimum(f(0.99), co[3] * np.exp(pw, dtype=f)).astype(f)
+        col = np.zeros((3, H, W), f)
+        T = np.ones((H, W), f)
+        for c in range(3):
+            col[c][blended] = (rgb[c] * alpha * f(1.0))[blended]
+        T[blended] = (f(1.0) - alpha)[blended]
+        return col, T
+    col, T = image(other)
+    rel = np.abs(col[0] - out.reshape(3, H, W)[0])[blended] / np.maximum(out.reshape(3, H, W)[0][blended], 1e-3)
+    assert rel.max() > 1e-4, rel.max()          # the two orders really are further apart than the plain bar
+    st0, _ = orc.check_pixels(r, col, T, last, alpha_margin=0.0, T_margin=0.0)
+    st4, _ = orc.check_pixels(r, col, T, last, alpha_margin=0.0, T_margin=0.0, exp_cond=4.0)
+    assert (st0 == 2).sum() > 0 and (st4 != 0).sum() == 0, ((st0 == 2).sum(), (st4 != 0).sum())
+    # an error of 32 x 2^-24 x magnitude in the exponent is outside what exp_cond = 4 admits
+    col, T = image((power.astype(np.float64) + 32.0 * 2.0 ** -24 * mag).astype(f))
+    st, _ = orc.check_pixels(r, col, T, last, alpha_margin=0.0, T_margin=0.0, exp_cond=4.0)
+    assert (st == 2).sum() > 0

@@ -111,7 +111,7 @@ def assert_close_rel(name, got, want, rtol=1e-4, floor=None, max_bad_frac=0.0):
         raise AssertionError(f"{name}: {bad.sum()}/{bad.size} outside rtol={rtol} (worst idx {i}: got {got[i]!r} want {want[i]!r}, scale {scale!r})")
 
 
-def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4, chain_noise_trials=0):
+def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4, chain_noise_trials=0, cond_kappa=0.0, images=None):
     """What the averaged gradients of one iteration may differ from the oracle's by, per entry, with every part of it
     accounted for — and the oracle's averaged gradients themselves (one forward + backward per pass serves both).
     For every pass the oracle reports, per splat and pixel-stage sum q, sum|term| of the fp32 summation
@@ -129,6 +129,13 @@ def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4, 
     the sums are perturbed by 2^-17 relative (far inside their own 1e-4 budget), the chain's exactly linear response chain(delta) is
     taken out, and what remains — chain(sums + delta) - chain(sums) - chain(delta), largest of that many trials — is the noise; the
     budget then also holds 4 x it ("noise" in the result).  The fixed-size parity cases (near-isotropic splats) run WITHOUT this term.
+    cond_kappa > 0 (same sweep): the nine sums themselves are ill-conditioned where big splats are seen far along their long axis — the
+    exponent, dG/dmean and dL/dalpha subtract products orders of magnitude above their difference — and the budget of the sums gains
+    cond_kappa x 2^-24 x cond9, the oracle's first-order bound on what that costs any fp32 evaluation order (gs_oracle.cpp, pixel_cond).
+    images (same sweep): per pass, the image the loss is formed from instead of the oracle's own — the implementation's.  The loss
+    truth / 255 - render is a difference whose relative sensitivity to the render has no bound where the two are close, so where the
+    forward images differ by more than rounding (needle splats: pixel_run's exp_cond) the backward is compared on the SAME dL/dpixel
+    and the images are compared by the pixel check; the fixed cases leave this None and compare end to end.
     Returns {array: {"budget": with flips, "sumabs": sum|term| carried through the chain, without the 1e-4 and flips,
     "want": the oracle's averaged gradient — accumulateGradients restated in fp32 numpy, bit-identical to orc.train_views
     (tests/test_gpu_trainer.py::test_step_budget_restates_accumulate_gradients)}, "num_rendered": [per pass]}."""
@@ -147,8 +154,8 @@ def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4, 
         vp = view_parts(views40[v])
         r, img, R = oracle_forward(orc, s, D, M, vp, W, H)
         num_rendered.append(R)
-        dpix = orc.image_int_to_loss(truths[v], img, W, H)
-        og = r.backward(dpix, want_abs=True, flip_margin=flip_margin)
+        dpix = orc.image_int_to_loss(truths[v], img if images is None else np.asarray(images[v], np.float32).reshape(-1), W, H)
+        og = r.backward(dpix, want_abs=True, flip_margin=flip_margin, want_cond=cond_kappa > 0)
         # accumulateGradients, src/Trainer.cu:47-77 (same fp32 operations in the same order as oracle/gs_oracle.cpp)
         gm = og["dL_dmean3D"].reshape(P, 3)
         out["var"]["want"][:, 0] += np.sqrt((gm[:, 0] * gm[:, 0] + gm[:, 1] * gm[:, 1]) + gm[:, 2] * gm[:, 2]) / S
@@ -156,7 +163,7 @@ def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4, 
             out[k]["want"] += og[n].reshape(P, st) / S
         out["opac"]["want"][:, 0] += og["dL_dopacity"] / S
         abs9 = og["abs9"].astype(f32)
-        tol9 = (1e-4 * og["abs9"] + og["flip9"]).astype(f32)
+        tol9 = (1e-4 * og["abs9"] + og["flip9"] + (cond_kappa * 2.0 ** -24 * og["cond9"] if cond_kappa > 0 else 0.0)).astype(f32)
         loc_b, loc_a = np.zeros((P, 3), f32), np.zeros((P, 3), f32)
         for q in range(8):   # (sum 8, dL_dopacity, does not enter the chain)
             unit = np.zeros((P, 9), f32); unit[:, q] = 1.0
