@@ -27,7 +27,7 @@ CASES = [
 ]
 
 
-def _check_forward(orc, s, D, M, vp, W, H, mod=1.0, min_solid=0.99, check_pixels=True, T_margin=1e-4, exp_cond=0.0):
+def _check_forward(orc, s, D, M, vp, W, H, mod=1.0, min_solid=0.99, check_pixels=True, T_margin=1e-4, exp_cond=0.0, quiet=False):
     sr = SeamRaster()
     out, R = sr.forward(s, D, M, vp, W, H, mod)
     r, oout, oR = oracle_forward(orc, s, D, M, vp, W, H, mod)
@@ -70,8 +70,9 @@ def _check_forward(orc, s, D, M, vp, W, H, mod=1.0, min_solid=0.99, check_pixels
     fT = sr.field("image", "final_T", np.float32)
     status, leaves = orc.check_pixels(r, out, fT, ncon, alpha_margin=1e-4, T_margin=T_margin, rtol=1e-4, floor_T=1e-4, floor_C=1e-3, exp_cond=exp_cond)
     n_other, n_none, n_open = int((status == 1).sum()), int((status == 2).sum()), int((status == 3).sum())
-    print(f"pixels {W}x{H}: {status.size - n_other - n_none - n_open} equal the oracle's blend, {n_other} an admissible blend with a flipped "
-          f"threshold decision (T margin {T_margin:g}), {n_none} NO admissible blend, {n_open} undecided; largest decision tree {int(leaves.max())} blends")
+    if not quiet:
+        print(f"pixels {W}x{H}: {status.size - n_other - n_none - n_open} equal the oracle's blend, {n_other} an admissible blend with a flipped "
+              f"threshold decision (T margin {T_margin:g}), {n_none} NO admissible blend, {n_open} undecided; largest decision tree {int(leaves.max())} blends")
     assert n_none == 0 and n_open == 0, (n_none, n_open, np.flatnonzero(status >= 2)[:8])
     assert n_other <= (1.0 - min_solid) * status.size, (n_other, status.size)   # flipped decisions stay the exception
     return sr, r, out, oout

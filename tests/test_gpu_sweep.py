@@ -104,7 +104,7 @@ def test_random_scene_sweep(orc, seed):
                                      x["dL_dconic"].reshape(P, 4)[:, [0, 1, 3]], x["dL_dopacity"].reshape(P, 1)], axis=1).astype(f32)
     for v in range(2 * n_cams):
         vp = view_parts(views[v])
-        sr, r, gimg, img = _check_forward(orc, s, s["D"], M, vp, W, H, min_solid=0.9, T_margin=flip_margin, exp_cond=KAPPA)
+        sr, r, gimg, img = _check_forward(orc, s, s["D"], M, vp, W, H, min_solid=0.9, T_margin=flip_margin, exp_cond=KAPPA, quiet=True)
         gpu_images.append(np.ascontiguousarray(gimg, f32).reshape(-1))
         dpix = orc.image_int_to_loss((fw + fb)[v], gpu_images[v], W, H)
         og = r.backward(dpix, want_abs=True, flip_margin=flip_margin, want_cond=True)
