@@ -1312,11 +1312,13 @@ extern "C" int gs_trainer_render(gs_trainer* t, uint32_t* fb, int fb_on_device, 
 // image kernels as entry points
 // =============================================================================================
 extern "C" int gs_image_float_to_int(const float* src, uint32_t* fb, int w, int h) {
+    if (!src || !fb || w <= 0 || h <= 0) { set_error("gs_image_float_to_int: NULL image or empty size (%d x %d)", w, h); return GS_ERR_INVALID_ARGUMENT; }
     GS_TRY(launch_image_float_to_int(src, fb, w, h, 0));
     GS_HIP(hipDeviceSynchronize());
     return GS_OK;
 }
 extern "C" int gs_image_int_to_loss(const uint32_t* truth, const float* rast, float* loss, int w, int h) {
+    if (!truth || !rast || !loss || w <= 0 || h <= 0) { set_error("gs_image_int_to_loss: NULL image or empty size (%d x %d)", w, h); return GS_ERR_INVALID_ARGUMENT; }
     GS_TRY(launch_image_int_to_loss(truth, rast, loss, w, h, 0));
     GS_HIP(hipDeviceSynchronize());
     return GS_OK;

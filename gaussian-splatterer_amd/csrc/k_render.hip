@@ -147,12 +147,17 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
 #endif
             // the backward of the same camera walks the same lists against the same blocks: it reuses this ballot
             if (hm && lane == 0) hm[(size_t)((base + sub) >> 6) * 4 + wave] = mask;
+            // The pixel's last contributor is recorded as the entry's BYTE OFFSET in the staging arrays — the register that already
+            // holds the LDS address of the three reads — and turned into a list position once per 64 entries: a position formed on
+            // the scalar unit would cost a v_mov per hit to reach the select (v_cndmask takes one scalar operand, the mask).
+            uint32_t last_off = 0xffffffffu;
             while (mask) {
                 const int k = __builtin_ctzll(mask);
                 asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(k));  // one SALU instruction instead of the add / addc / and of mask &= mask - 1
-                const int jj = sub + k;
-                const float4 A = st.A[jj], B = st.B[jj];
-                const float cb = st.C[jj].x;
+                const uint32_t off = (uint32_t)(sub + k) * 16u;
+                const char* const rec = reinterpret_cast<const char*>(&st) + off;
+                const float4 A = *reinterpret_cast<const float4*>(rec), B = *reinterpret_cast<const float4*>(rec + sizeof(st.A));
+                const float cb = *reinterpret_cast<const float*>(rec + sizeof(st.A) + sizeof(st.B));
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power = dx * (A.z * dx + A.w * dy) + B.x * dy * dy;  // log2 of the Gaussian weight
                 float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(power));
@@ -163,11 +168,12 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
                 const float w = alpha * (go ? Tw : 0.0f);
                 Tw = go ? test_T : -fabsf(Tw);
                 C0 += B.z * w; C1 += B.w * w; C2 += cb * w;
-                last = (go & valid) ? (uint32_t)(base + jj + 1) : last;
+                last_off = (go & valid) ? off : last_off;
 #ifdef GS_DIAG_COUNT_ACTIVE
                 diag_hits++; diag_active += (unsigned long long)__popcll(__ballot(go & valid));
 #endif
             }
+            last = last_off != 0xffffffffu ? (uint32_t)base + (last_off >> 4) + 1u : last;
         }
     }
 #ifdef GS_DIAG_COUNT_ACTIVE

@@ -53,19 +53,30 @@ def wild_rig(rng):
     return gs.camera.get_cameras_project(pr)
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(80))
 def test_random_scene_sweep(orc, seed):
     from test_gpu_raster import _check_forward
     from test_gpu_trainer import _download, _read_grads
     rng = np.random.default_rng(0x5EED5EED + seed)
-    big = seed >= 48          # the last sixteen scenes: 6-20 thousand splats, images up to 420 px
+    big = 48 <= seed < 64     # sixteen scenes with 6-20 thousand splats and images up to 420 px
+    tiny = seed >= 64         # sixteen scenes on images of 1 ... 20 pixels a side (one partial tile, single rows and columns)
     s, kind = wild_scene(rng, big)
     t, _ = wild_scene(rng)
     P, M = s["count"], s["M"]
     W, H = (int(rng.integers(17, 210)), int(rng.integers(17, 210))) if not big else (int(rng.integers(200, 420)), int(rng.integers(200, 420)))
+    if tiny:
+        W, H = int(rng.integers(1, 21)), int(rng.integers(1, 21))
     cams = wild_rig(rng)
     n_cams = len(cams)
     views = gs.camera.train_views(cams, W, H)
+    # pass lists the reference's white / black scheme does not produce (gs_trainer_set_views takes any): every fourth scene has random
+    # backgrounds on all passes; every fourth has its second half on cameras of another field of view, so that NO two passes share a
+    # camera (the kernels' unpaired form); every fourth both
+    if seed % 4 in (1, 3):
+        views[:, 37:40] = rng.uniform(0.0, 1.0, (2 * n_cams, 3)).astype(np.float32)
+    if seed % 4 in (2, 3):
+        other = [gs.camera.Camera(c.location, (0, 0, 0), c.fovDegY + 5.0) for c in cams]
+        views[n_cams:, :37] = gs.camera.train_views(other, W, H)[n_cams:, :37]
     if t["M"] != M:       # the truth set only has to be an image: re-draw its colours at this scene's SH size
         t["sh"] = np.ascontiguousarray(rng.uniform(-1.0, 1.0, (t["count"], M, 3)), np.float32).reshape(-1)
         t["M"], t["D"] = M, s["D"]
@@ -79,7 +90,7 @@ def test_random_scene_sweep(orc, seed):
     host.shDegree = s["D"]
     tr = gs.Trainer(W, H)
     tr.model = gs.ModelSplatsDevice(host)
-    tr.captureTruths(cams, fw, fb)
+    tr.captureTruths(cams, fw, fb, view_blocks=views)
     proj = gs.Project()
     st = tr.accumulate(stats=True)
     flip_margin = 1e-4 if st.max_tile_list <= 1024 else 1e-3
@@ -150,7 +161,11 @@ def test_random_scene_sweep(orc, seed):
         n_bad, worst = unexplained("avg_" + k + " (fused pair)", gf[k], bud[k]["want"], bud[k]["budget"], stride[k])
         worst_all = max(worst_all, worst)
         assert n_bad == 0, (seed, kind, k, n_bad, worst)
-    assert not gf["var"].any()
+    if seed % 4 in (2, 3):     # no two passes share a camera: the step runs the per-pass form, which produces `var` as well
+        n_bad, worst = unexplained("avg_var (unpaired step)", gf["var"], bud["var"]["want"], bud["var"]["budget"], 1)
+        assert n_bad == 0, (seed, kind, "var", n_bad, worst)
+    else:                      # one backward per camera on the summed residuals: `var` has no reader on such a step and is zero
+        assert not gf["var"].any()
     # a densify / prune step (src/Trainer.cu:433-542) on the same scene, thresholds set so that split, clone and prune all find
     # candidates among these splats: bit for bit the oracle's restatement, given the GPU's own gradients
     import ctypes as C
@@ -185,7 +200,7 @@ def test_random_scene_sweep(orc, seed):
     # reference's tan_fovx quirk: RGBA8 equal to the oracle's, a last-place step allowed where the float sits on a rounding boundary
     import math
     tr.model = gs.ModelSplatsDevice(host)
-    rw, rh, mod = int(rng.integers(9, 300)), int(rng.integers(9, 300)), float(rng.uniform(0.3, 2.5))
+    rw, rh, mod = int(rng.integers(1, 300)), int(rng.integers(1, 300)), float(rng.uniform(0.3, 2.5))
     cam = cams[int(rng.integers(0, n_cams))]
     fbuf = tr.render(rw, rh, mod, cam)
     blk = gs.camera.view_block(cam, rw, rh, white=False)
@@ -196,7 +211,7 @@ def test_random_scene_sweep(orc, seed):
     wantb = orc.image_float_to_int(rimg, rw, rh).reshape(rh, rw)
     shifts = np.arange(0, 32, 8)[:, None, None]
     diff = np.abs(((fbuf >> shifts) & 0xFF).astype(int) - ((wantb >> shifts) & 0xFF).astype(int))
-    assert diff.max() <= 1 and (diff > 0).mean() < 1e-2, (seed, "render", rw, rh, mod, int(diff.max()), float((diff > 0).mean()))
+    assert diff.max() <= 1 and (diff > 0).sum() <= max(2, 1e-2 * diff.size), (seed, "render", rw, rh, mod, int(diff.max()), float((diff > 0).mean()))
     print(f"[sweep {seed}: {kind}, {P} splats, M={M}, {2 * n_cams} passes @{W}x{H}] {st.num_rendered} list entries, longest tile list "
           f"{st.max_tile_list}: zero unexplained entries in both forms, worst error/budget {worst_all:.2f}; densify {P} -> {n2} splats bit-exact; render {rw}x{rh} x{mod:.2f}: {int((diff > 0).sum())} bytes one step off; chain noise allowance up to {noise_share:.2g} x the sums' budget (dL_dscale)")
     tr.close()

@@ -932,3 +932,25 @@ def test_any_sort_grids_give_the_same_lists(small_first, mid_grid, W):
             assert np.array_equal(a[3][k].view(np.uint32), b[3][k].view(np.uint32)), k
     for k in ("loc", "sh", "scale", "opac", "rot"):
         assert np.array_equal(res[0][2][k].view(np.uint32), res[1][2][k].view(np.uint32)), k
+
+
+def test_c_abi_refuses_bad_arguments():
+    """Every entry point of include/gsplat.h with a wrong argument (NULL handles, NULL outputs, empty or negative sizes, ranks outside
+    the world, unknown option names, a step without model or truth ...): a non-zero gs_status and a message, never a signal — and the
+    library works on afterwards.  The list lives in tools/abi_fuzz.py, which runs each case in a process of its own; its first run
+    found gs_image_float_to_int / gs_image_int_to_loss launching on NULL images (a GPU fault), now argument errors."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import abi_fuzz
+    fx = abi_fuzz.fixtures()
+    all_cases = abi_fuzz.cases()
+    assert len(all_cases) >= 80
+    for name, fn in all_cases:
+        status = fn(fx)
+        assert status != 0, name
+        assert (fx["L"].gs_last_error() or b"") != b"", name
+    st = fx["tr"].train(gs.Project(), densify=False, stats=True)     # the trainer of the fixtures still steps
+    assert st.views == 2 and np.isfinite(st.loss)
+    for t in fx["keep"][:2]:
+        t.close()
