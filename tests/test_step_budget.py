@@ -39,3 +39,65 @@ def test_chain_matrix_zero_blocks(orc):
             assert not col["dL_dscale"].any() and not col["dL_drot"].any()
         if q == 8:
             assert not col["dL_dmean3D"].any()
+
+
+def test_conditioning_terms_of_the_sweep_on_the_cpu(orc):
+    """The three budget terms tests/test_gpu_sweep.py adds, exercised without a GPU on one of its scenes (seed 53: 20 000
+    splats, scales over two decades).  The fp64 oracle stands in for "another implementation": against it the fp32 oracle's nine sums
+    leave the plain budget 1e-4 sum|term| + flips by up to 75 x — a needle splat seen along its axis — and the conditioning bound cond9
+    (gs_oracle.cpp, pixel_cond) explains that entry.  step_budget's options (chain noise, cond_kappa, images) only ever widen a budget."""
+    import gsplat_amd as gs
+    from test_gpu_sweep import KAPPA, wild_rig, wild_scene
+    from util import step_budget, view_parts
+    rng = np.random.default_rng(0x5EED5EED + 53)
+    s, kind = wild_scene(rng, big=True)
+    wild_scene(rng)
+    P, M = s["count"], s["M"]
+    W, H = int(rng.integers(200, 420)), int(rng.integers(200, 420))
+    cams = wild_rig(rng)
+    views = gs.camera.train_views(cams, W, H)
+    vp = view_parts(views[0])
+
+    def run(dt):
+        r = orc.Rasterizer(dt)
+        c = lambda a: np.asarray(a, dt)
+        r.forward(s["D"], M, c(vp["bg"]), W, H, c(s["loc"]), c(s["sh"]), c(s["opac"]), c(s["scale"]), 1.0, c(s["rot"]), c(vp["view"]), c(vp["proj"]),
+                  c(vp["campos"]), vp["tanx"], vp["tany"])
+        return r
+    r32, r64 = run(np.float32), run(np.float64)
+    dpix = np.random.default_rng(5).uniform(-1, 1, 3 * W * H).astype(np.float32)
+    g32 = r32.backward(dpix, want_abs=True, flip_margin=1e-4, want_cond=True)
+    g64 = r64.backward(dpix.astype(np.float64))
+    sums = lambda x: np.concatenate([x["dL_dcolor"].reshape(P, 3), x["dL_dmean2D"].reshape(P, 3)[:, :2], x["dL_dconic"].reshape(P, 4)[:, [0, 1, 3]],
+                                     x["dL_dopacity"].reshape(P, 1)], axis=1).astype(np.float64)
+    assert (g32["cond9"] >= 0).all() and np.isfinite(g32["cond9"]).all()
+    plain = 1e-4 * g32["abs9"] + g32["flip9"]
+    d = np.abs(sums(g32) - sums(g64))
+    worst = np.unravel_index(np.argmax(np.where(g32["abs9"] > 1e-6, d / (plain + 1e-300), 0.0)), d.shape)
+    assert d[worst] > 20 * plain[worst], (worst, d[worst] / plain[worst])                      # far outside the plain budget ...
+    assert d[worst] <= plain[worst] + KAPPA * 2.0 ** -24 * g32["cond9"][worst], worst          # ... and inside it with the conditioning bound
+    n_plain = int((d > plain + 1e-30).sum())
+    n_cond = int((d > plain + KAPPA * 2.0 ** -24 * g32["cond9"] + 1e-30).sum())
+    assert n_cond < n_plain
+    # step_budget: every option widens, none narrows; `images` = the oracle's own images reproduces the default
+    small = dict(s)
+    keep = 600
+    for k, n in (("loc", 3), ("sh", 3 * M), ("scale", 3), ("opac", 1), ("rot", 4)):
+        small[k] = s[k][:keep * n].copy()
+    small["count"] = keep
+    Ws, Hs = 96, 80
+    v2 = gs.camera.train_views(cams[:1], Ws, Hs)
+    truths = np.zeros((2, Ws * Hs), np.uint32)
+    base = step_budget(orc, small, s["D"], M, Ws, Hs, v2, truths, 2.0)
+    wide = step_budget(orc, small, s["D"], M, Ws, Hs, v2, truths, 2.0, chain_noise_trials=4, cond_kappa=KAPPA)
+    imgs = []
+    for v in range(2):
+        p = view_parts(v2[v])
+        out, _ = orc.Rasterizer(np.float32).forward(s["D"], M, p["bg"], Ws, Hs, small["loc"], small["sh"], small["opac"], small["scale"], 1.0, small["rot"],
+                                                    p["view"], p["proj"], p["campos"], p["tanx"], p["tany"])
+        imgs.append(out)
+    same = step_budget(orc, small, s["D"], M, Ws, Hs, v2, truths, 2.0, images=imgs)
+    for k in ("loc", "sh", "scale", "opac", "rot", "var"):
+        assert np.array_equal(base[k]["want"], wide[k]["want"]) and np.array_equal(base[k]["want"], same[k]["want"])
+        assert (wide[k]["budget"] >= base[k]["budget"] * (1 - 1e-6)).all() and np.array_equal(same[k]["budget"], base[k]["budget"])
+    assert (wide["scale"]["noise"] > 0).any()
