@@ -415,7 +415,8 @@ inline void pixel_backward(const ViewState<R>& g, uint32_t beg, uint32_t end, R 
 //     along its long axis): ANY fp32 evaluation order, the reference's included, carries ~m ulps of relative error in G = exp(power) and
 //     in alpha; through T = prod(1 - alpha) and the colour recurrence that error reaches the terms of every other entry of the pixel;
 //   * dG/dmean = -G (a dx + b dy), -G (c dy + b dx): the two products cancel along the same axis;
-//   * dL/dalpha = T sum_c (colour_c - accum_c) dL/dpixel_c - T_final / (1 - alpha) (bg . dL/dpixel).
+//   * dL/dalpha = T sum_c (colour_c - accum_c) dL/dpixel_c - T_final / (1 - alpha) (bg . dL/dpixel);
+//   * and T itself, a product of as many factors as the pixel blends entries: one ulp apiece.
 // An implementation that applies per-splat constants after summing over pixels (a . sum(u dx) + b . sum(u dy) instead of
 // sum(u (a dx + b dy))) has the same bound with a different draw, which 1e-4 of sum|term| — terms AFTER the cancellation — cannot
 // see.  emit(k, q, c): |error of term q of entry k| <~ c x 2^-24; the tests allow a small multiple of it (cond9).
@@ -446,7 +447,11 @@ inline void pixel_cond(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixf
     std::vector<double> front(n, 0.0);
     double run = 0.0;
     for (size_t j = n; j-- > 0;) { front[j] = run; run += ent[j].rho * ent[j].alpha / (1.0 - ent[j].alpha); }
-    const double front_all = run;
+    // ... plus one ulp per factor: T is a running product of n factors (the forward multiplies front to back, a backward that starts
+    // from T_final divides back to front), so the T any entry sees carries up to n ulps whatever the order — a heap of 12 000 faint
+    // splats on one tile moved every sum of a splat blended there by 3.8e-4 of its size
+    for (size_t j = 0; j < n; j++) front[j] += (double)n;
+    const double front_all = run + (double)n;
     double Tt = (double)T_final, accum[3] = { 0, 0, 0 }, dacc[3] = { 0, 0, 0 }, last_col[3] = { 0, 0, 0 }, last_alpha = 0, last_rho = 0;
     double bg_dot = 0;
     for (int c = 0; c < 3; c++) bg_dot += (double)bg[c] * (double)dpx[c];
@@ -795,6 +800,10 @@ inline bool pixel_run(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx
         }
     }
     leaf.tolT *= Tt;
+    // one ulp per factor of the running product T (and of the weights alpha T the colour is made of)
+    const R per_factor = R(exp_cond) * R(5.9604644775390625e-08) * R(terms.size());
+    leaf.tolT += per_factor * Tt;
+    for (int c = 0; c < 3; c++) leaf.tolC[c] += per_factor * C[c];
     return true;
 }
 
