@@ -89,6 +89,8 @@ template <class R> struct ViewState {
     std::vector<R> final_T;
     std::vector<uint32_t> n_contrib;
     std::vector<float> margin;  // per-pixel fragility: min relative distance to a discrete threshold
+    std::vector<float> pmargin; // per-pixel: min over its pairs of |power| / (2^-24 m), m = the magnitudes the exponent's products cancel from: how
+                                // many ulps of its own conditioning the `power > 0: skip` decision of the most fragile pair is away from flipping
     std::vector<float> splat_margin;  // per-splat fragility: min margin over the pixels the splat is blended at
     int R_total = 0;
 };
@@ -250,11 +252,18 @@ template <class R> void bin_and_sort(ViewState<R>& g) {
     }
 }
 
+// |power| in units of the exponent's own conditioning, 2^-24 (|a| dx^2 / 2 + |c| dy^2 / 2 + |b dx dy|): below a few of them the sign of the
+// computed power — the `power > 0: skip` decision — belongs to the evaluation order, not to the scene (pixel_run, PixelFlip kind 3).
+template <class R> inline float power_ulps_from_zero(const R* co, R dx, R dy, R power) {
+    const double m = 0.5 * (std::fabs((double)co[0]) * dx * dx + std::fabs((double)co[2]) * dy * dy) + std::fabs((double)co[1] * dx * dy);
+    return m > 0.0 ? (float)std::min(1e30, std::fabs((double)power) / (5.9604644775390625e-08 * m)) : 1e30f;
+}
+
 // A.6 — front-to-back alpha compositing, one pixel at a time, integer pixel centres.
 template <class R> void render_forward(ViewState<R>& g, const R* bg, R* out_color) {
     const int W = g.W, H = g.H;
     const size_t N = (size_t)W * H;
-    g.final_T.assign(N, 0); g.n_contrib.assign(N, 0); g.margin.assign(N, 1.0f);
+    g.final_T.assign(N, 0); g.n_contrib.assign(N, 0); g.margin.assign(N, 1.0f); g.pmargin.assign(N, 1e30f);
     g.splat_margin.assign(g.P, 1.0f);
     // lock-free min on non-negative floats (their bit patterns order like unsigned integers); tiles run in parallel
     auto splat_min = [&](uint32_t id, float m) {
@@ -273,13 +282,14 @@ template <class R> void render_forward(ViewState<R>& g, const R* bg, R* out_colo
                 const R pixfx = (R)px, pixfy = (R)py;
                 R Tt = R(1.0), C[3] = { 0, 0, 0 };
                 uint32_t contributor = 0, last = 0;
-                float marg = 1.0f;
+                float marg = 1.0f, pmarg = 1e30f;
                 for (uint32_t k = beg; k < end; k++) {
                     contributor++;
                     const uint32_t id = g.point_list[k];
                     const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
                     const R* co = &g.conic_opacity[4 * (size_t)id];
                     const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    pmarg = std::min(pmarg, power_ulps_from_zero<R>(co, dx, dy, power));
                     if (power > R(0.0)) continue;
                     const R alpha = std::min(R(0.99), co[3] * std::exp(power));
                     const float ma = (float)(std::fabs(alpha - R(1.0 / 255.0)) * R(255.0));
@@ -294,7 +304,7 @@ template <class R> void render_forward(ViewState<R>& g, const R* bg, R* out_colo
                     last = contributor;
                 }
                 const size_t pix = (size_t)py * W + px;
-                g.final_T[pix] = Tt; g.n_contrib[pix] = last; g.margin[pix] = marg;
+                g.final_T[pix] = Tt; g.n_contrib[pix] = last; g.margin[pix] = marg; g.pmargin[pix] = pmarg;
                 // A flipped decision at this pixel moves T / the colour recurrence of EVERY splat blended here, not
                 // only the one that flipped: the pixel's fragility is inherited by all entries that (nearly) reach it.
                 if (marg < 1e-2f)
@@ -328,13 +338,13 @@ template <class R> struct Grads {
 // accumulates |term_flipped - term| per splat and sum: the admissible deviation of an implementation that flips
 // those pairs.  The parity tests use  tol = 1e-4 * sum|term| + flip9(margin)  and report how the count of
 // out-of-tolerance splats depends on the margin (tests/test_gpu_raster.py).
-struct PixelFlip { long k = -1; int kind = 0; };  // kind 1: alpha test of list entry k inverted, 2: T test inverted
+struct PixelFlip { long k = -1; int kind = 0; };  // kind 1: alpha test of list entry k inverted, 2: T test inverted, 3: `power > 0: skip` inverted
 
 // Forward blend of one pixel over list entries [beg, end) -> (final T, last contributor), as render_forward does,
 // with an optional forced decision.  Collects the fragile pairs when `frag` is given.
 template <class R>
 inline void pixel_forward(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx, R pixfy, PixelFlip flip, R& T_out,
-                          uint32_t& last_out, std::vector<PixelFlip>* frag, float frag_margin) {
+                          uint32_t& last_out, std::vector<PixelFlip>* frag, float frag_margin, float power_ulps = 0.0f) {
     R Tt = R(1.0);
     uint32_t contributor = 0, last = 0;
     for (uint32_t k = beg; k < end; k++) {
@@ -343,7 +353,10 @@ inline void pixel_forward(const ViewState<R>& g, uint32_t beg, uint32_t end, R p
         const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
         const R* co = &g.conic_opacity[4 * (size_t)id];
         const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-        if (power > R(0.0)) continue;
+        bool pskip = power > R(0.0);
+        if (frag && power_ulps > 0.0f && power_ulps_from_zero<R>(co, dx, dy, power) < power_ulps) frag->push_back({ (long)k, 3 });
+        if (flip.kind == 3 && flip.k == (long)k) pskip = !pskip;
+        if (pskip) continue;
         const R alpha = std::min(R(0.99), co[3] * std::exp(power));
         bool skip = alpha < R(1.0) / R(255.0);
         if (frag && (float)(std::fabs(alpha - R(1.0 / 255.0)) * R(255.0)) < frag_margin) frag->push_back({ (long)k, 1 });
@@ -375,7 +388,9 @@ inline void pixel_backward(const ViewState<R>& g, uint32_t beg, uint32_t end, R 
         const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
         const R* co = &g.conic_opacity[4 * (size_t)id];
         const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-        if (power > R(0.0)) continue;
+        bool pskip = power > R(0.0);
+        if (flip.kind == 3 && flip.k == (long)k) pskip = !pskip;
+        if (pskip) continue;
         const R G = std::exp(power);
         const R alpha = std::min(R(0.99), co[3] * G);
         bool skip = alpha < R(1.0) / R(255.0);
@@ -485,7 +500,7 @@ inline void pixel_cond(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixf
 
 template <class R>
 void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const Grads<R>& o, double* abs9, double* flip9 = nullptr,
-                     float flip_margin = 0.0f, double* cond9 = nullptr) {
+                     float flip_margin = 0.0f, double* cond9 = nullptr, float power_ulps = 0.0f) {
     const int W = g.W, H = g.H, P = g.P;
     const size_t N = (size_t)W * H;
     const size_t Rn = g.point_list.size();
@@ -512,11 +527,11 @@ void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const
                 if (cond9)
                     pixel_cond<R>(g, beg, end, pixfx, pixfy, g.final_T[pix], g.n_contrib[pix], bg, dpx, ddelx_dx, ddely_dy,
                                   [&](uint32_t k, int q, double c) { partcond[(size_t)k * 9 + q] += c; });
-                if (!flip9 || !(g.margin[pix] < flip_margin)) continue;
+                if (!flip9 || !(g.margin[pix] < flip_margin || (power_ulps > 0.0f && g.pmargin[pix] < power_ulps))) continue;
                 // this pixel holds at least one pair within flip_margin of a threshold: one re-run per such pair
                 frag.clear();
                 R Tq; uint32_t lastq;
-                pixel_forward<R>(g, beg, end, pixfx, pixfy, PixelFlip{}, Tq, lastq, &frag, flip_margin);
+                pixel_forward<R>(g, beg, end, pixfx, pixfy, PixelFlip{}, Tq, lastq, &frag, flip_margin, power_ulps);
                 if (frag.empty()) continue;
                 const size_t n = (size_t)(end - beg) * 9;
                 t0.assign(n, 0.0);
@@ -736,7 +751,7 @@ void preprocess_backward(const ViewState<R>& g, int D, int M, const R* means, co
 // T_margin, relative, of its threshold) and not in the list it stops and reports it.  Exploring both values of every
 // reported decision depth-first enumerates the admissible blends of the pixel (orc_check_pixels_f32): a foreign result
 // has to equal ONE of them — colour, final T and last contributor — instead of being excluded from the comparison.
-struct ForcedDecision { uint32_t k; int kind; bool value; };  // kind 1: skip (alpha test), 2: stop (T test)
+struct ForcedDecision { uint32_t k; int kind; bool value; };  // kind 1: skip (alpha test), 2: stop (T test), 3: skip (power > 0; only with exp_cond)
 template <class R> struct PixelLeaf { R T, C[3]; uint32_t last; R tolT, tolC[3]; };
 // returns true when the run completed (leaf filled); false when it stopped at an unforced fragile decision (*branch, with its
 // nominal value)
@@ -763,7 +778,12 @@ inline bool pixel_run(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx
         const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
         const R* co = &g.conic_opacity[4 * (size_t)id];
         const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-        if (power > R(0.0)) continue;
+        bool pskip = power > R(0.0);
+        if (!forced_value(k, 3, pskip) && exp_cond > 0.0f && power_ulps_from_zero<R>(co, dx, dy, power) < exp_cond) {
+            *branch = { k, 3, pskip };
+            return false;
+        }
+        if (pskip) continue;
         const R alpha = std::min(R(0.99), co[3] * std::exp(power));
         bool skip = alpha < R(1.0) / R(255.0);
         if (!forced_value(k, 1, skip) && (float)(std::fabs(alpha - R(1.0 / 255.0)) * R(255.0)) < alpha_margin) {
@@ -822,8 +842,8 @@ int forward_impl(State<R>* st, int P, int D, int M, const R* bg, int W, int H, c
 template <class R>
 void backward_impl(State<R>* st, int D, int M, const R* bg, const R* means, const R* shs, const R* scales, R mod,
                    const R* rots, const R* view, const R* proj, const R* campos, R tanx, R tany, const R* dL_dpix,
-                   const Grads<R>& o, double* abs9, double* flip9 = nullptr, float flip_margin = 0.0f, double* cond9 = nullptr) {
-    render_backward<R>(st->v, bg, dL_dpix, o, abs9, flip9, flip_margin, cond9);
+                   const Grads<R>& o, double* abs9, double* flip9 = nullptr, float flip_margin = 0.0f, double* cond9 = nullptr, float power_ulps = 0.0f) {
+    render_backward<R>(st->v, bg, dL_dpix, o, abs9, flip9, flip_margin, cond9, power_ulps);
     preprocess_backward<R>(st->v, D, M, means, scales, mod, rots, shs, view, proj, campos, tanx, tany, o);
 }
 
@@ -911,14 +931,15 @@ void orc_backward_f32_flip(orc_state* s, int D, int M, const float* bg, const fl
     Grads<float> o{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
     backward_impl<float>(&s->f, D, M, bg, means, shs, scales, mod, rots, view, proj, campos, tanx, tany, dL_dpix, o, abs9, flip9, flip_margin);
 }
-// The same, plus cond9[P][9]: the conditioning of every sum in units of 2^-24 (pixel_cond).
+// The same, plus cond9[P][9]: the conditioning of every sum in units of 2^-24 (pixel_cond); power_ulps > 0 adds the pairs whose power
+// lies within that many units of its own conditioning of zero to the decisions flip9 is taken over (PixelFlip kind 3).
 void orc_backward_f32_cond(orc_state* s, int D, int M, const float* bg, const float* means, const float* shs,
                            const float* scales, float mod, const float* rots, const float* view, const float* proj,
                            const float* campos, float tanx, float tany, const float* dL_dpix, float* dL_dmean2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
-                           float* dL_dsh, float* dL_dscale, float* dL_drot, double* abs9, double* flip9, float flip_margin, double* cond9) {
+                           float* dL_dsh, float* dL_dscale, float* dL_drot, double* abs9, double* flip9, float flip_margin, double* cond9, float power_ulps) {
     Grads<float> o{ dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
-    backward_impl<float>(&s->f, D, M, bg, means, shs, scales, mod, rots, view, proj, campos, tanx, tany, dL_dpix, o, abs9, flip9, flip_margin, cond9);
+    backward_impl<float>(&s->f, D, M, bg, means, shs, scales, mod, rots, view, proj, campos, tanx, tany, dL_dpix, o, abs9, flip9, flip_margin, cond9, power_ulps);
 }
 // The per-splat half of the backward alone (upstream's computeCov2DCUDA + preprocessCUDA backward)
 // on caller-supplied pixel-stage sums: sums9[P][9] = dL_dcolor(3), dL_dmean2D(2), dL_dconic x/y/w(3), dL_dopacity(1).

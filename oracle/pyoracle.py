@@ -131,12 +131,13 @@ class Rasterizer:
             raise KeyError(name)
         return buf[:n].view(dt).copy()
 
-    def backward(self, dL_dpix, want_abs=False, flip_margin=None, want_cond=False):
+    def backward(self, dL_dpix, want_abs=False, flip_margin=None, want_cond=False, power_ulps=0.0):
         """flip_margin (fp32 only): also return g["flip9"][P, 9], the admissible deviation of an implementation that
         takes the other branch at every blend decision within that relative margin of its threshold (gs_oracle.cpp,
         render_backward).  want_cond (with flip_margin): also g["cond9"][P, 9], the conditioning of every sum in units of
         2^-24 (gs_oracle.cpp, pixel_cond): what the cancellations inside the exponent, dG/dmean and dL/dalpha cost ANY fp32
-        evaluation order."""
+        evaluation order.  power_ulps > 0 (with want_cond): flip9 also covers the `power > 0: skip` decision of every pair whose power lies
+        within that many units of its own conditioning (2^-24 m) of zero."""
         a = self.args
         dt = self.dt
         P, M = self.P, a["M"]
@@ -153,7 +154,7 @@ class Rasterizer:
             if want_cond:
                 assert flip_margin is not None
                 cond9 = np.zeros(9 * P, np.float64)
-                fn, extra = lib().orc_backward_f32_cond, extra + (_p(cond9, f64p),)
+                fn, extra = lib().orc_backward_f32_cond, extra + (_p(cond9, f64p), C.c_float(power_ulps))
             fn(self.h, C.c_int(a["D"]), C.c_int(M), _p(a["bg"], f32p), _p(a["means"], f32p),
                                    _p(a["shs"], f32p), _p(a["scales"], f32p), C.c_float(a["mod"]),
                                    _p(a["rots"], f32p), _p(a["view"], f32p), _p(a["proj"], f32p),

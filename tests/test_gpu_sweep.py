@@ -130,7 +130,7 @@ def test_random_scene_sweep(orc, seed):
         sr, r, gimg, img = _check_forward(orc, s, s["D"], M, vp, W, H, min_solid=0.9, T_margin=flip_margin, exp_cond=KAPPA, quiet=True)
         gpu_images.append(np.ascontiguousarray(gimg, f32).reshape(-1))
         dpix = orc.image_int_to_loss((fw + fb)[v], gpu_images[v], W, H)
-        og = r.backward(dpix, want_abs=True, flip_margin=flip_margin, want_cond=True)
+        og = r.backward(dpix, want_abs=True, flip_margin=flip_margin, want_cond=True, power_ulps=KAPPA)
         gv = sr.backward(dpix)
         tol9 = 1e-4 * og["abs9"] + og["flip9"] + KAPPA * 2.0 ** -24 * og["cond9"] + 1e-30
         err9 = np.abs(sums(gv).astype(np.float64) - sums(og))

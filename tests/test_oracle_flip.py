@@ -187,3 +187,53 @@ def test_pixel_check_exponent_conditioning(orc):
     col, T = image((power.astype(np.float64) + 32.0 * 2.0 ** -24 * mag).astype(f))
     st, _ = orc.check_pixels(r, col, T, last, alpha_margin=0.0, T_margin=0.0, exp_cond=4.0)
     assert (st == 2).sum() > 0
+
+
+def test_power_sign_decision_on_the_ridge_of_a_needle(orc):
+    """The third discrete decision of the blend, `power > 0: skip the pair`.  On the ridge line of a needle splat thousands of pixels long
+    the quadratic form is ~1e-5 while its three products are ~100 (it takes a needle this long: the 0.3 px the projection adds to every
+    axis bounds the ratio by sigma_long^2 / 0.3): the SIGN of the computed power there belongs to the fp32 evaluation order.  With
+    exp_cond, a pair whose |power| is below that many units of its conditioning (2^-24 m) may be taken either way: an image in which
+    the most fragile such pair of the scene is decided the other way is admissible at that pixel (status 1) exactly when exp_cond
+    reaches its distance, and refused (status 2) below it; the backward's flip allowance covers the same pair (power_ulps)."""
+    f = np.float32
+    W = H = 65                                                    # odd: the origin projects onto the centre of pixel (32, 32)
+    cam = gs.camera.Camera((0.0, 0.0, 10.0), (0.0, 0.0, 0.0), 60.0)
+    vp = view_parts(gs.camera.train_views([cam], W, H)[1])     # the black pass
+    # a needle through the origin along the image diagonal: the pixels (32 + k, 32 +- k) sit ON its ridge
+    s = dict(loc=np.zeros(3, f), scale=np.array([300.0, 0.02, 0.02], f), rot=np.array([0.9238795, 0.0, 0.0, 0.3826834], f),
+             opac=np.array([0.8], f), sh=np.array([1.2, 0.4, 0.9], f))
+    r = orc.Rasterizer(f)
+    out, R = r.forward(0, 1, vp["bg"], W, H, s["loc"], s["sh"], s["opac"], s["scale"], 1.0, s["rot"], vp["view"], vp["proj"], vp["campos"], vp["tanx"], vp["tany"])
+    assert R > 0
+    m2, co, rgb = r.get("means2D").reshape(-1, 2)[0], r.get("conic_opacity").reshape(-1, 4)[0], r.get("rgb").reshape(-1, 3)[0]
+    ys, xs = np.mgrid[0:H, 0:W]
+    dx, dy = (m2[0] - xs.astype(f)).astype(f), (m2[1] - ys.astype(f)).astype(f)
+    power = (f(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy).astype(f)
+    mag = 0.5 * (abs(float(co[0])) * dx.astype(np.float64) ** 2 + abs(float(co[2])) * dy.astype(np.float64) ** 2) + np.abs(float(co[1]) * dx.astype(np.float64) * dy)
+    ulps = np.where(mag > 0, np.abs(power.astype(np.float64)) / (2.0 ** -24 * mag + 1e-300), np.inf)     # (not the centre pixel: nothing cancels there)
+    fT, last = r.get("final_T").reshape(H, W), r.get("n_contrib").reshape(H, W)
+    py, px = np.unravel_index(np.argmin(ulps), ulps.shape)
+    d = float(ulps[py, px])
+    assert d < 64.0, d                       # the scene does hold a pair whose power is a few ulps of its conditioning from zero
+    skipped = bool(power[py, px] > 0)
+    assert skipped == (last[py, px] == 0)
+    # the same image with THAT decision inverted: blended where the oracle skipped, or the other way round
+    col, T, lst = out.reshape(3, H, W).copy(), fT.copy(), last.copy()
+    if skipped:
+        alpha = min(f(0.99), co[3] * np.exp(power[py, px], dtype=f))
+        col[:, py, px] = rgb * alpha
+        T[py, px], lst[py, px] = f(1.0) - alpha, 1
+    else:
+        col[:, py, px], T[py, px], lst[py, px] = 0.0, 1.0, 0
+    below, _ = orc.check_pixels(r, col, T, lst, alpha_margin=0.0, T_margin=0.0, exp_cond=d * 0.5)
+    above, leaves = orc.check_pixels(r, col, T, lst, alpha_margin=0.0, T_margin=0.0, exp_cond=d * 2.0 + 1.0)
+    pix = py * W + px
+    assert below[pix] == 2 and above[pix] == 1 and leaves[pix] >= 2
+    assert (np.delete(above, pix) == 0).all()
+    # the backward: without power_ulps no allowance at a pixel whose only fragile decision is this one, with it there is
+    dpix = np.zeros((3, H, W), f)
+    dpix[:, py, px] = 1.0
+    g0 = r.backward(dpix.reshape(-1), want_abs=True, flip_margin=1e-6, want_cond=True, power_ulps=0.0)
+    g1 = r.backward(dpix.reshape(-1), want_abs=True, flip_margin=1e-6, want_cond=True, power_ulps=d * 2.0 + 1.0)
+    assert g0["flip9"].sum() == 0 and g1["flip9"][0, :3].min() > 0

@@ -131,7 +131,9 @@ def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4, 
     budget then also holds 4 x it ("noise" in the result).  The fixed-size parity cases (near-isotropic splats) run WITHOUT this term.
     cond_kappa > 0 (same sweep): the nine sums themselves are ill-conditioned where big splats are seen far along their long axis — the
     exponent, dG/dmean and dL/dalpha subtract products orders of magnitude above their difference — and the budget of the sums gains
-    cond_kappa x 2^-24 x cond9, the oracle's first-order bound on what that costs any fp32 evaluation order (gs_oracle.cpp, pixel_cond).
+    cond_kappa x 2^-24 x cond9, the oracle's first-order bound on what that costs any fp32 evaluation order (gs_oracle.cpp, pixel_cond);
+    the flip allowance then also covers the `power > 0: skip` decision of pairs whose power lies within cond_kappa units of its own
+    conditioning of zero (a pixel on the ridge line of a needle: the sign of the computed power belongs to the evaluation order).
     images (same sweep): per pass, the image the loss is formed from instead of the oracle's own — the implementation's.  The loss
     truth / 255 - render is a difference whose relative sensitivity to the render has no bound where the two are close, so where the
     forward images differ by more than rounding (needle splats: pixel_run's exp_cond) the backward is compared on the SAME dL/dpixel
@@ -155,7 +157,7 @@ def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4, 
         r, img, R = oracle_forward(orc, s, D, M, vp, W, H)
         num_rendered.append(R)
         dpix = orc.image_int_to_loss(truths[v], img if images is None else np.asarray(images[v], np.float32).reshape(-1), W, H)
-        og = r.backward(dpix, want_abs=True, flip_margin=flip_margin, want_cond=cond_kappa > 0)
+        og = r.backward(dpix, want_abs=True, flip_margin=flip_margin, want_cond=cond_kappa > 0, power_ulps=cond_kappa)
         # accumulateGradients, src/Trainer.cu:47-77 (same fp32 operations in the same order as oracle/gs_oracle.cpp)
         gm = og["dL_dmean3D"].reshape(P, 3)
         out["var"]["want"][:, 0] += np.sqrt((gm[:, 0] * gm[:, 0] + gm[:, 1] * gm[:, 1]) + gm[:, 2] * gm[:, 2]) / S
