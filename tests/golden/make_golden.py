@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/cfg1.npz (and seam_cases.npz, below) from the CPU oracle (oracle/gs_oracle.cpp) at BASELINE cfg1 scale:
+"""Generates tests/golden/cfg1.npz (and seam_cases.npz, budget_case.npz, below) from the CPU oracle (oracle/gs_oracle.cpp) at BASELINE cfg1 scale:
 1k random-init splats (seed 0x5EED0001), one camera, white + black pass, 256x256, truth = quantised
 oracle render of the second splat set (seed + 1000, P/2 splats).
 
@@ -95,6 +95,39 @@ def build_seam_cases():
     return out
 
 
+# The accounting quantities of the parity budget on ONE scene of the seeded sweep (tests/test_gpu_sweep.py, scene 12: 300 needle-prone
+# splats, 4 passes @184x144): sum|term|, the decision-flip allowance, the conditioning bound and the measured chain noise are what a
+# GPU result is allowed to deviate by — an edit of the oracle that moves THEM would loosen or tighten every sweep assertion silently.
+def build_budget_case():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_sweep import KAPPA, wild_rig, wild_scene
+    from util import step_budget
+    rng = np.random.default_rng(0x5EED5EED + 12)
+    s, kind = wild_scene(rng)
+    wild_scene(rng)
+    P, M = s["count"], s["M"]
+    W, H = int(rng.integers(17, 210)), int(rng.integers(17, 210))
+    cams = wild_rig(rng)
+    views = gs.camera.train_views(cams, W, H)
+    b = views[0]
+    r = orc.Rasterizer(np.float32)
+    img, R = r.forward(s["D"], M, b[37:40], W, H, s["loc"], s["sh"], s["opac"], s["scale"], 1.0, s["rot"], b[0:16], b[16:32], b[32:35], float(b[35]), float(b[36]))
+    dpix = np.random.default_rng(12).uniform(-1, 1, (3, H, W)).astype(np.float32)
+    g = r.backward(dpix, want_abs=True, flip_margin=1e-3, want_cond=True, power_ulps=KAPPA)
+    out = dict(shape=np.array([P, M, W, H, len(cams), R], np.int64), kind=kind)
+    for name in ("abs9", "flip9", "cond9"):
+        out[name + "_per_sum"] = g[name].sum(0)
+        out[name + "_head"] = g[name][:32].copy()
+    out["margin_min"] = float(r.get("margin").min())
+    truths = np.zeros((len(views), W * H), np.uint32)
+    bud = step_budget(orc, s, s["D"], M, W, H, views, truths, float(len(views)), flip_margin=1e-3, chain_noise_trials=8, cond_kappa=KAPPA)
+    for k in ("loc", "sh", "scale", "opac", "rot", "var"):
+        out["budget_" + k + "_sum"] = float(bud[k]["budget"].sum())
+        out["want_" + k + "_abs_sum"] = float(np.abs(bud[k]["want"].astype(np.float64)).sum())
+    out["noise_scale_sum"] = float(bud["scale"]["noise"].sum())
+    return out
+
+
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
     out, _ = build()
@@ -103,4 +136,7 @@ if __name__ == "__main__":
     print("wrote", path, os.path.getsize(path), "bytes")
     path = os.path.join(here, "seam_cases.npz")
     np.savez_compressed(path, **build_seam_cases())
+    print("wrote", path, os.path.getsize(path), "bytes")
+    path = os.path.join(here, "budget_case.npz")
+    np.savez_compressed(path, **build_budget_case())
     print("wrote", path, os.path.getsize(path), "bytes")
