@@ -64,11 +64,16 @@ def wild_rig(rng):
     return gs.camera.get_cameras_project(pr)
 
 
-@pytest.mark.parametrize("seed", range(88))
+# scenes 0 ... 87, and five found by running the sweep on other seed bases (GS_SWEEP_BASE; 616 scenes in all): in each of them one pixel
+# had a needle's alpha 1.3e-4 below 1/255 for the oracle and above it for the GPU — the alpha and T decisions see the exponent's
+# conditioning as well (gs_oracle.cpp, "FRAGILE").  An id of 1000 b + k is scene k of base 1000 b.
+@pytest.mark.parametrize("seed", list(range(88)) + [2055, 2056, 3050, 3055, 4056])
 def test_random_scene_sweep(orc, seed):
     from test_gpu_raster import _check_forward
     from test_gpu_trainer import _download, _read_grads
-    rng = np.random.default_rng(0x5EED5EED + seed)
+    import os
+    base, seed = seed // 1000 * 1000 + int(os.environ.get("GS_SWEEP_BASE", "0")), seed % 1000     # GS_SWEEP_BASE=1000, 2000 ...: other scenes, for hunting
+    rng = np.random.default_rng(0x5EED5EED + seed + base)
     big = 48 <= seed < 64     # sixteen scenes with 6-20 thousand splats and images up to 420 px
     tiny = 64 <= seed < 80    # sixteen scenes on images of 1 ... 20 pixels a side (one partial tile, single rows and columns)
     pile = seed >= 80         # eight heaps: tile lists of thousands of entries
@@ -227,6 +232,6 @@ def test_random_scene_sweep(orc, seed):
     shifts = np.arange(0, 32, 8)[:, None, None]
     diff = np.abs(((fbuf >> shifts) & 0xFF).astype(int) - ((wantb >> shifts) & 0xFF).astype(int))
     assert diff.max() <= 1 and (diff > 0).sum() <= max(2, 1e-2 * diff.size), (seed, "render", rw, rh, mod, int(diff.max()), float((diff > 0).mean()))
-    print(f"[sweep {seed}: {kind}, {P} splats, M={M}, {2 * n_cams} passes @{W}x{H}] {st.num_rendered} list entries, longest tile list "
+    print(f"[sweep {base + seed}: {kind}, {P} splats, M={M}, {2 * n_cams} passes @{W}x{H}] {st.num_rendered} list entries, longest tile list "
           f"{st.max_tile_list}: zero unexplained entries in both forms, worst error/budget {worst_all:.2f}; densify {P} -> {n2} splats bit-exact; render {rw}x{rh} x{mod:.2f}: {int((diff > 0).sum())} bytes one step off; chain noise allowance up to {noise_share:.2g} x the sums' budget (dL_dscale)")
     tr.close()
