@@ -455,7 +455,7 @@ inline void pixel_backward(const ViewState<R>& g, uint32_t beg, uint32_t end, R 
 // see.  emit(k, q, c): |error of term q of entry k| <~ c x 2^-24; the tests allow a small multiple of it (cond9).
 template <class R, class Emit>
 inline void pixel_cond(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx, R pixfy, R T_final, uint32_t last_contributor,
-                       const R* bg, const R dpx[3], R ddelx_dx, R ddely_dy, Emit emit) {
+                       const R* bg, const R dpx[3], R ddelx_dx, R ddely_dy, PixelFlip flip, Emit emit) {
     struct E { uint32_t k; double dx, dy, G, alpha, m, rho, a, b, c, op, col[3]; };
     std::vector<E> ent;   // back to front, as the backward visits them
     uint32_t contributor = end - beg;
@@ -466,10 +466,14 @@ inline void pixel_cond(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixf
         const R dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
         const R* co = &g.conic_opacity[4 * (size_t)id];
         const R power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-        if (power > R(0.0)) continue;
+        bool pskip = power > R(0.0);
+        if (flip.kind == 3 && flip.k == (long)k) pskip = !pskip;
+        if (pskip) continue;
         const R G = std::exp(power);
         const R alpha = std::min(R(0.99), co[3] * G);
-        if (alpha < R(1.0) / R(255.0)) continue;
+        bool skip = alpha < R(1.0) / R(255.0);
+        if (flip.kind == 1 && flip.k == (long)k) skip = !skip;
+        if (skip) continue;
         const double m = 0.5 * (std::fabs((double)co[0]) * dx * dx + std::fabs((double)co[2]) * dy * dy) + std::fabs((double)co[1] * dx * dy);
         ent.push_back({ k, (double)dx, (double)dy, (double)G, (double)alpha, m, alpha < R(0.99) ? m : 0.0, (double)co[0], (double)co[1], (double)co[2],
                         (double)co[3], { (double)g.rgb[3 * (size_t)id], (double)g.rgb[3 * (size_t)id + 1], (double)g.rgb[3 * (size_t)id + 2] } });
@@ -543,7 +547,7 @@ void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const
                                       if (abs9) partabs[(size_t)k * 9 + q] += std::fabs((double)term);
                                   });
                 if (cond9)
-                    pixel_cond<R>(g, beg, end, pixfx, pixfy, g.final_T[pix], g.n_contrib[pix], bg, dpx, ddelx_dx, ddely_dy,
+                    pixel_cond<R>(g, beg, end, pixfx, pixfy, g.final_T[pix], g.n_contrib[pix], bg, dpx, ddelx_dx, ddely_dy, PixelFlip{},
                                   [&](uint32_t k, int q, double c) { partcond[(size_t)k * 9 + q] += c; });
                 // (d < margin + ulps c  is implied by neither  d < margin  nor  d < ulps c  alone, but by  d < 2 max of the two: the
                 //  pixel is re-examined on the doubled criteria, pixel_forward then applies the exact one)
@@ -564,6 +568,13 @@ void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const
                     pixel_backward<R>(g, beg, end, pixfx, pixfy, Tf, lastf, bg, dpx, ddelx_dx, ddely_dy, f,
                                       [&](uint32_t k, int q, R term) { t1[(size_t)(k - beg) * 9 + q] = (double)term; });
                     for (size_t j = 0; j < n; j++) partflip[(size_t)beg * 9 + j] += std::fabs(t1[j] - t0[j]);
+                    // the flipped pixel's terms are fp32 sums with a conditioning of their own (a splat blended only THROUGH a flip has
+                    // nothing in the nominal bound): it joins cond9 for every term the flip moved
+                    if (cond9)
+                        pixel_cond<R>(g, beg, end, pixfx, pixfy, Tf, lastf, bg, dpx, ddelx_dx, ddely_dy, f, [&](uint32_t k, int q, double c) {
+                            const size_t j = (size_t)(k - beg) * 9 + q;
+                            if (t1[j] != t0[j]) partcond[(size_t)k * 9 + q] += c;
+                        });
                 }
             }
     }

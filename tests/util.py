@@ -165,22 +165,38 @@ def step_budget(orc, s, D, M, W, H, views40, truths, samples, flip_margin=1e-4, 
             out[k]["want"] += og[n].reshape(P, st) / S
         out["opac"]["want"][:, 0] += og["dL_dopacity"] / S
         abs9 = og["abs9"].astype(f32)
-        tol9 = (1e-4 * og["abs9"] + og["flip9"] + (cond_kappa * 2.0 ** -24 * og["cond9"] if cond_kappa > 0 else 0.0)).astype(f32)
+        # (the flipped terms are fp32 sums like the others: 1e-4 of THEM too — a splat that is blended only through a flipped decision
+        #  has sum|term| = 0 and must not be held to the oracle's flipped value exactly; found on a 100 000-splat scene of the sweep.
+        #  Their conditioning is part of cond9 for the same reason: gs_oracle.cpp, render_backward)
+        tol9 = (1e-4 * (og["abs9"] + og["flip9"]) + og["flip9"] + (cond_kappa * 2.0 ** -24 * og["cond9"] if cond_kappa > 0 else 0.0)).astype(f32)
         loc_b, loc_a = np.zeros((P, 3), f32), np.zeros((P, 3), f32)
         for q in range(8):   # (sum 8, dL_dopacity, does not enter the chain)
             unit = np.zeros((P, 9), f32); unit[:, q] = 1.0
             col = orc.chain(r, unit)
+            # A itself is an fp32 evaluation of the chain: where the chain cancels internally (needle splats) its entries are good to
+            # a few per cent only (finite differences -0.0567 against -0.0597 on unit input), and a budget |A| x tolerance inherits that.
+            # With the chain noise requested, A's own noise — same measurement, on the unit input — is added to |A| (4 x, as below).
+            a_noise = None
+            if chain_noise_trials:
+                arng = np.random.default_rng(0xA000 + 16 * v + q)
+                a_noise = {n: np.zeros(col[n].shape) for n, _ in chain_names.values()}
+                for _ in range(min(chain_noise_trials, 4)):
+                    shifted = (unit.astype(np.float64) * (1.0 + arng.uniform(-1.0, 1.0, (P, 1)) * 2.0 ** -17)).astype(f32)
+                    pert, lin = orc.chain(r, shifted), orc.chain(r, shifted - unit)
+                    for n in a_noise:
+                        np.maximum(a_noise[n], np.abs(pert[n].astype(np.float64) - col[n] - lin[n]), out=a_noise[n])
+            coef = lambda n: np.abs(col[n]) if a_noise is None else np.abs(col[n]) + 4.0 * a_noise[n]
             for k, (n, st) in chain_names.items():
                 # which sums reach which output (tests/test_step_budget.py checks the zero blocks): the SH gradient is
                 # basis x dL_dcolour (sums 0-2); scale and rotation come from the conic sums (5-7) alone
                 if (k == "sh" and q >= 3) or (k in ("scale", "rot") and q not in (5, 6, 7)):
                     continue
                 if k == "sh":   # colour sum q reaches channel q of every coefficient only (same test as the other zero blocks)
-                    A = np.abs(col[n].reshape(P, M, 3)[:, :, q])
+                    A = coef(n).reshape(P, M, 3)[:, :, q]
                     out[k]["budget"].reshape(P, M, 3)[:, :, q] += A * (tol9[:, q, None] / S)
                     out[k]["sumabs"].reshape(P, M, 3)[:, :, q] += A * (abs9[:, q, None] / S)
                     continue
-                A = np.abs(col[n].reshape(P, st))
+                A = coef(n).reshape(P, st)
                 out[k]["budget"] += A * (tol9[:, q, None] / S)
                 out[k]["sumabs"] += A * (abs9[:, q, None] / S)
                 if k == "loc":
