@@ -192,6 +192,22 @@ def test_random_scene_sweep(orc, seed):
         assert n_bad == 0, (seed, kind, "var", n_bad, worst)
     else:                      # one backward per camera on the summed residuals: `var` has no reader on such a step and is zero
         assert not gf["var"].any()
+    # three Adam iterations on the same scene: parameters bit for bit the oracle's update applied to the GPU's own gradients of each
+    # iteration (moments, bias correction, clamps) — on models whose gradients span many orders of magnitude
+    from gsplat_amd import capi as _capi
+    aproj = gs.Project(updateRule=_capi.GS_UPDATE_ADAM, lrLocation=1e-3, lrSh=2e-3, lrScale=5e-4, lrOpacity=1e-3, lrRotation=1e-3)
+    tr.model = gs.ModelSplatsDevice(host)
+    awant = {k: s[k].copy() for k in ["loc", "sh", "scale", "opac", "rot"]}
+    am, av = np.zeros((11 + 3 * M) * P, np.float32), np.zeros((11 + 3 * M) * P, np.float32)
+    for it in range(1, 4):
+        tr.train(aproj, densify=False)
+        ga = _read_grads(tr, P, M)
+        orc.apply_adam(awant["loc"], awant["sh"], awant["scale"], awant["opac"], awant["rot"], ga, am, av, it,
+                       (aproj.lrLocation, aproj.lrSh, aproj.lrScale, aproj.lrOpacity, aproj.lrRotation), aproj.paramScaleMax,
+                       aproj.adamBeta1, aproj.adamBeta2, aproj.adamEps, M)
+        got = _download(tr)
+        for k in awant:
+            assert np.array_equal(got[k].view(np.uint32), awant[k].view(np.uint32)), (seed, "adam", it, k)
     # a densify / prune step (src/Trainer.cu:433-542) on the same scene, thresholds set so that split, clone and prune all find
     # candidates among these splats: bit for bit the oracle's restatement, given the GPU's own gradients
     import ctypes as C
@@ -239,5 +255,5 @@ def test_random_scene_sweep(orc, seed):
     diff = np.abs(((fbuf >> shifts) & 0xFF).astype(int) - ((wantb >> shifts) & 0xFF).astype(int))
     assert diff.max() <= 1 and (diff > 0).sum() <= max(2, 1e-2 * diff.size), (seed, "render", rw, rh, mod, int(diff.max()), float((diff > 0).mean()))
     print(f"[sweep {base + seed}: {kind}, {P} splats, M={M}, {2 * n_cams} passes @{W}x{H}] {st.num_rendered} list entries, longest tile list "
-          f"{st.max_tile_list}: zero unexplained entries in both forms, worst error/budget {worst_all:.2f}; densify {P} -> {n2} splats bit-exact; render {rw}x{rh} x{mod:.2f}: {int((diff > 0).sum())} bytes one step off; chain noise allowance up to {noise_share:.2g} x the sums' budget (dL_dscale)")
+          f"{st.max_tile_list}: zero unexplained entries in both forms, worst error/budget {worst_all:.2f}; three Adam iterations and densify {P} -> {n2} splats bit-exact; render {rw}x{rh} x{mod:.2f}: {int((diff > 0).sum())} bytes one step off; chain noise allowance up to {noise_share:.2g} x the sums' budget (dL_dscale)")
     tr.close()
