@@ -109,9 +109,16 @@ def test_random_scene_sweep(orc, seed):
         out, _ = orc.Rasterizer(np.float32).forward(t["D"], M, vp["bg"], W, H, t["loc"], t["sh"], t["opac"], t["scale"], 1.0, t["rot"],
                                                     vp["view"], vp["proj"], vp["campos"], vp["tanx"], vp["tany"])
         (fw if v < n_cams else fb).append(orc.image_float_to_int(out, W, H))
+    # every fifth scene runs the trainer in BASELINE cfg5's fp16-SH mode (the projection reads a half-precision copy of the SH planes):
+    # with coefficients that are exact in half precision to begin with, every check below holds unchanged
+    fp16_sh = seed % 5 == 0
+    if fp16_sh:
+        s["sh"] = s["sh"].astype(np.float16).astype(np.float32)
     host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
     host.shDegree = s["D"]
     tr = gs.Trainer(W, H)
+    if fp16_sh:
+        tr.set_option("sh_fp16", 1)
     tr.model = gs.ModelSplatsDevice(host)
     tr.captureTruths(cams, fw, fb, view_blocks=views)
     proj = gs.Project()
