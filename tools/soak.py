@@ -1,50 +1,77 @@
 #!/usr/bin/env python3
-"""Soak run of the driver loop on the GPU: cfg2-sized model, truths from a hidden target model rendered by the
-product's preview path, re-captured with re-rotated camera spheres every 40 iterations, densify/prune every 50,
-Adam.  Prints loss, splat count and device memory along the way; fails on a non-finite model or a growing footprint.
-  python tools/soak.py [iterations]"""
-import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
-import numpy as np
-import gsplat_amd as gs
-from gsplat_amd import capi
+"""Soak run of the auto-train loop (src/ui/UiFrame.cpp:266-298) with the reference's default project values: the canonical grid start,
+truth images re-captured from a target splat set with re-rotated camera spheres, densify every `intervalDensify` iterations — for
+thousands of iterations, under both update rules.  Watches what a benchmark never sees: the model growing towards its capacity through
+dozens of densify steps, non-finite parameters, device memory creeping.   gpurun -- 'python tools/soak.py --iterations 6000'"""
+import argparse
 import ctypes as C
+import json
+import os
+import sys
+import time
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
-P, M, W, H = 10000, 4, 256, 256
-target = gs.synth.random_splats(6000, M, 1)
-thost = gs.ModelSplatsHost.fromVectors(target["loc"], target["sh"], target["scale"], target["opac"], target["rot"]); thost.shDegree = 1
-renderer = gs.Trainer(W, H); renderer.model = gs.ModelSplatsDevice(thost)
+import numpy as np
 
-def capture(cameras):
-    fw = [renderer.render(W, H, 1.0, c, background=(1.0, 1.0, 1.0)).reshape(-1) for c in cameras]
-    fb = [renderer.render(W, H, 1.0, c, background=(0.0, 0.0, 0.0)).reshape(-1) for c in cameras]
-    return fw, fb
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import gsplat_amd as gs  # noqa: E402
+from gsplat_amd import capi  # noqa: E402
 
-s = gs.synth.random_splats(P, M, 2)
-host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"]); host.shDegree = 1
-tr = gs.Trainer(W, H); tr.model = gs.ModelSplatsDevice(host)
-proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=2e-3, lrSh=5e-3, lrScale=5e-4, lrOpacity=5e-3, lrRotation=1e-3)
-proj.intervalCapture, proj.intervalDensify = 40, 50
-auto = gs.driver.AutoTrainer(tr, proj, capture)
 
-def mem_free():
+def free_bytes(hip):
     free, total = C.c_size_t(), C.c_size_t()
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemGetInfo(C.byref(free), C.byref(total))
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
     return free.value
 
-t0 = time.time(); free0 = None; losses = []
-for it in range(iters):
-    auto.step()
-    if it % 100 == 99:
-        st = tr.train(proj, stats=True)
-        h = gs.ModelSplatsHost.fromDevice(tr.model)
-        ok = all(np.isfinite(a[:k * h.count]).all() for a, k in ((h.locations, 3), (h.shs, 3 * M), (h.scales, 3), (h.opacities, 1), (h.rotations, 4)))
-        f = mem_free()
-        free0 = free0 or f
-        losses.append(st.loss)
-        print(f"iter {proj.iterations:5d}  splats {h.count:7d}  loss {st.loss:10.1f}  device free {f / 2**30:7.2f} GiB  finite {ok}  {time.time() - t0:6.1f} s", flush=True)
-        assert ok, "non-finite parameters"
-        assert f > free0 - (2 << 30), "device memory footprint keeps growing"
-print("soak ok", "loss first/last", losses[0], losses[-1])
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=6000)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--adam", type=int, default=1)
+    a = ap.parse_args()
+    hip = C.CDLL("libamdhip64.so")
+    W = H = a.size
+    target = gs.synth.random_splats(3000, 4, 5)
+    target["scale"] *= 3.0
+    thost = gs.ModelSplatsHost.fromVectors(target["loc"] * 0.5, target["sh"], target["scale"], target["opac"], target["rot"])
+    painter = gs.Trainer(W, H)
+    painter.model = gs.ModelSplatsDevice(thost)
+
+    def capture(cameras):
+        fw = [painter.render(W, H, 1.0, c, background=(1.0, 1.0, 1.0)).reshape(-1) for c in cameras]
+        fb = [painter.render(W, H, 1.0, c, background=(0.0, 0.0, 0.0)).reshape(-1) for c in cameras]
+        return fw, fb
+    tr = gs.Trainer(W, H)
+    tr.model = gs.ModelSplatsDevice(gs.fields.initFieldGrid())
+    p = gs.Project.initProject()            # the reference's defaults (src/Project.h): 25 + 25 cameras, capture / densify intervals
+    if a.adam:
+        p.updateRule = capi.GS_UPDATE_ADAM
+    drv = gs.driver.AutoTrainer(tr, p, capture)
+    log, t0 = [], time.time()
+    free0 = None
+    for it in range(a.iterations):
+        cap, den = drv.step()
+        if it == 50:
+            tr.synchronize(); free0 = free_bytes(hip)
+        if den or it == a.iterations - 1:
+            n = tr.model.count
+            host = gs.ModelSplatsHost.fromDevice(tr.model)
+            M = host.shCoeffs
+            finite = all(np.isfinite(x).all() for x in (host.locations[:3 * n], host.shs[:3 * M * n], host.scales[:3 * n], host.opacities[:n], host.rotations[:4 * n]))
+            log.append(dict(iteration=it, count=n, finite=bool(finite), free_MB=round(free_bytes(hip) / 2 ** 20), scale_max=float(host.scales[:3 * n].max()) if n else 0.0,
+                            opacity_range=[float(host.opacities[:n].min()), float(host.opacities[:n].max())] if n else None))
+            if not finite or n == 0:
+                break
+    tr.synchronize()
+    st = tr.train(p, densify=False, stats=True)
+    free1 = free_bytes(hip)
+    print(json.dumps(dict(iterations=p.iterations, seconds=round(time.time() - t0, 1), cameras=len(tr.truthCameras), update="adam" if a.adam else "sgd",
+                          final_count=tr.model.count, capacity=tr.model.capacity, final_loss=float(st.loss), longest_tile_list=int(st.max_tile_list),
+                          memory_grown_since_iteration_50_MB=round((free0 - free1) / 2 ** 20, 1) if free0 else None,
+                          peak_count=max(x["count"] for x in log), iteration_of_peak=max(log, key=lambda x: x["count"])["iteration"],
+                          free_MB_at_thirds=[log[len(log) // 3]["free_MB"], log[2 * len(log) // 3]["free_MB"], log[-1]["free_MB"]],
+                          densify_log_first=log[:3], densify_log_last=log[-3:], all_finite=all(x["finite"] for x in log))))
+
+
+if __name__ == "__main__":
+    main()
