@@ -1,0 +1,233 @@
+"""EIGHT ranks of the product on the one GPU, in one process: eight trainers, each on its own HIP stream and host thread, each owning the
+cameras c % 8 == rank, wired together by collective hooks that move data between the trainers' device buffers through the host
+(thread barriers + hipMemcpy) — what RCCL does between eight GPUs, with none of its machinery.  RCCL refuses more than one rank per
+device and gloo needs a process per rank (the box allows six on the GPU), so this is the only way the world-8 code paths of the
+LIBRARY — rank-dependent chunk offsets of the gather buffer, the SH rebuild over eight ranks' records, the sharded update's eight
+chunks — run before an 8-GPU node does.  All three exchanges are checked against one trainer that owns every camera:
+  * compact exchange: SH gradient planes bit for bit the single-GPU step's (no collective sums them), the twelve other planes the same
+    sums re-associated; replicas bit-identical after Adam iterations with a densify step in the middle;
+  * all-reduce and reduce-scatter / sharded update / all-gather: replicas bit-identical, next to the single-trainer run.
+The simulated all-reduce adds the ranks' buffers in rank order on the host, so every rank holds the same bits — as a ring all-reduce
+guarantees."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import gsplat_amd as gs
+from gsplat_amd import capi
+
+pytestmark = pytest.mark.gpu
+WORLD, P, M, N_CAMS, W, H = 8, 4000, 16, 16, 144, 112
+D2H, H2D, D2D = 2, 1, 3
+
+
+class HostCollectives:
+    """gs_collective_fn / gs_allreduce_fn for `world` trainers of one process.  Each hook: wait for the caller's stream (its part of the
+    buffer is then complete), meet the other ranks, move the data with synchronous copies, meet again (nobody overwrites what another
+    rank still reads)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.bar = threading.Barrier(world)
+        self.bufs = [None] * world
+        self.calls = {"all_gather": 0, "all_reduce": 0, "reduce_scatter": 0}
+        self.keep = []
+
+    def _meet(self, rank, buf, stream):
+        assert self.hip.hipStreamSynchronize(stream) == 0
+        self.bufs[rank] = buf
+        self.bar.wait()
+
+    def _copy(self, dst, src, nbytes, kind):
+        assert self.hip.hipMemcpy(dst, src, nbytes, kind) == 0
+
+    def hooks(self, rank):
+        world = self.world
+
+        def all_gather(buf, n, stream, user):        # in place: rank r's chunk is floats [r c, (r + 1) c)
+            self._meet(rank, buf, stream)
+            c = n // world
+            for r in range(world):
+                if r != rank:
+                    self._copy(buf + 4 * r * c, self.bufs[r] + 4 * r * c, 4 * c, D2D)
+            self.bar.wait()
+            if rank == 0:
+                self.calls["all_gather"] += 1
+            return 0
+
+        def summed(n):
+            acc = np.zeros(n, np.float32)
+            tmp = np.empty(n, np.float32)
+            for r in range(world):                   # rank order on every rank: the same bits everywhere
+                self._copy(tmp.ctypes.data, self.bufs[r], 4 * n, D2H)
+                with np.errstate(all="ignore"):      # the payload ends in padding floats nobody writes or reads (plane strides are multiples of 64)
+                    acc += tmp
+            return acc
+
+        def all_reduce(buf, n, stream, user):
+            self._meet(rank, buf, stream)
+            acc = summed(n)
+            self.bar.wait()
+            self._copy(buf, acc.ctypes.data, 4 * n, H2D)
+            self.bar.wait()
+            if rank == 0:
+                self.calls["all_reduce"] += 1
+            return 0
+
+        def reduce_scatter(buf, n, stream, user):    # in place: the rank's chunk receives the sum of everybody's
+            self._meet(rank, buf, stream)
+            c = n // world
+            acc = np.zeros(c, np.float32)
+            tmp = np.empty(c, np.float32)
+            for r in range(world):
+                self._copy(tmp.ctypes.data, self.bufs[r] + 4 * rank * c, 4 * c, D2H)
+                with np.errstate(all="ignore"):
+                    acc += tmp
+            self.bar.wait()
+            self._copy(buf + 4 * rank * c, acc.ctypes.data, 4 * c, H2D)
+            self.bar.wait()
+            if rank == 0:
+                self.calls["reduce_scatter"] += 1
+            return 0
+        def guarded(f):      # an exception must not cross the C boundary, and must not leave the other ranks at a barrier
+            def g(buf, n, stream, user):
+                try:
+                    return f(buf, n, stream, user)
+                except BaseException as e:      # noqa: BLE001
+                    print("collective hook of rank", rank, "failed:", repr(e), flush=True)
+                    self.bar.abort()
+                    return 1
+            return g
+        fns = {k: capi.ALLREDUCE_FN(guarded(f)) for k, f in (("all_gather", all_gather), ("all_reduce", all_reduce), ("reduce_scatter", reduce_scatter))}
+        self.keep.append(fns)
+        return fns
+
+
+def _scene():
+    s = gs.synth.random_splats(P, M, 808)
+    cams = gs.camera.get_cameras(N_CAMS)
+    rng = np.random.default_rng(8)
+    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(N_CAMS)]
+    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(N_CAMS)]
+    host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+    host.shDegree = s["D"]
+    host.capacity = P + 800
+    return s, cams, fw, fb, host
+
+
+def _grad_planes(tr):
+    ptr, n = tr.grad_buffer()
+    tr.synchronize()
+    buf = np.empty(n, np.float32)
+    capi.check(capi.lib().gs_memcpy_d2h(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n * 4))
+    planes = 12 + 3 * M
+    return buf.reshape(planes, n // planes)[:, :P].copy()
+
+
+def _model_bits(tr):
+    h = gs.ModelSplatsHost.fromDevice(tr.model)
+    n = h.count
+    return np.concatenate([h.locations[:3 * n], h.shs[:3 * M * n], h.scales[:3 * n], h.opacities[:n], h.rotations[:4 * n]])
+
+
+def _run_rank(rank, world, install, out, errors):
+    try:
+        s, cams, fw, fb, host = _scene()
+        tr = gs.Trainer(W, H)
+        tr.model = gs.ModelSplatsDevice(host)
+        tr.captureTruths(cams, fw, fb)
+        tr.shard(rank, world)
+        if install is not None:
+            install(tr, rank, cams)
+        still = gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0)
+        tr.train(still)
+        g_fused = _grad_planes(tr)
+        tr.set_option("fuse_camera_passes", 0)
+        tr.train(still)
+        g_pass = _grad_planes(tr)
+        tr.set_option("fuse_camera_passes", 1)
+        proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=1e-3, lrSh=2e-3, lrScale=5e-4, lrOpacity=1e-3, lrRotation=1e-3,
+                          paramDensifyVariance=0.05, paramCullOpacity=0.15, paramSplitSize=0.06)
+        for k in range(4):
+            tr.train(proj, densify=(k == 2))
+        out[rank] = (g_fused, g_pass, _model_bits(tr))
+        tr.close()
+    except BaseException as e:      # noqa: BLE001 — a dead rank would leave the others at a barrier
+        errors.append((rank, repr(e)))
+        raise
+
+
+def _world(install_factory, world=WORLD):
+    coll = HostCollectives(world)
+    out, errors = [None] * world, []
+    threads = [threading.Thread(target=_run_rank, args=(r, world, install_factory(coll), out, errors)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    if errors or any(t.is_alive() for t in threads):
+        coll.bar.abort()
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    return out, coll
+
+
+def _single():
+    out, errors = [None], []
+    _run_rank(0, 1, None, out, errors)
+    return out[0]
+
+
+@pytest.mark.parametrize("world", [8, 5, 3])       # 16 cameras: two per rank; 4 + 3 + 3 + 3 + 3; 6 + 5 + 5
+def test_compact_exchange_at_world_eight_five_and_three(world):
+    def factory(coll):
+        def install(tr, rank, cams):
+            f = coll.hooks(rank)
+            campos = np.ascontiguousarray([c.location for c in cams], np.float32).reshape(-1, 3)
+            capi.check(capi.lib().gs_trainer_set_compact_exchange(tr.handle, C.cast(f["all_gather"], C.c_void_p), C.cast(f["all_reduce"], C.c_void_p), None,
+                                                                  rank, world, campos.shape[0], campos.ctypes.data_as(C.c_void_p)))
+        return install
+    ranks, coll = _world(factory, world)
+    sf, sp, smodel = _single()
+    assert coll.calls["all_gather"] == coll.calls["all_reduce"] == 6
+    sh = slice(3, 3 + 3 * M)
+    geo = [0, 1, 2] + list(range(3 + 3 * M, 12 + 3 * M))
+    for g_fused, g_pass, model in ranks:
+        assert np.array_equal(g_fused[sh].view(np.uint32), sf[sh].view(np.uint32))      # SH gradients: the single-GPU bits, from eight ranks' records
+        assert np.array_equal(g_pass[sh].view(np.uint32), sp[sh].view(np.uint32))
+        for got, want in ((g_fused, sf), (g_pass, sp)):
+            for pl in geo:
+                assert np.abs(got[pl] - want[pl]).max() <= 2e-6 * np.abs(want[pl]).max() + 1e-30, pl
+        assert not g_fused[-1].any() and g_pass[-1].any() and np.abs(sf[sh]).max() > 0
+        assert np.array_equal(model.view(np.uint32), ranks[0][2].view(np.uint32))       # eight bit-identical replicas
+    assert ranks[0][2].size != (11 + 3 * M) * P                                           # densify changed the count
+    assert np.abs(smodel[:300] - ranks[0][2][:300]).max() < 1e-2
+
+
+@pytest.mark.parametrize("form", ["allreduce", "sharded"])
+def test_allreduce_and_sharded_update_at_world_eight(form):
+    def factory(coll):
+        def install(tr, rank, cams):
+            f = coll.hooks(rank)
+            if form == "allreduce":
+                capi.check(capi.lib().gs_trainer_set_allreduce(tr.handle, C.cast(f["all_reduce"], C.c_void_p), None))
+            else:
+                capi.check(capi.lib().gs_trainer_set_sharded_update(tr.handle, C.cast(f["reduce_scatter"], C.c_void_p), C.cast(f["all_gather"], C.c_void_p), None, rank, WORLD))
+        return install
+    ranks, coll = _world(factory)
+    sf, sp, smodel = _single()
+    for g_fused, g_pass, model in ranks:
+        assert np.array_equal(model.view(np.uint32), ranks[0][2].view(np.uint32))       # eight bit-identical replicas
+    if form == "allreduce":     # the gradient buffer holds the all-reduced planes on every rank
+        for pl in range(11 + 3 * M):
+            assert np.abs(ranks[0][0][pl] - sf[pl]).max() <= 2e-6 * np.abs(sf[pl]).max() + 1e-30, pl
+        assert coll.calls["all_reduce"] == 6
+    else:
+        # (the densify step gathers three more buffers: it runs on complete parameters and moments, tests/test_gpu_dist2.py)
+        assert coll.calls["reduce_scatter"] == 6 and coll.calls["all_gather"] == 6 + 3, coll.calls
+    assert ranks[0][2].size != (11 + 3 * M) * P
+    assert np.abs(smodel[:300] - ranks[0][2][:300]).max() < 1e-2
