@@ -108,19 +108,23 @@ class HostCollectives:
         return fns
 
 
-def _scene():
+SMALL = (P, N_CAMS, W, H)
+
+
+def _scene(shape):
+    P, n_cams, W, H = shape
     s = gs.synth.random_splats(P, M, 808)
-    cams = gs.camera.get_cameras(N_CAMS)
+    cams = gs.camera.get_cameras(n_cams)
     rng = np.random.default_rng(8)
-    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(N_CAMS)]
-    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(N_CAMS)]
+    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(n_cams)]
+    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(n_cams)]
     host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
     host.shDegree = s["D"]
-    host.capacity = P + 800
+    host.capacity = P + P // 5
     return s, cams, fw, fb, host
 
 
-def _grad_planes(tr):
+def _grad_planes(tr, P):
     ptr, n = tr.grad_buffer()
     tr.synchronize()
     buf = np.empty(n, np.float32)
@@ -135,9 +139,10 @@ def _model_bits(tr):
     return np.concatenate([h.locations[:3 * n], h.shs[:3 * M * n], h.scales[:3 * n], h.opacities[:n], h.rotations[:4 * n]])
 
 
-def _run_rank(rank, world, install, out, errors):
+def _run_rank(rank, world, install, out, errors, shape=SMALL):
     try:
-        s, cams, fw, fb, host = _scene()
+        P, _, W, H = shape
+        s, cams, fw, fb, host = _scene(shape)
         tr = gs.Trainer(W, H)
         tr.model = gs.ModelSplatsDevice(host)
         tr.captureTruths(cams, fw, fb)
@@ -146,10 +151,10 @@ def _run_rank(rank, world, install, out, errors):
             install(tr, rank, cams)
         still = gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0)
         tr.train(still)
-        g_fused = _grad_planes(tr)
+        g_fused = _grad_planes(tr, P)
         tr.set_option("fuse_camera_passes", 0)
         tr.train(still)
-        g_pass = _grad_planes(tr)
+        g_pass = _grad_planes(tr, P)
         tr.set_option("fuse_camera_passes", 1)
         proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=1e-3, lrSh=2e-3, lrScale=5e-4, lrOpacity=1e-3, lrRotation=1e-3,
                           paramDensifyVariance=0.05, paramCullOpacity=0.15, paramSplitSize=0.06)
@@ -162,10 +167,10 @@ def _run_rank(rank, world, install, out, errors):
         raise
 
 
-def _world(install_factory, world=WORLD):
+def _world(install_factory, world=WORLD, shape=SMALL):
     coll = HostCollectives(world)
     out, errors = [None] * world, []
-    threads = [threading.Thread(target=_run_rank, args=(r, world, install_factory(coll), out, errors)) for r in range(world)]
+    threads = [threading.Thread(target=_run_rank, args=(r, world, install_factory(coll), out, errors, shape)) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -176,14 +181,17 @@ def _world(install_factory, world=WORLD):
     return out, coll
 
 
-def _single():
+def _single(shape=SMALL):
     out, errors = [None], []
-    _run_rank(0, 1, None, out, errors)
+    _run_rank(0, 1, None, out, errors, shape)
     return out[0]
 
 
-@pytest.mark.parametrize("world", [8, 5, 3])       # 16 cameras: two per rank; 4 + 3 + 3 + 3 + 3; 6 + 5 + 5
-def test_compact_exchange_at_world_eight_five_and_three(world):
+# 16 cameras: two per rank; 4 + 3 + 3 + 3 + 3; 6 + 5 + 5 — and BASELINE cfg3 itself (100 000 splats, 8 cameras @1024^2, SH degree 3): one camera per rank
+@pytest.mark.parametrize("world,shape", [(8, SMALL), (5, SMALL), (3, SMALL), (8, (100000, 8, 1024, 1024))])
+def test_compact_exchange_at_world_eight_five_and_three(world, shape):
+    P = shape[0]
+
     def factory(coll):
         def install(tr, rank, cams):
             f = coll.hooks(rank)
@@ -191,8 +199,8 @@ def test_compact_exchange_at_world_eight_five_and_three(world):
             capi.check(capi.lib().gs_trainer_set_compact_exchange(tr.handle, C.cast(f["all_gather"], C.c_void_p), C.cast(f["all_reduce"], C.c_void_p), None,
                                                                   rank, world, campos.shape[0], campos.ctypes.data_as(C.c_void_p)))
         return install
-    ranks, coll = _world(factory, world)
-    sf, sp, smodel = _single()
+    ranks, coll = _world(factory, world, shape)
+    sf, sp, smodel = _single(shape)
     assert coll.calls["all_gather"] == coll.calls["all_reduce"] == 6
     sh = slice(3, 3 + 3 * M)
     geo = [0, 1, 2] + list(range(3 + 3 * M, 12 + 3 * M))
