@@ -19,7 +19,7 @@ groups = [
      re.compile(r"^(pixel-stage outliers|\s+flip allowance / sum)")),
     ("Rasterizer seam, backward: per-splat chain outputs outside the accounted budget (asserted zero)",
      re.compile(r"^\[seam, ")),
-    ("Scene sweep (tests/test_gpu_sweep.py): 93 seeded scenes outside the fixed cases' family; per scene forward state / lists bit-exact, every "
+    ("Scene sweep (tests/test_gpu_sweep.py): 105 seeded scenes outside the fixed cases' family; per scene forward state / lists bit-exact, every "
      "pixel an admissible blend, nine sums inside their budget, chain and pass average bit for bit, densify bit-exact — all asserted; the line "
      "reports the averaged gradients against the oracle (budget incl. the three conditioning terms of DESIGN.md 5)",
      re.compile(r"^\[sweep \d+:")),
