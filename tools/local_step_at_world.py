@@ -20,7 +20,7 @@ import gsplat_amd as gs  # noqa: E402
 from gsplat_amd import capi  # noqa: E402
 
 
-def measure(world, form, steps, config):
+def measure(world, form, steps, config, want_stages=False):
     P, M, V, W, H = gs.synth.CONFIGS[config]
     n_cams = V // 2
     s = gs.synth.random_splats(P, M, gs.synth.seed_for(config))
@@ -53,8 +53,18 @@ def measure(world, form, steps, config):
         tr.train(proj, densify=False)
     tr.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    stages = None
+    if want_stages:      # every stage timed with HIP events over a few more steps (the events cost ~3 us of stream time each)
+        capi.check(L.gs_trainer_set_profiling(tr.handle, 1))
+        for _ in range(20):
+            tr.train(proj, densify=False)
+        tr.synchronize()
+        sums, launches = (C.c_double * capi.GS_STAGE_COUNT)(), (C.c_longlong * capi.GS_STAGE_COUNT)()
+        capi.check(L.gs_trainer_stage_times(tr.handle, sums, launches))
+        L.gs_stage_name.restype = C.c_char_p
+        stages = {L.gs_stage_name(i).decode(): [round(sums[i] / 20, 4), int(launches[i]) // 20] for i in range(capi.GS_STAGE_COUNT) if launches[i]}
     tr.close()
-    return ms
+    return (ms, stages) if want_stages else ms
 
 
 def main():
@@ -69,6 +79,7 @@ def main():
             ms = measure(world, form, a.steps, a.config)
             out["local_step_ms"][f"{form}@{world}"] = round(ms, 4)
             out["ceiling_speedup"][f"{form}@{world}"] = round(single / ms, 2)
+    out["stages_ms_and_launches_per_step@8"] = {form: measure(8, form, 200, a.config, want_stages=True)[1] for form in ("allreduce", "sharded", "compact")}
     print(json.dumps(out))
 
 
