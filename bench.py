@@ -18,7 +18,6 @@ Rank 0 prints ONE JSON line.
 import argparse
 import ctypes as C
 import json
-import math
 import os
 import sys
 import time

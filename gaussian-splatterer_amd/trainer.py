@@ -9,7 +9,7 @@ import numpy as np
 
 from . import camera as cam
 from . import capi
-from .model import ModelSplatsDevice, ModelSplatsHost
+from .model import ModelSplatsDevice
 
 
 @dataclass

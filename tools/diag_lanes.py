@@ -12,7 +12,6 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np  # noqa: E402
 
 import gsplat_amd as gs  # noqa: E402
 from gsplat_amd import capi  # noqa: E402

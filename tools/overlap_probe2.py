@@ -13,8 +13,6 @@ import sys
 import threading
 import time
 
-import numpy as np
-
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import gsplat_amd as gs  # noqa: E402
 from gsplat_amd import capi  # noqa: E402
