@@ -262,9 +262,22 @@ def main():
                 g_ref, g_dp = grad_planes(ref), grad_planes(tr)
                 ref.close()
                 scale = np.abs(g_ref).max(1) + 1e-30
+                checked = "every gradient plane"
+                if collective.endswith("sharded"):
+                    # reduce-scatter leaves the iteration's sums in the rank's OWN chunk of the flat buffer only (the other chunks keep this
+                    # rank's partial sums; the update reads nothing of them): compare rank 0's chunk [0, total / world), the library's
+                    # one chunking of every plane-major buffer (gs_internal.h, shard_total_floats)
+                    Pa = tr.grad_buffer()[1] // (12 + 3 * M)
+                    n_flat, q = (12 + 3 * M) * Pa, world * 64
+                    chunk = (n_flat + q - 1) // q * q // world
+                    own = np.zeros((12 + 3 * M, Pa), bool)
+                    own.reshape(-1)[:min(chunk, n_flat)] = True
+                    own = own[:, :P]
+                    g_dp = np.where(own, g_dp, g_ref)
+                    checked = f"rank 0's chunk of the flat buffer ({int(own.sum())} of {own.size} entries): the reduce-scatter sums nothing else on this rank"
                 dev = float((np.abs(g_dp - g_ref).max(1) / scale).max())
                 sh_same = bool(np.array_equal(g_dp[3:3 + 3 * M].view(np.uint32), g_ref[3:3 + 3 * M].view(np.uint32)))
-                res = {"max_plane_deviation": dev, "sh_planes_bit_identical_to_unsharded_step": sh_same,
+                res = {"max_plane_deviation": dev, "sh_planes_bit_identical_to_unsharded_step": sh_same, "compared": checked,
                        "ok": bool(dev <= 2e-5 and np.isfinite(g_dp).all() and np.abs(g_ref).max() > 0)}
             return json.loads(gsdist.broadcast_bytes(json.dumps(res).encode() if rank == 0 else b"", src=0).decode())
         exchange_check = dict(check_once(), collective=collective)

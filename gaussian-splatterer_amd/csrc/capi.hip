@@ -60,16 +60,19 @@ static bool set_option(Options& o, const char* name, int value) {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    uint64_t generation = 0;   // advanced by every (re)allocation and release: what "is this still the buffer I initialised?" must compare —
+                               // the allocator may hand the SAME address back for a larger block after the free
     int ensure(size_t bytes) {
         if (bytes <= cap) return GS_OK;
         if (p) { GS_HIP(hipFree(p)); p = nullptr; cap = 0; }
+        generation++;
         bytes = round_up_sz(bytes, 256);
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GS_ERR_OUT_OF_MEMORY; }
         cap = bytes;
         return GS_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; generation++; }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -146,7 +149,7 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
 
 struct ScratchSet {
     DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, rowmark, hmask, color, finalT, ncontrib, scan_tmp, sgrads, shjac;
-    const void* rowmark_cleared = nullptr;  // the allocation of `rowmark` that has been zeroed (a new one holds stale bytes: the caller clears it and restarts the epochs)
+    uint64_t rowmark_cleared = ~0ull;  // the generation of `rowmark` that has been zeroed (a new allocation holds stale bytes: the caller clears it and restarts the epochs)
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
     Scratch s{};
@@ -497,7 +500,7 @@ struct gs_trainer {
     void* xchg_user = nullptr;
     int xchg_rank = 0, xchg_world = 1, xchg_cameras = 0;
     void* xchg_comms[2] = { nullptr, nullptr };  // gs_trainer_attach_comm_compact: the communicators of the all-gather and of the all-reduce
-    DevBuf xgeo, xrgb, xcampos;
+    DevBuf xgeo, xrgb;
     hipStream_t stream2 = nullptr;           // carries the all-reduce beside the all-gather
     hipEvent_t ev_packed = nullptr, ev_reduced = nullptr;
     gs_step_stats last{};
@@ -619,7 +622,7 @@ extern "C" int gs_trainer_destroy(gs_trainer* t) {
     gs_model_destroy(t->model);
     t->truth.release(); t->grad.release(); t->adam_m.release(); t->adam_v.release(); t->sh16.release(); t->densify_work.release();
     t->spare_planes.release(); t->spare_m.release(); t->spare_v.release();
-    t->xgeo.release(); t->xrgb.release(); t->xcampos.release();
+    t->xgeo.release(); t->xrgb.release();
     if (t->stream2) { (void)hipStreamSynchronize(t->stream2); (void)hipStreamDestroy(t->stream2); }
     if (t->ev_packed) (void)hipEventDestroy(t->ev_packed);
     if (t->ev_reduced) (void)hipEventDestroy(t->ev_reduced);
@@ -804,9 +807,9 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
         // all marks when the epochs wrap or the buffer is new.
         d.epoch = 0; d.marks_min_list = t->opt.row_marks < 0 ? 1024u : 0u;
         if (t->opt.row_marks != 0) {
-            if (t->row_epoch >= 255 || t->train.rowmark_cleared != t->train.rowmark.p) {
+            if (t->row_epoch >= 255 || t->train.rowmark_cleared != t->train.rowmark.generation) {
                 GS_HIP(hipMemsetAsync(t->train.rowmark.p, 0, t->train.rowmark.cap, t->stream));
-                t->train.rowmark_cleared = t->train.rowmark.p;
+                t->train.rowmark_cleared = t->train.rowmark.generation;
                 t->row_epoch = 0;
             }
             d.epoch = ++t->row_epoch;
@@ -1044,48 +1047,66 @@ static int step_compact_exchange(gs_trainer* t, const gs_hyper* h, int densify, 
     const int cmax = (C_ + G - 1) / G;
     const size_t Pa = (size_t)m->Pa;
     GS_TRY(t->xgeo.ensure(12 * Pa * 4));
-    GS_TRY(t->xrgb.ensure((size_t)G * 2 * cmax * 3 * Pa * 4));
+    const int hdr = exchange_header_floats(C_, G);
+    GS_TRY(t->xrgb.ensure((size_t)G * ((size_t)hdr + 2 * cmax * 3 * Pa) * 4));
     Exchange x;
-    x.geo = t->xgeo.as<float>(); x.rgb = t->xrgb.as<float>(); x.rank = t->xchg_rank; x.world = G;
+    x.geo = t->xgeo.as<float>(); x.rgb = t->xrgb.as<float>(); x.rank = t->xchg_rank; x.world = G; x.hdr = hdr;
     GS_TRY(accumulate_async(t, densify != 0, &x));   // sets x.slots for the form this step takes
     const bool per_pass = x.slots == 2 * cmax;
     if (m->count > 0) {
         if (!t->stream2) GS_HIP(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
         if (!t->ev_packed) { GS_HIP(hipEventCreateWithFlags(&t->ev_packed, hipEventDisableTiming)); GS_HIP(hipEventCreateWithFlags(&t->ev_reduced, hipEventDisableTiming)); }
         const bool overlap = t->opt.xchg_overlap != 0;
-        prof_stage_begin(t, 8, 6);
-        int rc = 0;
-        if (overlap) {
-            GS_HIP(hipEventRecord(t->ev_packed, t->stream));
-            GS_HIP(hipStreamWaitEvent(t->stream2, t->ev_packed, 0));
-            rc = t->xchg_reduce(x.geo, 12 * Pa, (void*)t->stream2, t->xchg_user);
-            if (rc == 0) GS_HIP(hipEventRecord(t->ev_reduced, t->stream2));
+        // Every early return below leaves the stage / roctx range closed, and — once the all-reduce is under way on the second stream —
+        // waits for it: the next step's pack kernel writes x.geo on the main stream and must not meet a collective still reading it.
+        struct StageScope {
+            gs_trainer* t; int stage; bool open = true;
+            StageScope(gs_trainer* t_, int stage_, int before) : t(t_), stage(stage_) { prof_stage_begin(t, stage, before); }
+            void end() { if (open) { prof_stage_end(t, stage); open = false; } }
+            ~StageScope() { end(); }
+        };
+        struct SecondStreamGuard {
+            gs_trainer* t; bool armed = false;
+            ~SecondStreamGuard() { if (armed && t->stream2) (void)hipStreamSynchronize(t->stream2); }
+        } second{ t };
+        {
+            StageScope stage(t, 8, 6);
+            int rc = 0;
+            if (overlap) {
+                GS_HIP(hipEventRecord(t->ev_packed, t->stream));
+                GS_HIP(hipStreamWaitEvent(t->stream2, t->ev_packed, 0));
+                second.armed = true;
+                rc = t->xchg_reduce(x.geo, 12 * Pa, (void*)t->stream2, t->xchg_user);
+                if (rc == 0) GS_HIP(hipEventRecord(t->ev_reduced, t->stream2));
+            }
+            const char* failed = rc != 0 ? "all-reduce (geometry planes)" : nullptr;
+            if (!failed) {
+                rc = t->xchg_gather(x.rgb, (size_t)G * ((size_t)x.hdr + (size_t)x.slots * 3 * Pa), (void*)t->stream, t->xchg_user);
+                if (rc != 0) failed = "all-gather (dL_dRGB records)";
+            }
+            if (!failed && !overlap) {
+                rc = t->xchg_reduce(x.geo, 12 * Pa, (void*)t->stream, t->xchg_user);
+                if (rc != 0) failed = "all-reduce (geometry planes)";
+            }
+            stage.end();
+            if (failed) { set_error("%s hook failed with %d", failed, rc); return GS_ERR_COLLECTIVE; }
         }
-        const char* failed = rc != 0 ? "all-reduce (geometry planes)" : nullptr;
-        if (!failed) {
-            rc = t->xchg_gather(x.rgb, (size_t)G * x.slots * 3 * Pa, (void*)t->stream, t->xchg_user);
-            if (rc != 0) failed = "all-gather (dL_dRGB records)";
-        }
-        if (!failed && !overlap) {
-            rc = t->xchg_reduce(x.geo, 12 * Pa, (void*)t->stream, t->xchg_user);
-            if (rc != 0) failed = "all-reduce (geometry planes)";
-        }
-        prof_stage_end(t, 8);
-        if (failed) { set_error("%s hook failed with %d", failed, rc); return GS_ERR_COLLECTIVE; }
         GS_TRY(debug_check(t, 8));
         Dims d;
         GS_TRY(trainer_dims(t, &d));
-        prof_stage_begin(t, 6, 8);
-        if (overlap) {
-            // the SH planes need the gathered records only: they are rebuilt while the all-reduce is still under way on the second
-            // stream; the twelve other planes follow behind its event
-            GS_TRY(launch_sh_rebuild(d, m->planes, x, t->xcampos.as<float>(), C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 1, t->stream));
-            GS_HIP(hipStreamWaitEvent(t->stream, t->ev_reduced, 0));
-            GS_TRY(launch_sh_rebuild(d, m->planes, x, t->xcampos.as<float>(), C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 2, t->stream));
-        } else {
-            GS_TRY(launch_sh_rebuild(d, m->planes, x, t->xcampos.as<float>(), C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 3, t->stream));
+        {
+            StageScope stage(t, 6, 8);
+            if (overlap) {
+                // the SH planes need the gathered records only: they are rebuilt while the all-reduce is still under way on the second
+                // stream; the twelve other planes follow behind its event
+                GS_TRY(launch_sh_rebuild(d, m->planes, x, C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 1, t->stream));
+                GS_HIP(hipStreamWaitEvent(t->stream, t->ev_reduced, 0));
+                second.armed = false;   // the main stream now waits for the all-reduce itself
+                GS_TRY(launch_sh_rebuild(d, m->planes, x, C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 2, t->stream));
+            } else {
+                GS_TRY(launch_sh_rebuild(d, m->planes, x, C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 3, t->stream));
+            }
         }
-        prof_stage_end(t, 6);
         GS_TRY(debug_check(t, 6));
     }
     GS_TRY(apply_update(t, h, 6));
@@ -1103,13 +1124,14 @@ extern "C" int gs_trainer_set_compact_exchange(gs_trainer* t, gs_collective_fn a
     GS_HIP(hipSetDevice(t->device));
     GS_HIP(hipStreamSynchronize(t->stream));
     if (!all_gather || !all_reduce) { t->xchg_gather = nullptr; t->xchg_reduce = nullptr; t->xchg_user = nullptr; t->xchg_rank = 0; t->xchg_world = 1; t->xchg_cameras = 0; return GS_OK; }
-    if (world < 1 || world > 64 || rank < 0 || rank >= world || n_cameras < world || !campos) {
-        set_error("gs_trainer_set_compact_exchange: rank %d of %d (1..64 ranks), %d cameras (at least one per rank), camera positions %s",
-                  rank, world, n_cameras, campos ? "given" : "missing");
+    // `campos` is accepted for ABI compatibility and not used: every rank sends the positions of its cameras in the header of its
+    // records (Exchange::hdr), taken from the view block the step rendered with, so a re-capture with moved cameras
+    // (gs_trainer_set_views) needs no second call here and cannot leave a stale SH basis behind.
+    (void)campos;
+    if (world < 1 || world > 64 || rank < 0 || rank >= world || n_cameras < world) {
+        set_error("gs_trainer_set_compact_exchange: rank %d of %d (1..64 ranks), %d cameras (at least one per rank)", rank, world, n_cameras);
         return GS_ERR_INVALID_ARGUMENT;
     }
-    GS_TRY(t->xcampos.ensure((size_t)n_cameras * 3 * sizeof(float)));
-    GS_HIP(hipMemcpy(t->xcampos.p, campos, (size_t)n_cameras * 3 * sizeof(float), hipMemcpyHostToDevice));
     t->xchg_gather = all_gather; t->xchg_reduce = all_reduce; t->xchg_user = user; t->xchg_rank = rank; t->xchg_world = world; t->xchg_cameras = n_cameras;
     return GS_OK;
 }

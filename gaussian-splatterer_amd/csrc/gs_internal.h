@@ -181,15 +181,20 @@ int launch_render_backward(const Dims& d, const Scratch& s, const int* items, in
 // twelve other planes; every rank rebuilds the SH planes itself (k_sh_rebuild).
 struct Exchange {
     float* geo = nullptr;  // [12][Pa]  loc 3 | scale 3 | opacity 1 | rot 4 | var 1: this rank's sums -> (all-reduce) -> the iteration's
-    float* rgb = nullptr;  // [world][slots][3][Pa]  dL_dRGB of every record of every rank; this rank writes chunk `rank` -> (all-gather)
+    float* rgb = nullptr;  // [world][hdr + slots * 3 * Pa]  per rank: the positions of the rank's cameras (3 floats per local camera, zero-padded to
+                           // hdr floats), then dL_dRGB of every record [slots][3][Pa]; this rank writes chunk `rank` -> (all-gather).  The positions
+                           // travel WITH the records they belong to: k_sh_rebuild forms every record's view direction from the gathered header, so
+                           // cameras that moved since the exchange was installed (a re-capture, gs_trainer_set_views) cannot leave a stale basis behind
     int rank = 0, world = 1;
     int slots = 0;         // records per rank: ceil(cameras / world) in the fused form, twice that (white | black) in the per-pass form
+    int hdr = 0;           // floats in front of a rank's records: 3 * ceil(cameras / world) rounded up to 64 (the planes stay 256-byte aligned)
 };
+inline int exchange_header_floats(int n_cameras, int world) { return ((3 * ((n_cameras + world - 1) / world)) + 63) / 64 * 64; }
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad_planes, const int* items,
                               int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st, const Exchange* x = nullptr);
-// after the exchange: every averaged-gradient plane from the reduced geometry planes and the gathered dL_dRGB (campos: [n_cameras][3], device)
+// after the exchange: every averaged-gradient plane from the reduced geometry planes and the gathered dL_dRGB + camera positions
 // parts: 1 = the SH planes (from the gathered records), 2 = the twelve other planes (from the reduced sums), 3 = both
-int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, const float* campos, int n_cameras, bool per_pass, float samples,
+int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, int n_cameras, bool per_pass, float samples,
                       float* grad_planes, int parts, hipStream_t st);
 // Seam form: one view, reference-shaped AoS outputs with the reference's += / = discipline.
 struct SeamGrads { float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot; };

@@ -359,7 +359,15 @@ template <int D> struct GradAcc {
 // SINGLE: the step has exactly one record per splat (one work item: the per-GPU load of an 8-GPU run) — the record never leaves
 // the registers: accumulateGradients is applied here and the gradient planes are written, no second launch.
 // Where a record's dL_dRGB goes in the compact exchange's gather buffer (Exchange::rgb): chunk `rank`, slot, three planes of Pa.
-__device__ inline float* exchange_rgb(const Exchange& x, int rank, int slot, size_t Pa) { return x.rgb + ((size_t)rank * x.slots + slot) * 3 * Pa; }
+__device__ inline float* exchange_chunk(const Exchange& x, int rank, size_t Pa) { return x.rgb + (size_t)rank * ((size_t)x.hdr + (size_t)x.slots * 3 * Pa); }
+__device__ inline float* exchange_rgb(const Exchange& x, int rank, int slot, size_t Pa) { return exchange_chunk(x, rank, Pa) + x.hdr + (size_t)slot * 3 * Pa; }
+// The header of this rank's chunk: the position of each of its cameras (local camera = geometry group), from the view block the step
+// rendered with.  One workgroup writes it; it leaves the rank with the records in the same all-gather.
+__device__ inline void exchange_write_header(const Dims& d, const Scratch& s, const Exchange& x) {
+    if (blockIdx.x != 0 || blockIdx.y != 0) return;
+    float* h = exchange_chunk(x, x.rank, (size_t)d.Pa);
+    for (int t = threadIdx.x; t < x.hdr; t += WG) { const int g = t / 3; h[t] = g < d.VG ? s.gviews[g].campos[t - 3 * g] : 0.0f; }
+}
 
 // SINGLE + x.geo != null (compact exchange): the geometry sums go to the exchange's twelve planes and the record's dL_dRGB to
 // its slot 0 of this rank's chunk of the gather buffer; no SH plane is touched (k_sh_rebuild writes them after the exchange).
@@ -376,6 +384,7 @@ __global__ __launch_bounds__(WG) GS_SBV_ATTR void k_splat_bwd_view(Dims d, const
                                                        const int* __restrict__ items, int n_pairs, int fused, float samples,
                                                        float* __restrict__ grad, Exchange x) {
     const int i = blockIdx.x * WG + threadIdx.x;
+    if constexpr (SINGLE) { if (x.geo) exchange_write_header(d, s, x); }
     if (i >= d.P) return;
     // blockIdx.y enumerates passes: the two passes of every pair item first, then the single items
     const int y = blockIdx.y;
@@ -468,6 +477,7 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __
 __global__ __launch_bounds__(WG) void k_exchange_pack(Dims d, Scratch s, float samples, const float4* __restrict__ rec_in, Exchange x,
                                                       const int* __restrict__ items, int n_fused_items) {
     const int i = blockIdx.x * WG + threadIdx.x;
+    exchange_write_header(d, s, x);
     if (i >= d.P) return;
     const size_t st = (size_t)d.Pa;
     GradAcc<0> acc;
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(WG) void k_exchange_pack(Dims d, Scratch s, float s
 // parts: bit 0 = the SH planes (needs the gathered records only), bit 1 = the twelve other planes (needs the all-reduce only):
 // with the two collectives side by side the SH planes are rebuilt while the all-reduce is still under way.
 template <int D>
-__global__ __launch_bounds__(WG) void k_sh_rebuild(Dims d, const float* __restrict__ params, Exchange x, const float* __restrict__ campos,
+__global__ __launch_bounds__(WG) void k_sh_rebuild(Dims d, const float* __restrict__ params, Exchange x,
                                                    int n_cameras, int per_pass, float samples, float* __restrict__ grad, int parts) {
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(WG) void k_sh_rebuild(Dims d, const float* __restri
             const int slot = (k < n_cameras ? 0 : x.slots / 2) + c / x.world;
             const float* rgb = exchange_rgb(x, c % x.world, slot, st);
             const float dRGB[3] = { rgb[i], rgb[st + i], rgb[2 * st + i] };
-            acc.add_sh(dRGB, samples, mx, my, mz, campos + 3 * c);
+            acc.add_sh(dRGB, samples, mx, my, mz, exchange_chunk(x, c % x.world, st) + 3 * (c / x.world));   // the position that came with the record
         }
         constexpr int NC = GradAcc<D>::NC;
 #pragma unroll
@@ -570,16 +580,16 @@ int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch&
     return GS_OK;
 }
 
-int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, const float* campos, int n_cameras, bool per_pass, float samples,
+int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, int n_cameras, bool per_pass, float samples,
                       float* grad, int parts, hipStream_t stream) {
     if (d.P == 0) return GS_OK;
     const dim3 grid((d.P + WG - 1) / WG);
     const int pp = per_pass ? 1 : 0;
     switch (d.D) {
-        case 0: hipLaunchKernelGGL(k_sh_rebuild<0>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad, parts); break;
-        case 1: hipLaunchKernelGGL(k_sh_rebuild<1>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad, parts); break;
-        case 2: hipLaunchKernelGGL(k_sh_rebuild<2>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad, parts); break;
-        default: hipLaunchKernelGGL(k_sh_rebuild<3>, grid, dim3(WG), 0, stream, d, params, x, campos, n_cameras, pp, samples, grad, parts); break;
+        case 0: hipLaunchKernelGGL(k_sh_rebuild<0>, grid, dim3(WG), 0, stream, d, params, x, n_cameras, pp, samples, grad, parts); break;
+        case 1: hipLaunchKernelGGL(k_sh_rebuild<1>, grid, dim3(WG), 0, stream, d, params, x, n_cameras, pp, samples, grad, parts); break;
+        case 2: hipLaunchKernelGGL(k_sh_rebuild<2>, grid, dim3(WG), 0, stream, d, params, x, n_cameras, pp, samples, grad, parts); break;
+        default: hipLaunchKernelGGL(k_sh_rebuild<3>, grid, dim3(WG), 0, stream, d, params, x, n_cameras, pp, samples, grad, parts); break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

@@ -149,7 +149,11 @@ class TorchShardedUpdate:
                     if self.native_reduce_scatter:
                         dist.reduce_scatter_tensor(t[self.rank * c:(self.rank + 1) * c], t, op=dist.ReduceOp.SUM)
                     else:
+                        # gloo stand-in: the sums everywhere, then everything outside the rank's own chunk POISONED — a real
+                        # reduce-scatter leaves this rank's partial sums there, and nothing downstream may read them
                         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                        t[:self.rank * c] = float("nan")
+                        t[(self.rank + 1) * c:] = float("nan")
                 self.calls["reduce_scatter"] += 1
                 return 0
             except Exception as e:  # never let an exception cross the C boundary

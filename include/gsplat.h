@@ -293,8 +293,12 @@ int gs_trainer_set_sharded_update(gs_trainer* trainer, gs_collective_fn reduce_s
  * long as the all-reduce leaves identical sums on all ranks (RCCL's does).
  * Layout contract: the iteration has n_cameras cameras in the reference's order (src/Trainer.cu:311-314: pass c = camera c on
  * white, pass n_cameras + c = camera c on black); camera c belongs to rank c % world with BOTH passes (at least one camera
- * per rank), gs_trainer_set_views on each rank holds exactly those passes and total_samples = 2 * n_cameras.  `campos`
- * [n_cameras][3] (host): every camera's position, rank-independent.  Pass NULL hooks to leave the form.
+ * per rank), gs_trainer_set_views on each rank holds exactly those passes and total_samples = 2 * n_cameras.  The camera
+ * positions the SH basis needs travel WITH the records: every rank puts the positions of its cameras, as set by its latest
+ * gs_trainer_set_views, in a small header of its chunk (3 floats per camera, padded to 64), so re-captured / re-rotated cameras
+ * (the reference re-captures every intervalCapture iterations, src/ui/UiFrame.cpp:266-298) need no second call here.  `campos`
+ * is kept in the signature for ABI stability and is NOT read (may be NULL).  The all_gather hook is called with
+ * world * (header + records) floats.  Pass NULL hooks to leave the form.
  * Trainer option "exchange_overlap" (default 1): 0 issues the two collectives one after the other on the trainer's stream. */
 int gs_trainer_set_compact_exchange(gs_trainer* trainer, gs_collective_fn all_gather, gs_allreduce_fn all_reduce, void* user, int rank,
                                     int world, int n_cameras, const float* campos);

@@ -598,6 +598,116 @@ void render_backward(const ViewState<R>& g, const R* bg, const R* dL_dpix, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The reference's OWN summation (test-side service, not part of the restatement above).  Upstream's backward render
+// kernel — the call at src/Trainer.cu:378-412 — has one thread per pixel walk its tile's list back to front and add the
+// nine terms of every blended (pixel, splat) pair to the splat's global accumulators with fp32 atomicAdd (buffers
+// pre-zeroed at src/Trainer.cu:366-375).  The terms are deterministic fp32 values (pixel_backward<float> below is that
+// arithmetic); the ORDER in which a splat's accumulator receives them is whatever the hardware retires first, so two runs of the
+// reference differ by the rounding of two different fp32 summation orders.  render_backward above avoids the question by
+// summing in double; this block answers it: atomic_prepare keeps every emitted term, atomic_sums adds a splat's terms in
+// fp32 in a seeded order.  K seeds = K admissible runs of the reference; their per-entry [min, max] is the reference's
+// run-to-run envelope, the yardstick the parity tolerances are calibrated against (tests/test_reference_noise.py).
+//   mode 0: every (tile, pixel) term of a splat in one uniformly random order (tiles run concurrently on the device);
+//   mode 1: tiles in random order, the pixels of one tile in random order, tile after tile (a device that runs few tiles at once);
+//   mode 2: ascending tile, raster pixel order (one fixed admissible order);   mode 3: the reverse of mode 2.
+// ---------------------------------------------------------------------------------------------
+struct AtomicRec { float t[9]; };
+struct AtomicTerms {
+    std::vector<AtomicRec> rec;          // grouped by list entry k (= one (tile, splat) pair), pixel order inside
+    std::vector<uint64_t> entry_off;     // [Rn + 1]
+    std::vector<uint32_t> splat_entry;   // list positions k of every splat, ascending (= ascending tile)
+    std::vector<uint64_t> splat_off;     // [P + 1]
+    int P = 0;
+};
+
+inline uint64_t splitmix64(uint64_t& x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <class It> inline void seeded_shuffle(It first, size_t n, uint64_t& st) {
+    for (size_t i = n; i > 1; i--) {
+        const size_t j = (size_t)(splitmix64(st) % (uint64_t)i);   // (modulo bias ~ n / 2^64: none that matters)
+        std::swap(first[i - 1], first[j]);
+    }
+}
+
+uint64_t atomic_prepare(const ViewState<float>& g, const float* bg, const float* dL_dpix, AtomicTerms& at) {
+    const int W = g.W, H = g.H, P = g.P;
+    const size_t N = (size_t)W * H;
+    const size_t Rn = g.point_list.size();
+    const int T = g.gx * g.gy;
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    struct TileRec { uint32_t k; AtomicRec r; };
+    std::vector<std::vector<TileRec>> per_tile(T);
+    std::vector<uint64_t> count(Rn + 1, 0);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < T; tile++) {
+        const int tx = tile % g.gx, ty = tile / g.gx;
+        const uint32_t beg = g.ranges[2 * (size_t)tile], end = g.ranges[2 * (size_t)tile + 1];
+        if (end <= beg) continue;
+        std::vector<TileRec>& out = per_tile[tile];
+        for (int py = ty * TILE; py < std::min(H, (ty + 1) * TILE); py++)
+            for (int px = tx * TILE; px < std::min(W, (tx + 1) * TILE); px++) {
+                const size_t pix = (size_t)py * W + px;
+                const float dpx[3] = { dL_dpix[pix], dL_dpix[N + pix], dL_dpix[2 * N + pix] };
+                pixel_backward<float>(g, beg, end, (float)px, (float)py, g.final_T[pix], g.n_contrib[pix], bg, dpx, ddelx_dx, ddely_dy, PixelFlip{},
+                                      [&](uint32_t k, int q, float term) {
+                                          if (q == 0) { out.push_back(TileRec{}); out.back().k = k; }
+                                          out.back().r.t[q] = term;
+                                      });
+            }
+        for (const TileRec& tr : out) count[tr.k]++;     // k in [beg, end): this tile's own counters
+    }
+    at.entry_off.assign(Rn + 1, 0);
+    for (size_t k = 0; k < Rn; k++) at.entry_off[k + 1] = at.entry_off[k] + count[k];
+    at.rec.resize(at.entry_off[Rn]);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < T; tile++) {
+        std::vector<TileRec>& out = per_tile[tile];
+        if (out.empty()) continue;
+        const uint32_t beg = g.ranges[2 * (size_t)tile], end = g.ranges[2 * (size_t)tile + 1];
+        std::vector<uint64_t> cur(at.entry_off.begin() + beg, at.entry_off.begin() + end);
+        for (const TileRec& tr : out) at.rec[cur[tr.k - beg]++] = tr.r;
+        std::vector<TileRec>().swap(out);
+    }
+    at.P = P;
+    at.splat_off.assign((size_t)P + 1, 0);
+    for (size_t k = 0; k < Rn; k++) at.splat_off[(size_t)g.point_list[k] + 1]++;
+    for (int i = 0; i < P; i++) at.splat_off[(size_t)i + 1] += at.splat_off[i];
+    at.splat_entry.resize(Rn);
+    std::vector<uint64_t> cur(at.splat_off.begin(), at.splat_off.end() - 1);
+    for (size_t k = 0; k < Rn; k++) at.splat_entry[cur[g.point_list[k]]++] = (uint32_t)k;
+    return (uint64_t)at.rec.size();
+}
+
+void atomic_sums(const AtomicTerms& at, uint64_t seed, int mode, float* sums9) {
+    const int P = at.P;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < P; i++) {
+        float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };    // the pre-zeroed accumulators, src/Trainer.cu:366-375
+        const uint64_t e0 = at.splat_off[i], e1 = at.splat_off[(size_t)i + 1];
+        uint64_t st = seed * 0xD1342543DE82EF95ull + (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+        std::vector<uint64_t> order;
+        std::vector<uint32_t> ents(at.splat_entry.begin() + e0, at.splat_entry.begin() + e1);
+        if (mode == 1) seeded_shuffle(ents.begin(), ents.size(), st);
+        for (uint32_t k : ents) {
+            const size_t first = order.size();
+            for (uint64_t r = at.entry_off[k]; r < at.entry_off[(size_t)k + 1]; r++) order.push_back(r);
+            if (mode == 1) seeded_shuffle(order.begin() + first, order.size() - first, st);
+        }
+        if (mode == 0) seeded_shuffle(order.begin(), order.size(), st);
+        if (mode == 3) std::reverse(order.begin(), order.end());
+        for (uint64_t r : order) {
+            const float* t = at.rec[r].t;
+            for (int q = 0; q < 9; q++) acc[q] = acc[q] + t[q];     // one fp32 round-to-nearest add per atomicAdd
+        }
+        for (int q = 0; q < 9; q++) sums9[(size_t)i * 9 + q] = acc[q];
+    }
+}
+
 // A.8 + A.9 — per-splat backward: conic -> cov2D -> cov3D & mean; mean2D -> mean; colour -> SH &
 // mean; cov3D -> scale & rotation (gradient w.r.t. the unnormalised quaternion).
 template <class R>
@@ -905,7 +1015,7 @@ inline void quat_to_mat3(float w, float x, float y, float z, float out[3][3]) {
 // =============================================================================================
 extern "C" {
 
-struct orc_state { State<float> f; State<double> d; };
+struct orc_state { State<float> f; State<double> d; AtomicTerms at; };
 
 orc_state* orc_state_new() { return new orc_state(); }
 void orc_state_free(orc_state* s) { delete s; }
@@ -995,6 +1105,13 @@ void orc_chain_f32(orc_state* s, int D, int M, const float* means, const float* 
     Grads<float> o{ m2.data(), con.data(), op.data(), col.data(), dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
     preprocess_backward<float>(s->f.v, D, M, means, scales, mod, rots, shs, view, proj, campos, tanx, tany, o);
 }
+// The reference's own fp32 atomicAdd summation (see atomic_prepare above), on the state of the last orc_forward_f32:
+// orc_atomic_prepare keeps every term upstream's backward render kernel would add for this dL_dpix and returns their number;
+// orc_atomic_sums writes sums9[P][9] (layout of orc_chain_f32) summed in fp32 in the order (seed, mode) names;
+// orc_atomic_release drops the terms.  The per-splat chain of such a run is orc_chain_f32 on those sums (it has no atomics upstream).
+uint64_t orc_atomic_prepare(orc_state* s, const float* bg, const float* dL_dpix) { return atomic_prepare(s->f.v, bg, dL_dpix, s->at); }
+void orc_atomic_sums(orc_state* s, uint64_t seed, int mode, float* sums9) { atomic_sums(s->at, seed, mode, sums9); }
+void orc_atomic_release(orc_state* s) { s->at = AtomicTerms(); }
 // Every pixel of a foreign implementation's forward output (colour [3][N] incl. background, final T, last contributor)
 // against the admissible blends of that pixel (pixel_run above).  status[pix]:
 //   0  equals the nominal blend (the one orc_forward_f32 produced)

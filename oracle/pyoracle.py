@@ -181,6 +181,43 @@ class Rasterizer:
         return g
 
 
+    # --- the reference's own fp32 atomicAdd summation (gs_oracle.cpp, atomic_prepare / atomic_sums) ---
+    def atomic_prepare(self, dL_dpix):
+        """Keep every term upstream's backward render kernel would atomicAdd for this dL_dpix (state of the last forward).
+        Returns their number."""
+        assert self.dt == np.float32
+        a = self.args
+        dpix = _c(dL_dpix, np.float32).reshape(-1)
+        assert dpix.size == 3 * a["W"] * a["H"]
+        L = lib()
+        L.orc_atomic_prepare.restype = C.c_uint64
+        return int(L.orc_atomic_prepare(self.h, _p(a["bg"], f32p), _p(dpix, f32p)))
+
+    def atomic_sums(self, seed, mode=0):
+        """The nine pixel-stage sums [P, 9] (layout of chain()) added in fp32 in the order (seed, mode) names: one admissible
+        run of the reference.  mode 0: one random order over all of a splat's (tile, pixel) terms; 1: random tile order, random
+        pixel order inside each tile; 2: ascending tile / raster pixel order; 3: its reverse."""
+        sums9 = np.zeros((self.P, 9), np.float32)
+        lib().orc_atomic_sums(self.h, C.c_uint64(seed), C.c_int(mode), _p(sums9, f32p))
+        return sums9
+
+    def atomic_release(self):
+        lib().orc_atomic_release(self.h)
+
+    def atomic_backward(self, seed, mode=0):
+        """One admissible run of the reference's backward (after atomic_prepare): the sums in the (seed, mode) order, then the
+        unchanged per-splat chain.  Same keys as backward()."""
+        P = self.P
+        sums9 = self.atomic_sums(seed, mode)
+        g = chain(self, sums9)
+        g["dL_dcolor"] = np.ascontiguousarray(sums9[:, 0:3]).reshape(-1)
+        m2 = np.zeros((P, 3), np.float32); m2[:, :2] = sums9[:, 3:5]
+        con = np.zeros((P, 4), np.float32); con[:, [0, 1, 3]] = sums9[:, 5:8]
+        g["dL_dmean2D"], g["dL_dconic"], g["dL_dopacity"] = m2.reshape(-1), con.reshape(-1), sums9[:, 8].copy()
+        g["sums9"] = sums9
+        return g
+
+
 def check_pixels(r, got_color, got_T, got_last, alpha_margin=1e-4, T_margin=1e-4, rtol=1e-4, floor_T=1e-4, floor_C=1e-3, max_leaves=4096, exp_cond=0.0):
     """Every pixel of another implementation's forward output against the ADMISSIBLE blends of Rasterizer `r`'s last
     forward (gs_oracle.cpp, orc_check_pixels_f32): the nominal blend, or the blend with fragile decisions — pairs within

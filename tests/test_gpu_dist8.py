@@ -239,3 +239,171 @@ def test_allreduce_and_sharded_update_at_world_eight(form):
         assert coll.calls["reduce_scatter"] == 6 and coll.calls["all_gather"] == 6 + 3, coll.calls
     assert ranks[0][2].size != (11 + 3 * M) * P
     assert np.abs(smodel[:300] - ranks[0][2][:300]).max() < 1e-2
+
+
+def _install(coll, form, world):
+    def install(tr, rank, cams):
+        f = coll.hooks(rank)
+        L = capi.lib()
+        if form == "compact":     # (no camera positions are handed over: they travel with the records, include/gsplat.h)
+            capi.check(L.gs_trainer_set_compact_exchange(tr.handle, C.cast(f["all_gather"], C.c_void_p), C.cast(f["all_reduce"], C.c_void_p), None,
+                                                          rank, world, len(cams), None))
+        elif form == "allreduce":
+            capi.check(L.gs_trainer_set_allreduce(tr.handle, C.cast(f["all_reduce"], C.c_void_p), None))
+        else:
+            capi.check(L.gs_trainer_set_sharded_update(tr.handle, C.cast(f["reduce_scatter"], C.c_void_p), C.cast(f["all_gather"], C.c_void_p), None, rank, world))
+    return install
+
+
+def _threads(world, target, args_of_rank):
+    errors = []
+    threads = [threading.Thread(target=target, args=args_of_rank(r) + (errors,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    return errors, any(t.is_alive() for t in threads)
+
+
+def _run_rank_recapture(rank, world, install, out, errors):
+    try:
+        P, _, W, H = SMALL
+        s, cams, fw, fb, host = _scene(SMALL)
+        tr = gs.Trainer(W, H)
+        tr.model = gs.ModelSplatsDevice(host)
+        tr.captureTruths(cams, fw, fb)
+        tr.shard(rank, world)
+        if install is not None:
+            install(tr, rank, cams)
+        still = gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0)
+        tr.train(still)
+        g0 = _grad_planes(tr, P)
+        # the reference re-rotates the camera rig and re-captures every intervalCapture iterations (src/ui/UiFrame.cpp:279-290,
+        # driver.AutoTrainer.step): other positions, other fields of view — and nobody touches the exchange
+        moved = gs.camera.get_cameras_project(_rotated_project())
+        tr.captureTruths(moved, fw, fb)
+        tr.train(still)
+        out[rank] = (g0, _grad_planes(tr, P))
+        tr.close()
+    except BaseException as e:      # noqa: BLE001
+        errors.append((rank, repr(e)))
+        raise
+
+
+def _rotated_project():
+    pr = gs.Project.initProject()
+    pr.sphere1.count, pr.sphere1.distance, pr.sphere1.fovDeg, pr.sphere1.rotX, pr.sphere1.rotY = N_CAMS, 8.0, 52.0, 133.0, 71.0
+    return pr
+
+
+def test_recapture_with_moved_cameras_under_a_live_compact_exchange():
+    """Round-4 advice: the compact exchange rebuilt the SH planes from camera positions stored when it was INSTALLED; after a
+    re-capture with re-rotated cameras every rank silently used stale view directions.  The positions now travel with the records
+    (a header in every rank's chunk of the all-gather): the step after a re-capture must give the single-GPU SH gradients bit for bit."""
+    world = WORLD
+    coll = HostCollectives(world)
+    out = [None] * world
+    errors, alive = _threads(world, _run_rank_recapture, lambda r: (r, world, _install(coll, "compact", world), out))
+    if errors or alive:
+        coll.bar.abort()
+    assert not errors and not alive, errors
+    single = [None]
+    _run_rank_recapture(0, 1, None, single, [])
+    s0, s1 = single[0]
+    sh = slice(3, 3 + 3 * M)
+    assert not np.array_equal(s0[sh], s1[sh])          # the move changed the SH gradients
+    for g0, g1 in out:
+        assert np.array_equal(g0[sh].view(np.uint32), s0[sh].view(np.uint32))
+        assert np.array_equal(g1[sh].view(np.uint32), s1[sh].view(np.uint32))     # (stale positions: differs in nearly every entry)
+        for pl in [0, 1, 2] + list(range(3 + 3 * M, 11 + 3 * M)):
+            assert np.abs(g1[pl] - s1[pl]).max() <= 2e-6 * np.abs(s1[pl]).max() + 1e-30, pl
+
+
+def _run_rank_sweep(rank, world, install, scene, out, errors):
+    try:
+        s, cams, views, fw, fb, W, H = scene
+        P, Msw = s["count"], s["M"]
+        host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+        host.shDegree = s["D"]
+        host.capacity = P + P // 5 + 8
+        tr = gs.Trainer(W, H)
+        tr.model = gs.ModelSplatsDevice(host)
+        tr.captureTruths(cams, fw, fb, view_blocks=views)
+        tr.shard(rank, world)
+        if install is not None:
+            install(tr, rank, cams)
+        still = gs.Project(lrLocation=0.0, lrSh=0.0, lrScale=0.0, lrOpacity=0.0, lrRotation=0.0)
+
+        def planes():
+            ptr, n = tr.grad_buffer()
+            tr.synchronize()
+            buf = np.empty(n, np.float32)
+            capi.check(capi.lib().gs_memcpy_d2h(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n * 4))
+            return buf.reshape(12 + 3 * Msw, -1)[:, :P].copy()
+        tr.train(still)
+        g_fused = planes()
+        tr.set_option("fuse_camera_passes", 0)
+        tr.train(still)
+        g_pass = planes()
+        tr.set_option("fuse_camera_passes", 1)
+        proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=1e-3, lrSh=2e-3, lrScale=5e-4, lrOpacity=1e-3, lrRotation=1e-3,
+                          paramDensifyVariance=0.05, paramCullOpacity=0.15, paramSplitSize=0.06)
+        for k in range(3):
+            tr.train(proj, densify=(k == 1))
+        h = gs.ModelSplatsHost.fromDevice(tr.model)
+        n = h.count
+        model = np.concatenate([h.locations[:3 * n], h.shs[:3 * Msw * n], h.scales[:3 * n], h.opacities[:n], h.rotations[:4 * n]])
+        out[rank] = (g_fused, g_pass, model)
+        tr.close()
+    except BaseException as e:      # noqa: BLE001
+        errors.append((rank, repr(e)))
+        raise
+
+
+@pytest.mark.parametrize("seed", [3, 9, 21, 33, 50])
+@pytest.mark.parametrize("form", ["compact", "allreduce", "sharded"])
+def test_sweep_scenes_through_the_world_harness(orc, seed, form):
+    """Scenes of tests/test_gpu_sweep.py — clusters / shells / slabs of anisotropic splats, ragged image sizes, random backgrounds on
+    every pass (odd seeds), ODD camera counts — through all three data-parallel forms, on as many ranks as the form's layout
+    contract admits (the compact exchange and camera sharding need a camera per rank; with fewer cameras than ranks the passes are dealt
+    one by one and the all-reduce / sharded forms still apply).  Against the one trainer that owns every camera: SH planes bit for bit
+    under the compact exchange, every plane within 2e-6 of its scale, replicas bit-identical through Adam steps and a densify."""
+    from test_gpu_sweep import wild_scene
+    rng = np.random.default_rng(0xD157 + seed)
+    s, kind = wild_scene(rng, big=(seed == 50))
+    P, Msw = s["count"], s["M"]
+    W, H = int(rng.integers(40, 200)), int(rng.integers(40, 200))
+    n_cams = int(rng.choice([3, 5, 7, 9, 11]))
+    pr = gs.Project.initProject()
+    pr.sphere1.count, pr.sphere1.distance, pr.sphere1.fovDeg = n_cams, float(rng.uniform(5.0, 11.0)), float(rng.uniform(35.0, 80.0))
+    pr.sphere1.rotX, pr.sphere1.rotY = float(rng.uniform(0, 360)), float(rng.uniform(0, 360))
+    cams = gs.camera.get_cameras_project(pr)
+    views = gs.camera.train_views(cams, W, H)
+    if seed % 2:      # random backgrounds; the two passes of a camera still share the camera (the compact exchange's layout contract)
+        views[:, 37:40] = rng.uniform(0.0, 1.0, (2 * n_cams, 3)).astype(np.float32)
+    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(n_cams)]
+    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(n_cams)]
+    scene = (s, cams, views, fw, fb, W, H)
+    world = min(WORLD, n_cams) if form == "compact" else WORLD
+    coll = HostCollectives(world)
+    out = [None] * world
+    errors, alive = _threads(world, _run_rank_sweep, lambda r: (r, world, _install(coll, form, world), scene, out))
+    if errors or alive:
+        coll.bar.abort()
+    assert not errors and not alive, errors
+    single = [None]
+    _run_rank_sweep(0, 1, None, scene, single, [])
+    sf, sp, smodel = single[0]
+    sh = slice(3, 3 + 3 * Msw)
+    for g_fused, g_pass, model in out:
+        assert np.array_equal(model.view(np.uint32), out[0][2].view(np.uint32))       # bit-identical replicas
+        if form == "compact":
+            assert np.array_equal(g_fused[sh].view(np.uint32), sf[sh].view(np.uint32))
+            assert np.array_equal(g_pass[sh].view(np.uint32), sp[sh].view(np.uint32))
+        if form != "sharded":     # (the sharded form leaves the sums in the rank's own chunk only)
+            for got, want in ((g_fused, sf), (g_pass, sp)):
+                for pl in range(11 + 3 * Msw):
+                    assert np.abs(got[pl] - want[pl]).max() <= 4e-6 * np.abs(want[pl]).max() + 1e-30, (pl, kind)
+    k = min(300, smodel.size, out[0][2].size)
+    assert np.abs(smodel[:k] - out[0][2][:k]).max() < 1e-2           # next to the single trainer's parameters
+    print(f"[world {world}, {form}] sweep scene {seed} ({kind}, {P} splats, M={Msw}, {n_cams} cameras @{W}x{H}): {out[0][2].size // (11 + 3 * Msw)} splats after densify, replicas identical")
