@@ -194,8 +194,18 @@ def main():
     if use_dist:
         from gsplat_amd import dist as gsdist
         if collective == "auto":
-            collective = "torch-compact" if gsdist.choose_exchange(n_cams, world, M) == "compact" else "torch"
-            collective_note = f"auto -> {collective}"
+            # The exchange form by the bytes it moves (gsdist.choose_exchange); its collectives by the library's OWN RCCL communicators
+            # (gs_comm_*: ncclAllReduce / ncclAllGather enqueued from C on the trainer's streams — no Python inside the step) wherever
+            # librccl loads on EVERY rank, else through torch.distributed (a ctypes -> Python callback per collective and step).
+            form = gsdist.choose_exchange(n_cams, world, M)
+            ident = (C.c_char * capi.GS_COMM_ID_BYTES)()
+            native = L.gs_comm_unique_id(ident) == 0      # local probe: loads librccl, creates nothing
+            why = None if native else capi.last_error()
+            flag = torch.tensor([1 if native else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)    # CPU tensor: gloo under the mixed backend
+            native = bool(int(flag[0])) and "nccl" in args.dist_backend     # (a gloo rehearsal on one GPU has no second device for RCCL)
+            collective = ("rccl" if native else "torch") + ("-compact" if form == "compact" else "")
+            collective_note = f"auto -> {collective}" + ("" if native else f" (native RCCL hooks not usable on every rank: {why or 'another rank, or a gloo rehearsal'})")
         if collective.endswith("compact") and n_cams < world:
             collective, collective_note = "torch", f"{collective} needs at least one camera per rank ({n_cams} cameras, {world} ranks): all-reduce instead"
         # with --exchange-overlap the all-reduce of the compact exchange runs beside its all-gather: a process group (communicator) of its own
@@ -353,9 +363,12 @@ def main():
     DOM_STAGE = 5
     capi.check(L.gs_trainer_set_profiling(tr.handle, 0 if args.no_stage_events else (1 << (DOM_STAGE + 1))))
     sync_all()
+    host_us = []
     t_start = time.perf_counter()
     for _ in range(args.steps):
+        t_h = time.perf_counter()
         tr.train(proj, densify=False)
+        host_us.append((time.perf_counter() - t_h) * 1e6)
     sync_all()
     elapsed = time.perf_counter() - t_start
     ms = (C.c_double * capi.GS_STAGE_COUNT)()
@@ -457,6 +470,15 @@ def main():
                       "render_forward": n_groups * 40 * R_mean + V_local * 12 * N + n_groups * 8 * N}.get(dom, dom_bytes)
         step_bytes = sum(stage_bytes(k, P, M, N, R_mean, V_local) for k in kern) + (48 + 12 * M) * P
         step_form_bytes = sum(stage_form_bytes(k, P, M, N, R_mean, V_local, n_groups) for k in kern)
+        update_fused = "update" not in kern and "splat_backward" in kern
+        if update_fused:     # no update launch: the per-splat reduction applied it (its bytes are part of that stage's time)
+            step_bytes += stage_bytes("update", P, M, N, R_mean, V_local)
+            step_form_bytes += stage_form_bytes("update", P, M, N, R_mean, V_local, n_groups)
+        # what this box's HBM sustains for a streaming copy ("state both"): 1 GiB, float4 per lane, fastest of 5 launches
+        peak_measured = C.c_double(0.0)
+        if L.gs_debug_hbm_copy_rate(1 << 30, 5, C.byref(peak_measured)) != 0:
+            peak_measured = C.c_double(0.0)
+        peak_measured = float(peak_measured.value) or None
         ms_per_step = elapsed / args.steps * 1e3
         # Counters of the dominant kernel (rocprofv3 --pmc passes of the same command, tools/pmc_pass.sh, committed as
         # profiles/pmc_latest.json).  They are only reported when they were collected from the kernel sources this run
@@ -535,9 +557,23 @@ def main():
                          "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "step_form_GB": step_form_bytes / 1e9,
                          "step_frac_form": step_form_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "peak_measured": peak_measured,
+                         "peak_measured_note": "GB/s (read + written) of a 1 GiB float4 streaming copy on this device right after the run (gs_debug_hbm_copy_rate, fastest of 5): "
+                                               "the achievable HBM ceiling; the *_measured fractions below divide by it instead of the 8 TB/s specification",
+                         "frac_measured": None if not peak_measured else achieved / peak_measured,
+                         "frac_form_measured": None if not peak_measured else form_bytes / (dom_ms * 1e-3) / 1e9 / peak_measured,
+                         "step_frac_measured": None if not peak_measured else step_bytes / (ms_per_step * 1e-3) / 1e9 / peak_measured,
+                         "step_frac_form_measured": None if not peak_measured else step_form_bytes / (ms_per_step * 1e-3) / 1e9 / peak_measured,
                          "step_note": "step_frac prices SURVEY 8d's per-VIEW bytes x the views of the step although projection, lists, forward blend and "
                                       "the backward ran once per CAMERA; step_frac_form prices the bytes of the form that ran, every stage: the stricter figure"},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
+            "update_fused_into_splat_backward": update_fused,
+            "host": {"enqueue_us_per_step_mean": float(np.mean(host_us)), "enqueue_us_per_step_min": float(np.min(host_us)), "enqueue_us_per_step_max": float(np.max(host_us)),
+                     "gpu_us_per_step": ms_per_step * 1e3,
+                     "note": "wall time of the gs_trainer_step call on rank 0 (Python wrapper + C enqueue + the one early wait on the arena-overflow flags; a call that "
+                             "finds the stream's queue full also waits there), timed region; the host must stay below gpu_us_per_step for the device never to idle"},
+            "metric_definition": "v2 (rounds 4+): EXACTLY K timed steps after W warm-up steps, preceded by a ~1 s untimed pre-warm of the same workload and a model reset "
+                                 "(sustained clocks); v1 (rounds 1-3) timed the same K steps right after setup — that figure is `cold_start` here",
             "stages_note": "all-stage table: HIP events over %d extra steps run after the timed region (timing every stage costs ~3 us of stream time per event)" % min(args.steps, 10),
             "cold_start": cold_start,
             "prewarm": prewarm,

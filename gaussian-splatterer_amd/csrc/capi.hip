@@ -33,6 +33,7 @@ struct Options {
     int sh_fp16 = 0;     // the projection reads SH coefficients from a half-precision copy (BASELINE cfg5); fp32 master and gradients
     int long_sort = -1;  // k_tile_sort_long launch: -1 by the longest-list hint (default), 0 never (lists take the global-scratch path), 1 always
     int sort_grids = -1; // test hook: >= 0 replaces the device's hint for the sort grids: small_first | mid_grid << 16 (in tiles)
+    int fuse_update = 1;  // a step with no collective between gradients and update applies the update inside the per-splat reduction (no update launch)
     int xchg_overlap = 1; // compact exchange: the all-reduce of the geometry planes runs on a second stream beside the all-gather (0: one after the other)
     int row_marks = -1;   // gradient rows only for evaluated entries (row_epoch marks): -1 per camera by its longest tile list (from 1024 entries), 0 never, 1 always
     int reuse_masks = 1;  // the backward reuses the forward's per-(tile sub-block, wave) block ballots; 0: it runs the block test itself (same bits)
@@ -50,6 +51,7 @@ static bool set_option(Options& o, const char* name, int value) {
     if (strcmp(name, "long_list_sort_launch") == 0) { o.long_sort = value < 0 ? -1 : (value != 0); return true; }
     if (strcmp(name, "debug_sort_grids") == 0) { o.sort_grids = value < 0 ? -1 : value; return true; }
     if (strcmp(name, "exchange_overlap") == 0) { o.xchg_overlap = value != 0; return true; }
+    if (strcmp(name, "fuse_update") == 0) { o.fuse_update = value != 0; return true; }
     if (strcmp(name, "roctx") == 0) { o.roctx = value != 0; return true; }
     if (strcmp(name, "reuse_hit_masks") == 0) { o.reuse_masks = value != 0; return true; }
     if (strcmp(name, "row_marks") == 0) { o.row_marks = value < 0 ? -1 : (value != 0); return true; }
@@ -345,6 +347,40 @@ extern "C" int gs_debug_counters(unsigned long long out[8], int reset) {
     if (!out) return GS_ERR_INVALID_ARGUMENT;
     GS_TRY(require_device());
     return debug_counters(out, reset != 0);
+}
+
+extern "C" int gs_debug_hbm_copy_rate(size_t bytes, int repeats, double* gbytes_per_s) {
+    if (!gbytes_per_s || bytes < 16 || (bytes & 15) || repeats < 1 || repeats > 1000) { set_error("gs_debug_hbm_copy_rate: bad arguments"); return GS_ERR_INVALID_ARGUMENT; }
+    GS_TRY(require_device());
+    void *a = nullptr, *b = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = GS_OK;
+    double best_ms = 0.0;
+    auto fail = [&](const char* what, hipError_t e) { set_error("gs_debug_hbm_copy_rate: %s: %s", what, hipGetErrorString(e)); rc = e == hipErrorOutOfMemory ? GS_ERR_OUT_OF_MEMORY : GS_ERR_HIP; };
+    hipError_t e = hipMalloc(&a, bytes);
+    if (e == hipSuccess) e = hipMalloc(&b, bytes);
+    if (e != hipSuccess) fail("hipMalloc", e);
+    if (rc == GS_OK && (e = hipMemset(a, 0x3c, bytes)) != hipSuccess) fail("hipMemset", e);
+    if (rc == GS_OK && (e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) fail("hipStreamCreate", e);
+    if (rc == GS_OK && ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess)) fail("hipEventCreate", e);
+    for (int k = 0; rc == GS_OK && k <= repeats; k++) {   // k = 0: warm-up (first touch of the destination)
+        (void)hipEventRecord(e0, st);
+        rc = launch_copy_probe(a, b, bytes, st);
+        (void)hipEventRecord(e1, st);
+        if (rc == GS_OK && (e = hipEventSynchronize(e1)) != hipSuccess) fail("hipEventSynchronize", e);
+        float ms = 0.0f;
+        if (rc == GS_OK && (e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) fail("hipEventElapsedTime", e);
+        if (rc == GS_OK && k > 0 && ms > 0.0f && (best_ms == 0.0 || ms < best_ms)) best_ms = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (rc != GS_OK) return rc;
+    *gbytes_per_s = best_ms > 0.0 ? 2.0 * (double)bytes / (best_ms * 1e-3) / 1e9 : 0.0;
+    return GS_OK;
 }
 
 extern "C" int gs_hyper_defaults(gs_hyper* h) {
@@ -722,7 +758,12 @@ static int resolve_stats(gs_trainer* t) {
 // return the stream is still busy.  An overflowing arena is grown and the iteration replayed.
 // xchg != null (compact exchange): the per-splat stage leaves the rank's share of the exchange in *xchg's buffers instead of
 // gradient planes (k_sh_rebuild writes those after the collectives); xchg->slots is set here for the form the step takes.
-static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullptr) {
+// fuse_h != null (gs_trainer_step without a collective): the update is applied by the per-splat reduction of the same attempt (FusedUpdate);
+// *update_applied says whether it was (a step with ONE record per splat runs the chain and the reduction in one kernel, which reads
+// the parameters it would have to write: that form keeps the update launch).
+static int prepare_adam(gs_trainer* t, const gs_hyper* h);
+static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullptr, const gs_hyper* fuse_h = nullptr, bool* update_applied = nullptr) {
+    if (update_applied) *update_applied = false;
     if (t->V == 0 && t->total_samples <= 0) { set_error("Can't run training iteration, no truth data available!"); return GS_ERR_NO_TRUTH; }
     if (!t->model) return GS_ERR_NO_MODEL;
     GS_HIP(hipSetDevice(t->device));
@@ -862,8 +903,17 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
             GS_TRY(debug_check(t, 5));
             prof_stage_begin(t, 6, 5);
             if (xchg) xchg->slots = ((t->xchg_cameras + t->xchg_world - 1) / t->xchg_world) * (fuse ? 1 : 2);
+            FusedUpdate fu;
+            if (fuse_h) {
+                GS_TRY(prepare_adam(t, fuse_h));      // moments allocated and zeroed on the first Adam step; the step counter moves after the attempt
+                fu.u = make_update_args(pl, *fuse_h, t->adam_t + 1);
+                fu.params = m->planes; fu.am = t->adam_m.as<float>(); fu.av = t->adam_v.as<float>();
+                fu.sh16 = (t->opt.sh_fp16 && t->sh16_of == (const void*)m->planes) ? t->sh16.as<uint16_t>() : nullptr;
+            }
+            bool applied = false;
             GS_TRY(launch_splat_backward_avg(d, m->planes, s, (float)t->total_samples, t->grad.as<float>(), items, t->bwd_pairs,
-                                             t->bwd_singles, fuse, t->stream, xchg));
+                                             t->bwd_singles, fuse, t->stream, xchg, fuse_h ? &fu : nullptr, &applied));
+            if (update_applied) *update_applied = applied;
             prof_stage_end(t, 6);
             GS_TRY(debug_check(t, 6));
         }
@@ -886,6 +936,11 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
     t->stats_stale = true;
     t->accumulated = true;
     t->steps_on_these_lists++;
+    if (update_applied && *update_applied) {   // the attempt that went through applied the update (an overflowed one applies nothing: k_splat_bwd_reduce)
+        if (fuse_h->update_rule == GS_UPDATE_ADAM) t->adam_t++;
+        if (!(t->opt.sh_fp16 && t->sh16_of == (const void*)m->planes)) t->sh16_of = nullptr;
+        t->accumulated = false;
+    }
     return GS_OK;
 }
 
@@ -970,9 +1025,9 @@ static int trainer_densify(gs_trainer* t, const gs_hyper* h, gs_step_stats* st) 
 
 // The parameter update on the flat element range [lo, hi) of the planes (everything by default): Adam state is created
 // on first use and its step counter advanced once per call.
-static int apply_update(gs_trainer* t, const gs_hyper* h, int stage_before, size_t lo = 0, size_t hi = ~(size_t)0) {
+// Adam moments exist from the first Adam step on (zeroed, step counter 0); any other rule but the reference's is refused.
+static int prepare_adam(gs_trainer* t, const gs_hyper* h) {
     gs_model* m = t->model;
-    const Planes pl{ m->sh_coeffs };
     if (h->update_rule == GS_UPDATE_ADAM) {
         const size_t bytes = plane_buffer_floats(m->sh_coeffs, m->Pa) * 4;
         if (!t->adam_valid) {
@@ -981,11 +1036,17 @@ static int apply_update(gs_trainer* t, const gs_hyper* h, int stage_before, size
             GS_HIP(hipMemsetAsync(t->adam_v.p, 0, bytes, t->stream));
             t->adam_valid = true; t->adam_t = 0;
         }
-        t->adam_t++;
     } else if (h->update_rule != GS_UPDATE_SGD_CLAMP) {
         set_error("unknown update rule %d", h->update_rule);
         return GS_ERR_INVALID_ARGUMENT;
     }
+    return GS_OK;
+}
+static int apply_update(gs_trainer* t, const gs_hyper* h, int stage_before, size_t lo = 0, size_t hi = ~(size_t)0) {
+    gs_model* m = t->model;
+    const Planes pl{ m->sh_coeffs };
+    GS_TRY(prepare_adam(t, h));
+    if (h->update_rule == GS_UPDATE_ADAM) t->adam_t++;
     prof_stage_begin(t, 7, stage_before);
     // the update keeps the fp16 SH copy current for the elements it touches; a partial (sharded) update leaves the other
     // ranks' chunks to the all-gather, so the copy is rebuilt before the next projection
@@ -1141,7 +1202,18 @@ extern "C" int gs_trainer_step(gs_trainer* t, const gs_hyper* h, int densify, gs
     // `var` (accumulateGradients, src/Trainer.cu:52) is read by the densify block of the same iteration only (:444,453)
     // and starts from zero every iteration (:304-309): a step without densify does not need per-pass gradients
     if (t->xchg_gather && t->xchg_reduce) return step_compact_exchange(t, h, densify, stats);
-    GS_TRY(accumulate_async(t, densify != 0));
+    // no collective between the gradients and the update: the per-splat reduction applies the update itself (north_star: "fused Adam update")
+    const bool fuse_update = t->opt.fuse_update && !t->allreduce && !(t->shard_rs && t->shard_ag);
+    bool update_applied = false;
+    GS_TRY(accumulate_async(t, densify != 0, nullptr, fuse_update ? h : nullptr, &update_applied));
+    if (update_applied) {
+        if (densify) {
+            GS_TRY(resolve_stats(t));
+            GS_TRY(trainer_densify(t, h, &t->last));
+        }
+        if (stats) { GS_TRY(resolve_stats(t)); *stats = t->last; }
+        return GS_OK;
+    }
     if (t->shard_rs && t->shard_ag) {
         // Data-parallel sharded update: every rank ends up with the sum of its own chunk of the gradient buffer only
         // (reduce-scatter), updates that chunk of the parameters (and keeps Adam moments for that chunk only up to date),

@@ -190,8 +190,10 @@ struct Exchange {
     int hdr = 0;           // floats in front of a rank's records: 3 * ceil(cameras / world) rounded up to 64 (the planes stay 256-byte aligned)
 };
 inline int exchange_header_floats(int n_cameras, int world) { return ((3 * ((n_cameras + world - 1) / world)) + 63) / 64 * 64; }
+struct FusedUpdate;
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad_planes, const int* items,
-                              int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st, const Exchange* x = nullptr);
+                              int n_pairs, int n_singles, bool fuse_pairs, hipStream_t st, const Exchange* x = nullptr,
+                              const FusedUpdate* fu = nullptr, bool* update_applied = nullptr);
 // after the exchange: every averaged-gradient plane from the reduced geometry planes and the gathered dL_dRGB + camera positions
 // parts: 1 = the SH planes (from the gathered records), 2 = the twelve other planes (from the reduced sums), 3 = both
 int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, int n_cameras, bool per_pass, float samples,
@@ -199,6 +201,50 @@ int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, int
 // Seam form: one view, reference-shaped AoS outputs with the reference's += / = discipline.
 struct SeamGrads { float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot; };
 int launch_splat_backward_seam(const Dims& d, const float* params, const Scratch& s, const SeamGrads& g, hipStream_t st);
+// applyGradients (src/Trainer.cu:81-101) / the Adam extension for ONE element: the same fp32 operations wherever they run — the
+// update launch (k_update.hip) and the fused form inside the per-splat reduction (k_splat_bwd.hip, k_splat_bwd_reduce<D, true>).
+struct UpdateArgs {
+    float lr_loc, lr_sh, lr_scale, lr_opac, lr_rot, scale_max;
+    int rule;
+    float b1, b2, eps, bc1, bc2;
+    int M;
+};
+UpdateArgs make_update_args(const Planes& pl, const gs_hyper& h, int adam_t);
+#ifdef __HIPCC__
+// kind: 0 plain, 1 scale clamp, 2 opacity clamp
+__device__ inline void update_plane_rule(const UpdateArgs& u, const Planes& pl, int p, float& lr, int& kind) {
+    if (p < 3) { lr = u.lr_loc; kind = 0; }
+    else if (p < pl.scale(0)) { lr = u.lr_sh; kind = 0; }
+    else if (p < pl.opac()) { lr = u.lr_scale; kind = 1; }
+    else if (p == pl.opac()) { lr = u.lr_opac; kind = 2; }
+    else { lr = u.lr_rot; kind = 0; }
+}
+__device__ inline float update_element(const UpdateArgs& u, float lr, int kind, float x, float g, float* am, float* av, size_t idx) {
+    if (u.rule == GS_UPDATE_ADAM) {
+        float m = am[idx], v = av[idx];
+        m = u.b1 * m + (1.0f - u.b1) * g;
+        v = u.b2 * v + (1.0f - u.b2) * g * g;
+        am[idx] = m; av[idx] = v;
+        const float mh = m / u.bc1, vh = v / u.bc2;
+        x = x + lr * (mh / (sqrtf(vh) + u.eps));
+    } else {
+        x = x + g * lr;
+    }
+    if (kind == 1) x = fminf(u.scale_max, fmaxf(0.0f, x));
+    else if (kind == 2) x = fminf(1.0f, fmaxf(0.0f, x));
+    return x;
+}
+#endif
+// The update fused into the per-splat reduction of a step that has no collective between the two (north_star: "fused Adam update"):
+// the thread that has just formed a splat's averaged gradients applies them — the gradient planes are still stored (tests,
+// gs_trainer_grad_buffer, densify read them) but not read back, and the update launch is gone.  The arena-overflow verdict of the
+// step is on the device by then (Scratch::flags): an attempt that overflowed applies nothing, the host replays it.
+struct FusedUpdate {
+    UpdateArgs u;
+    float* params = nullptr;   // null: not fused
+    float *am = nullptr, *av = nullptr;
+    uint16_t* sh16 = nullptr;
+};
 // updates the flat element range [lo, hi) of the parameter planes (default: all of them)
 // sh16 != null: the fp16 read copy of every SH element this launch updates is refreshed in the same pass
 int launch_update(const Planes& pl, int P, int Pa, float* params, float* grads, float* adam_m, float* adam_v, int adam_t,
@@ -220,6 +266,7 @@ int launch_aos_to_soa(int P, int Pa, int M, const float* loc, const float* sh, c
                       const float* rot, float* planes, hipStream_t st);
 int launch_soa_to_aos(int P, int Pa, int M, const float* planes, float* loc, float* sh, float* scale, float* opac,
                       float* rot, hipStream_t st);
+int launch_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t st);
 int launch_image_float_to_int(const float* src, uint32_t* fb, int w, int h, hipStream_t st);
 int launch_image_int_to_loss(const uint32_t* truth, const float* rast, float* loss, int w, int h, hipStream_t st);
 int launch_ranges(const Dims& d, const Scratch& s, uint32_t* ranges, hipStream_t st);

@@ -6,6 +6,8 @@
 // (src/Trainer.cu:47-77): one thread owns one splat, walks the views in the reference's order,
 // sums that splat's (splat,tile) gradient rows (contiguous slots, fixed order), and writes every
 // averaged-gradient plane exactly once per step — no per-view read-modify-write, no atomics.
+#include <hip/hip_fp16.h>
+
 #include "gs_internal.h"
 #include "sh_jac.h"
 
@@ -450,14 +452,19 @@ __global__ __launch_bounds__(WG) GS_SBV_ATTR void k_splat_bwd_view(Dims d, const
 // basis(view direction) x dL_dRGB.  Every gradient plane is written exactly once per step.
 // n_fused_items > 0: the records are one per work item (the pair's summed gradient, at the item's first pass) and
 // `var`, which needs every pass's own location gradient, is written as zero (see render_bwd in k_render.hip).
-template <int D>
-__global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __restrict__ params, Scratch s, float samples,
+// UPD (a step with no collective between the reduction and the update): the thread applies the splat's update itself, plane by plane,
+// with update_element — k_update's operations on the value k_update would have read back from the gradient plane.  Every parameter
+// plane is updated, the SH planes beyond the model's degree with their zero gradient (Adam moves on a zero gradient too).  All
+// parameter reads of this kernel go through fu.params (it writes them).
+template <int D, bool UPD>
+__global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __restrict__ params_ro, Scratch s, float samples,
                                                          const float4* __restrict__ rec_in, float* __restrict__ grad,
-                                                         const int* __restrict__ items, int n_fused_items) {
+                                                         const int* __restrict__ items, int n_fused_items, FusedUpdate fu) {
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
+    const float* params = UPD ? (const float*)fu.params : params_ro;
     const float mx = params[pl.loc(0) * st + i], my = params[pl.loc(1) * st + i], mz = params[pl.loc(2) * st + i];
     GradAcc<D> acc;
     const int n_rec = n_fused_items > 0 ? n_fused_items : d.V;
@@ -467,6 +474,34 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __
         acc.add(r[0], r[1], r[2], r[3], samples, mx, my, mz, s.views[v].campos);
     }
     acc.store(grad, pl, st, i, d.M, n_fused_items > 0);
+    if constexpr (UPD) {
+        // an attempt whose binning arena overflowed is replayed by the host with a larger one: it must not move the model
+        uint32_t overflow = 0;
+        for (int g = 0; g < d.VG; g++) overflow |= s.flags[g * 4 + 0] & 1u;
+        if (overflow) return;
+        constexpr int NC = GradAcc<D>::NC;
+        auto upd = [&](int p, float g) {
+            float lr; int kind;
+            update_plane_rule(fu.u, pl, p, lr, kind);
+            const size_t idx = (size_t)p * st + i;
+            const float x = update_element(fu.u, lr, kind, fu.params[idx], g, fu.am, fu.av, idx);
+            fu.params[idx] = x;
+            if (fu.sh16 && p >= 3 && p < pl.scale(0)) reinterpret_cast<__half*>(fu.sh16)[(size_t)(p - 3) * st + i] = __float2half_rn(x);
+        };
+#pragma unroll
+        for (int c = 0; c < 3; c++) upd(pl.loc(c), acc.aLoc[c]);
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) upd(pl.sh(k, c), acc.aSh[k][c]);
+        for (int k = NC; k < d.M; k++)
+            for (int c = 0; c < 3; c++) upd(pl.sh(k, c), 0.0f);
+#pragma unroll
+        for (int c = 0; c < 3; c++) upd(pl.scale(c), acc.aScale[c]);
+        upd(pl.opac(), acc.aOpac);
+#pragma unroll
+        for (int c = 0; c < 4; c++) upd(pl.rot(c), acc.aRot[c]);
+    }
 }
 
 // The compact data-parallel exchange (capi.hip, gs_trainer_set_compact_exchange), rank side: the rank's records are summed into
@@ -551,7 +586,7 @@ __global__ __launch_bounds__(WG) void k_sh_rebuild(Dims d, const float* __restri
 // x != null: the compact exchange's rank side (the rank holds whole cameras: n1 == 0); grad is not written
 template <int D>
 static void launch_splat_avg_d(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, const int* items, int n2,
-                               int n1, bool fuse, const Exchange* x, hipStream_t stream) {
+                               int n1, bool fuse, const Exchange* x, hipStream_t stream, const FusedUpdate* fu, bool* update_applied) {
     const int bx = (d.P + WG - 1) / WG;
     float4* rec = reinterpret_cast<float4*>(s.splat_grads);
     fuse = fuse && n2 > 0;
@@ -563,18 +598,24 @@ static void launch_splat_avg_d(const Dims& d, const float* params, const Scratch
     }
     if (ny > 0) hipLaunchKernelGGL((k_splat_bwd_view<D, false>), dim3(bx, ny), dim3(WG), 0, stream, d, params, s, rec, items, n2, fuse ? 1 : 0, samples, grad, none);
     if (x) hipLaunchKernelGGL(k_exchange_pack, dim3(bx), dim3(WG), 0, stream, d, s, samples, (const float4*)rec, *x, items, fuse ? n2 : 0);
-    else hipLaunchKernelGGL(k_splat_bwd_reduce<D>, dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
-                            fuse ? n2 + n1 : 0);
+    else if (fu && fu->params) {
+        hipLaunchKernelGGL((k_splat_bwd_reduce<D, true>), dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
+                           fuse ? n2 + n1 : 0, *fu);
+        if (update_applied) *update_applied = true;
+    } else hipLaunchKernelGGL((k_splat_bwd_reduce<D, false>), dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
+                              fuse ? n2 + n1 : 0, FusedUpdate{});
 }
 
 int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch& s, float samples, float* grad, const int* items,
-                              int n_pairs, int n_singles, bool fuse_pairs, hipStream_t stream, const Exchange* x) {
+                              int n_pairs, int n_singles, bool fuse_pairs, hipStream_t stream, const Exchange* x, const FusedUpdate* fu,
+                              bool* update_applied) {
+    if (update_applied) *update_applied = false;
     if (d.P == 0) return GS_OK;
     switch (d.D) {
-        case 0: launch_splat_avg_d<0>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream); break;
-        case 1: launch_splat_avg_d<1>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream); break;
-        case 2: launch_splat_avg_d<2>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream); break;
-        default: launch_splat_avg_d<3>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream); break;
+        case 0: launch_splat_avg_d<0>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream, fu, update_applied); break;
+        case 1: launch_splat_avg_d<1>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream, fu, update_applied); break;
+        case 2: launch_splat_avg_d<2>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream, fu, update_applied); break;
+        default: launch_splat_avg_d<3>(d, params, s, samples, grad, items, n_pairs, n_singles, fuse_pairs, x, stream, fu, update_applied); break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

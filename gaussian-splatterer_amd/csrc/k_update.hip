@@ -12,13 +12,6 @@
 
 namespace gs {
 
-struct UpdateArgs {
-    float lr_loc, lr_sh, lr_scale, lr_opac, lr_rot, scale_max;
-    int rule;
-    float b1, b2, eps, bc1, bc2;
-    int M;
-};
-
 // [lo, hi): the flat element range (plane * Pa + splat) this launch owns — everything on one GPU, the rank's chunk
 // under the data-parallel sharded update; blockIdx.y counts planes from the first one the range touches.
 __global__ __launch_bounds__(WG) void k_update(UpdateArgs u, int P, int Pa, float* __restrict__ params,
@@ -30,32 +23,28 @@ __global__ __launch_bounds__(WG) void k_update(UpdateArgs u, int P, int Pa, floa
     if (i >= P) return;
     if ((size_t)p * Pa + i < lo || (size_t)p * Pa + i >= hi) return;
     const Planes pl{ u.M };
-    // plane group -> learning rate / clamp
-    float lr; int kind;  // 0 plain, 1 scale clamp, 2 opacity clamp
-    if (p < 3) { lr = u.lr_loc; kind = 0; }
-    else if (p < pl.scale(0)) { lr = u.lr_sh; kind = 0; }
-    else if (p < pl.opac()) { lr = u.lr_scale; kind = 1; }
-    else if (p == pl.opac()) { lr = u.lr_opac; kind = 2; }
-    else { lr = u.lr_rot; kind = 0; }
+    float lr; int kind;
+    update_plane_rule(u, pl, p, lr, kind);
     const size_t idx = (size_t)p * Pa + i;
-    const float g = grads[idx];
-    float x = params[idx];
-    if (u.rule == GS_UPDATE_ADAM) {
-        float m = am[idx], v = av[idx];
-        m = u.b1 * m + (1.0f - u.b1) * g;
-        v = u.b2 * v + (1.0f - u.b2) * g * g;
-        am[idx] = m; av[idx] = v;
-        const float mh = m / u.bc1, vh = v / u.bc2;
-        x = x + lr * (mh / (sqrtf(vh) + u.eps));
-    } else {
-        x = x + g * lr;
-    }
-    if (kind == 1) x = fminf(u.scale_max, fmaxf(0.0f, x));
-    else if (kind == 2) x = fminf(1.0f, fmaxf(0.0f, x));
+    const float x = update_element(u, lr, kind, params[idx], grads[idx], am, av, idx);
     params[idx] = x;
     // trainer option "sh_fp16": the projection reads the SH coefficients from a half-precision copy (BASELINE cfg5);
     // the fp32 master above stays the optimiser's state — a learning rate of 1e-4 would vanish below half an fp16 ulp
     if (sh16 && p >= 3 && p < pl.scale(0)) sh16[(size_t)(p - 3) * Pa + i] = __float2half_rn(x);
+}
+
+// streaming-copy probe (gs_debug_hbm_copy_rate): one float4 per lane and trip, grid-stride over a grid that fills the chip a few times
+__global__ __launch_bounds__(WG) void k_copy_probe(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * WG;
+    for (size_t k = (size_t)blockIdx.x * WG + threadIdx.x; k < n4; k += stride) dst[k] = src[k];
+}
+int launch_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t st) {
+    const size_t n4 = bytes / 16;
+    if (!n4) return GS_OK;
+    const unsigned grid = (unsigned)std::min<size_t>((n4 + WG - 1) / WG, 256 * 32);
+    hipLaunchKernelGGL(k_copy_probe, dim3(grid), dim3(WG), 0, st, (const float4*)src, (float4*)dst, n4);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
 }
 
 __global__ __launch_bounds__(WG) void k_sh_to_half(int P, int Pa, const float* __restrict__ planes, __half* __restrict__ sh16) {
@@ -71,18 +60,23 @@ int launch_sh_to_half(int M, int P, int Pa, const float* planes, uint16_t* sh16,
     return GS_OK;
 }
 
-int launch_update(const Planes& pl, int P, int Pa, float* params, float* grads, float* adam_m, float* adam_v, int adam_t,
-                  const gs_hyper& h, hipStream_t st, size_t lo, size_t hi, uint16_t* sh16) {
-    if (P == 0) return GS_OK;
-    hi = std::min(hi, (size_t)pl.count() * Pa);
-    if (lo >= hi) return GS_OK;
-    const int first_plane = (int)(lo / Pa), last_plane = (int)((hi - 1) / Pa);
+UpdateArgs make_update_args(const Planes& pl, const gs_hyper& h, int adam_t) {
     UpdateArgs u;
     u.lr_loc = h.lr_location; u.lr_sh = h.lr_sh; u.lr_scale = h.lr_scale; u.lr_opac = h.lr_opacity; u.lr_rot = h.lr_rotation;
     u.scale_max = h.scale_max; u.rule = h.update_rule; u.b1 = h.adam_beta1; u.b2 = h.adam_beta2; u.eps = h.adam_eps;
     u.bc1 = 1.0f - powf(h.adam_beta1, (float)adam_t);
     u.bc2 = 1.0f - powf(h.adam_beta2, (float)adam_t);
     u.M = pl.M;
+    return u;
+}
+
+int launch_update(const Planes& pl, int P, int Pa, float* params, float* grads, float* adam_m, float* adam_v, int adam_t,
+                  const gs_hyper& h, hipStream_t st, size_t lo, size_t hi, uint16_t* sh16) {
+    if (P == 0) return GS_OK;
+    hi = std::min(hi, (size_t)pl.count() * Pa);
+    if (lo >= hi) return GS_OK;
+    const int first_plane = (int)(lo / Pa), last_plane = (int)((hi - 1) / Pa);
+    const UpdateArgs u = make_update_args(pl, h, adam_t);
     hipLaunchKernelGGL(k_update, dim3((P + WG - 1) / WG, last_plane - first_plane + 1), dim3(WG), 0, st, u, P, Pa, params,
                        (const float*)grads, adam_m, adam_v, lo, hi, first_plane, reinterpret_cast<__half*>(sh16));
     GS_HIP(hipGetLastError());

@@ -89,6 +89,11 @@ int gs_debug_wave_reduce9(const float* in_host, float* out_host);
  * the block test, [6] / [7] backward iterations if hits were packed by 8x4 half / 4x4 quadrant.  active / (64 * hits) is the
  * useful-lane fraction of a hit.  reset != 0 zeroes them. */
 int gs_debug_counters(unsigned long long out[8], int reset);
+/* Diagnostic: what this device's HBM sustains for a plain streaming copy — the achievable ceiling SURVEY 8(d) asks to be stated
+ * next to the 8 TB/s specification.  Copies `bytes` (a multiple of 16; two buffers of that size are allocated and freed) with a
+ * float4-per-lane kernel `repeats` times after one warm-up launch and returns the FASTEST launch's (read + written bytes) / time in
+ * GB/s, from HIP events on a stream of its own.  bench.py reports it as roofline.peak_measured. */
+int gs_debug_hbm_copy_rate(size_t bytes, int repeats, double* gbytes_per_s);
 
 /* ------------------------------------------------------------------------------------------
  * Raw device-memory helpers (current HIP device).  They exist so that C / ctypes callers and the

@@ -192,6 +192,52 @@ def test_step_adam_matches_oracle(orc):
     tr.close()
 
 
+@pytest.mark.parametrize("rule,sh_fp16,arena", [(capi.GS_UPDATE_ADAM, 0, 0), (capi.GS_UPDATE_SGD_CLAMP, 0, 0), (capi.GS_UPDATE_ADAM, 1, 0), (capi.GS_UPDATE_ADAM, 0, 1100)])
+def test_fused_update_equals_the_update_launch(orc, rule, sh_fp16, arena):
+    """gs_trainer_step without a collective applies the update inside the per-splat reduction (k_splat_bwd_reduce<D, true>; trainer option
+    "fuse_update", default on): same gradient buffer, same parameters, same Adam moments and step count as the form with the update launch
+    — bit for bit, through plain steps, a densify step, the fp16-SH read copy, and an attempt whose arena overflows (the overflowed
+    attempt must apply nothing: the replay applies the update once)."""
+    P, M, n_cams, W, H = 1200, 9, 3, 128, 96
+    res = []
+    for fuse in (1, 0):
+        capi.check(capi.lib().gs_set_option(b"arena_entries", arena))
+        try:
+            s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 4321)
+        finally:
+            capi.check(capi.lib().gs_set_option(b"arena_entries", 0))
+        if sh_fp16:
+            tr.set_option("sh_fp16", 1)
+            host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"].astype(np.float16).astype(np.float32), s["scale"], s["opac"], s["rot"])
+            host.shDegree = s["D"]
+            tr.model = gs.ModelSplatsDevice(host)
+        tr.set_option("fuse_update", fuse)
+        proj = gs.Project(updateRule=rule, lrLocation=1e-3, lrSh=2e-3, lrScale=5e-4, lrOpacity=1e-3, lrRotation=1e-3,
+                          paramDensifyVariance=0.05, paramCullOpacity=0.15, paramSplitSize=0.06)
+        trail = []
+        for k in range(5):
+            st = tr.train(proj, densify=(k == 2), stats=True)
+            n = st.count_after
+            trail.append((st.num_rendered, st.loss, st.arena_regrows, n, _read_grads(tr, n, M), _download(tr)))
+        m1, m2, steps = tr.adam_state()
+        res.append((trail, m1, m2, steps))
+        tr.close()
+    (ta, m1a, m2a, sa), (tb, m1b, m2b, sb) = res
+    assert sa == sb == (5 if rule == capi.GS_UPDATE_ADAM else 0)
+    if arena:
+        assert ta[0][2] >= 1 and tb[0][2] >= 1      # the first step of both runs overflowed and was replayed
+    for a, b in zip(ta, tb):
+        assert a[:4] == b[:4]
+        for k in a[4]:
+            assert np.array_equal(a[4][k].view(np.uint32), b[4][k].view(np.uint32)), k
+        for k in ("loc", "sh", "scale", "opac", "rot"):
+            assert np.array_equal(a[5][k].view(np.uint32), b[5][k].view(np.uint32)), k
+    assert ta[2][3] != P                             # the densify step changed the count
+    if rule == capi.GS_UPDATE_ADAM:
+        assert np.array_equal(m1a.view(np.uint32), m1b.view(np.uint32)) and np.array_equal(m2a.view(np.uint32), m2b.view(np.uint32))
+        assert np.abs(m1a).max() > 0
+
+
 def test_training_reduces_loss(orc):
     P, M, n_cams, W, H = 2000, 4, 2, 128, 128
     s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 5)

@@ -120,6 +120,10 @@ def test_source_stamp_ignores_comments_only(tmp_path):
     text = f.read_text()
     f.write_text("// a new comment\n" + text.replace("\n", "\n   ", 3) + "\n/* trailing\n block */\n")
     assert source_stamp(str(root)) == base
+    f.write_text(text)
+    f = root / "gaussian-splatterer_amd" / "csrc" / "gs_internal.h"     # the update rule both update kernels share
+    text = f.read_text()
+    assert "1.0f - u.b1" in text
     f.write_text(text.replace("1.0f - u.b1", "1.0f - u.b2", 1))
     assert source_stamp(str(root)) != base
 
