@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--sh-fp16", action="store_true", help="trainer option sh_fp16: the projection reads a half-precision copy of the SH planes (BASELINE config 5)")
     ap.add_argument("--long-steps", type=int, default=2000, help="steps of the untimed-by-the-metric long run reported as `long_run` (0: skip); the default keeps "
                     "the GPU busy for ~2.5 s at cfg3, long enough for an external utilisation sampler to see the run")
+    ap.add_argument("--fuse-update", type=int, default=1, help="diagnostic: 0 runs the update as a launch of its own (trainer option fuse_update) instead of inside the per-splat reduction")
     ap.add_argument("--views", type=int, default=0, help="diagnostic only: override the number of views per step (not the metric's config)")
     ap.add_argument("--exchange-overlap", type=int, default=0,
                     help="*-compact only: 1 runs the all-reduce of the twelve non-SH planes on the trainer's second stream and a communicator of its own, "
@@ -185,6 +186,8 @@ def main():
     tr.model = gs.ModelSplatsDevice(host)
     if args.sh_fp16:
         tr.set_option("sh_fp16", 1)
+    if not args.fuse_update:
+        tr.set_option("fuse_update", 0)
     tr.captureTruths(cams, framesW, framesB)
     tr.shard(rank, world)
     proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM if args.update == "adam" else capi.GS_UPDATE_SGD_CLAMP)

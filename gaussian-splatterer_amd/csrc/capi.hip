@@ -150,7 +150,7 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
 }
 
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, rowmark, hmask, color, finalT, ncontrib, scan_tmp, sgrads, shjac;
+    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, rowmark, hmask, color, finalT, ncontrib, scan_tmp, sgrads, shjac, meancopy;
     uint64_t rowmark_cleared = ~0ull;  // the generation of `rowmark` that has been zeroed (a new allocation holds stale bytes: the caller clears it and restarts the epochs)
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
@@ -197,9 +197,10 @@ struct ScratchSet {
         // [block_sums: v x splat_blocks(Pa)] [partials of the three-phase scan, used only past g_scan_single_max items]
         GS_TRY(scan_tmp.ensure((v * splat_blocks(Pa) + scan_partials_count(std::max(T, NST), (int)v) + 64) * 4));
         s.block_sums = scan_tmp.as<uint32_t>();
-        if (want_splat_grads) { GS_TRY(sgrads.ensure(v * Pa * 64)); GS_TRY(shjac.ensure(v * Pa * 48)); }
+        if (want_splat_grads) { GS_TRY(sgrads.ensure(v * Pa * 64)); GS_TRY(shjac.ensure(v * Pa * 48)); GS_TRY(meancopy.ensure((size_t)3 * Pa * 4)); }
         s.splat_grads = sgrads.as<float>();
         s.sh_jac = want_splat_grads ? shjac.as<float>() : nullptr;
+        s.mean_copy = want_splat_grads ? meancopy.as<float>() : nullptr;
         set_view_block_pointers(s, views.as<char>(), (int)v);
         s.geom = geom.as<GeomRec>();
         s.tiles_touched = tiles.as<uint32_t>();
@@ -233,7 +234,7 @@ struct ScratchSet {
     }
     void release() {
         for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &wghist, &colscan, &coarse_count, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &rowmark, &hmask, &color,
-                           &finalT, &ncontrib, &scan_tmp, &sgrads, &shjac })
+                           &finalT, &ncontrib, &scan_tmp, &sgrads, &shjac, &meancopy })
             b->release();
     }
 };

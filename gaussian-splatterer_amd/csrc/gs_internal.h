@@ -136,6 +136,8 @@ struct Scratch {
     const float* zero_row;     // sixteen zero floats in front of row_epoch's allocation: what k_splat_bwd_view reads in place of an absent row
     float* splat_grads;        // [V][Pa][16]  per-(view,splat) backward records (trainer only)
     float* sh_jac;             // [G][Pa][12]  d colour / d view direction (9 used), written by the projection (trainer only, else null)
+    float* mean_copy;          // [3][Pa]  the positions this step's projection read (trainer only, else null): the fused update's SH parts form their
+                               //          view directions from it while the geometry part of the same splat may already have moved the position plane
     const uint16_t* sh16;      // [3M][Pa] IEEE half read copy of the SH planes (trainer option "sh_fp16"), or null: read the fp32 planes
     float* out_color;          // [V][3][N]
     float* final_T;            // [V][N]
@@ -219,12 +221,11 @@ __device__ inline void update_plane_rule(const UpdateArgs& u, const Planes& pl, 
     else if (p == pl.opac()) { lr = u.lr_opac; kind = 2; }
     else { lr = u.lr_rot; kind = 0; }
 }
-__device__ inline float update_element(const UpdateArgs& u, float lr, int kind, float x, float g, float* am, float* av, size_t idx) {
+// the rule on values: returns the new parameter, moves the moments (Adam only)
+__device__ inline float update_value(const UpdateArgs& u, float lr, int kind, float x, float g, float& m, float& v) {
     if (u.rule == GS_UPDATE_ADAM) {
-        float m = am[idx], v = av[idx];
         m = u.b1 * m + (1.0f - u.b1) * g;
         v = u.b2 * v + (1.0f - u.b2) * g * g;
-        am[idx] = m; av[idx] = v;
         const float mh = m / u.bc1, vh = v / u.bc2;
         x = x + lr * (mh / (sqrtf(vh) + u.eps));
     } else {
@@ -232,6 +233,13 @@ __device__ inline float update_element(const UpdateArgs& u, float lr, int kind, 
     }
     if (kind == 1) x = fminf(u.scale_max, fmaxf(0.0f, x));
     else if (kind == 2) x = fminf(1.0f, fmaxf(0.0f, x));
+    return x;
+}
+__device__ inline float update_element(const UpdateArgs& u, float lr, int kind, float x, float g, float* am, float* av, size_t idx) {
+    float m = 0.0f, v = 0.0f;
+    if (u.rule == GS_UPDATE_ADAM) { m = am[idx]; v = av[idx]; }
+    x = update_value(u, lr, kind, x, g, m, v);
+    if (u.rule == GS_UPDATE_ADAM) { am[idx] = m; av[idx] = v; }
     return x;
 }
 #endif

@@ -230,6 +230,10 @@ __global__ __launch_bounds__(WG) void k_preprocess(Dims d, const float* __restri
     for (int k = threadIdx.x; k < (v1 - v0) * d.NST; k += WG) hist[k] = 0;
     SplatIn<D> in;
     if (i < d.P) load_splat<D, H>(d, params, s, i, in);
+    if (s.mean_copy && blockIdx.y == 0 && i < d.P) {     // k_splat_bwd_reduce<D, true> (the fused update) reads the position from here
+#pragma unroll
+        for (int c = 0; c < 3; c++) s.mean_copy[(size_t)c * d.Pa + i] = in.loc[c];
+    }
     __syncthreads();
     for (int v = v0; v < v1; v++) {
         uint32_t* h = hist + (size_t)(v - v0) * d.NST;

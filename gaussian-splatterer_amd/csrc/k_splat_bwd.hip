@@ -293,11 +293,12 @@ template <int D> struct GradAcc {
 #pragma unroll
         for (int k = 0; k < NC; k++) aSh[k][0] = aSh[k][1] = aSh[k][2] = 0.0f;
     }
-    // one record: mean(3) scale(3) rot(4) opacity(1) dL_dRGB(3); (mx, my, mz) the splat, cp the pass's camera position
+    // one record: mean(3) scale(3) rot(4) opacity(1) pad | dL_dRGB(3) pad — the colour gradient fills a 16-byte quarter of its own, so the
+    // reduction's SH parts fetch that quarter alone; (mx, my, mz) the splat, cp the pass's camera position
     __device__ void add(const float4& r0, const float4& r1, const float4& r2, const float4& r3, float samples, float mx, float my, float mz,
                         const float* cp) {
         add_geometry(r0, r1, r2, samples);
-        const float dRGB[3] = { r2.w, r3.x, r3.y };
+        const float dRGB[3] = { r3.x, r3.y, r3.z };
         add_sh(dRGB, samples, mx, my, mz, cp);
     }
     // everything of accumulateGradients but the SH planes (the compact data-parallel exchange sums these per rank and all-reduces them)
@@ -354,7 +355,7 @@ template <int D> struct GradAcc {
 
 // Trainer stage 1: one thread per (pass, splat) — fully parallel.  Sums the splat's gradient rows of that pass and
 // runs the per-splat chain; the result is ONE 64-byte record per (pass, splat):
-//   mean(3) scale(3) rot(4) opacity(1) dL_dRGB(3, clamp-masked) pad(2).   Culled splats write zeros.
+//   mean(3) scale(3) rot(4) opacity(1) pad(1) | dL_dRGB(3, clamp-masked) pad(1).   Culled splats write zeros.
 // (Fusing the two passes of a camera into one thread was measured slower: 175 VGPRs, 2 waves/SIMD.)
 // Work items are the backward's {group, pass a, pass b}.  With fused pairs (render_bwd<2>) there is one
 // gradient set per item, in pass a's slice: blockIdx.y then enumerates items and the record is pass a's.
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(WG) GS_SBV_ATTR void k_splat_bwd_view(Dims d, const
     auto jac_at = [&](int ch, float, float, float, float& dx_, float& dy_, float& dz_) { dx_ = jv[3 * ch]; dy_ = jv[3 * ch + 1]; dz_ = jv[3 * ch + 2]; };
     splat_backward_core<D, false>(s.gviews[g], d.W, d.H, mean, sc, q, jac_at, __float_as_uint(j2.y), sum, sum[3], sum[4], sum[5], sum[6], sum[7], o, dRGB);
     const float4 r0 = make_float4(o.mean[0], o.mean[1], o.mean[2], o.scale[0]), r1 = make_float4(o.scale[1], o.scale[2], o.rot[0], o.rot[1]),
-                 r2 = make_float4(o.rot[2], o.rot[3], sum[8], dRGB[0]), r3 = make_float4(dRGB[1], dRGB[2], 0.0f, 0.0f);
+                 r2 = make_float4(o.rot[2], o.rot[3], sum[8], 0.0f), r3 = make_float4(dRGB[0], dRGB[1], dRGB[2], 0.0f);
     if constexpr (SINGLE) {
         GradAcc<D> acc;
         if (x.geo) {
@@ -452,10 +453,96 @@ __global__ __launch_bounds__(WG) GS_SBV_ATTR void k_splat_bwd_view(Dims d, const
 // basis(view direction) x dL_dRGB.  Every gradient plane is written exactly once per step.
 // n_fused_items > 0: the records are one per work item (the pair's summed gradient, at the item's first pass) and
 // `var`, which needs every pass's own location gradient, is written as zero (see render_bwd in k_render.hip).
-// UPD (a step with no collective between the reduction and the update): the thread applies the splat's update itself, plane by plane,
-// with update_element — k_update's operations on the value k_update would have read back from the gradient plane.  Every parameter
-// plane is updated, the SH planes beyond the model's degree with their zero gradient (Adam moves on a zero gradient too).  All
-// parameter reads of this kernel go through fu.params (it writes them).
+// The reduction is split into PARTS so that a step's 100 000 splats are more than 1.5 waves per SIMD: blockIdx.y = 0 owns the
+// twelve planes that are not SH (it reads 48 bytes of every record), blockIdx.y = 1 .. owns a range of SH coefficients each (the
+// record's dL_dRGB quarter, 16 bytes, + the view direction).  Every plane's sum runs over the records in the reference's order
+// exactly as one thread per splat ran it: the same bits.  (One thread per splat: 35 us at cfg3 for 75 MB — latency, not bytes.)
+// UPD (a step with no collective between the reduction and the update): the thread applies the update of ITS planes itself, with
+// update_value — k_update's operations on the value k_update would have read back from the gradient plane — parameters and moments
+// loaded a batch of planes at a time through restrict-qualified pointers (the compiler must not order every load behind the previous
+// plane's stores).  The SH planes beyond the model's degree get their zero gradient (Adam moves on a zero gradient too).
+// All parameter reads of the UPD kernel go through fu.params (it writes them).
+template <int N>
+__device__ inline void update_planes(const FusedUpdate& fu, const Planes& pl, const int (&plane)[N], const float (&g)[N], size_t st, int i) {
+    float* __restrict__ P = fu.params;
+    float* __restrict__ Am = fu.am;
+    float* __restrict__ Av = fu.av;
+    __half* __restrict__ H = reinterpret_cast<__half*>(fu.sh16);
+    const bool adam = fu.u.rule == GS_UPDATE_ADAM;
+    float x[N], m[N], v[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const size_t idx = (size_t)plane[k] * st + i;
+        x[k] = P[idx];
+        m[k] = adam ? Am[idx] : 0.0f;
+        v[k] = adam ? Av[idx] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        float lr; int kind;
+        update_plane_rule(fu.u, pl, plane[k], lr, kind);
+        x[k] = update_value(fu.u, lr, kind, x[k], g[k], m[k], v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const size_t idx = (size_t)plane[k] * st + i;
+        P[idx] = x[k];
+        if (adam) { Am[idx] = m[k]; Av[idx] = v[k]; }
+        if (H && plane[k] >= 3 && plane[k] < pl.scale(0)) H[(size_t)(plane[k] - 3) * st + i] = __float2half_rn(x[k]);
+    }
+}
+
+// SH coefficients [K0, K1) of splat i: avg_sh[k][c] += (basis[k] * dL_dRGB[c]) / S over the records, GradAcc::add_sh's operations
+template <int D, int K0, int K1, bool UPD>
+__device__ inline void reduce_sh_part(const Dims& d, const Scratch& s, float samples, const float4* __restrict__ rec_in, float* __restrict__ grad,
+                                      const int* __restrict__ items, int n_fused_items, const FusedUpdate& fu, bool apply, bool last_part,
+                                      float mx, float my, float mz, int i) {
+    constexpr int NC = (D + 1) * (D + 1), NK = K1 - K0;
+    const Planes pl{ d.M };
+    const size_t st = (size_t)d.Pa;
+    float a[NK][3];
+#pragma unroll
+    for (int k = 0; k < NK; k++) a[k][0] = a[k][1] = a[k][2] = 0.0f;
+    const int n_rec = n_fused_items > 0 ? n_fused_items : d.V;
+    for (int r = 0; r < n_rec; r++) {
+        const int v = n_fused_items > 0 ? items[3 * r + 1] : r;
+        const float4 q = rec_in[((size_t)v * st + i) * 4 + 3];
+        if (q.x != 0.0f || q.y != 0.0f || q.z != 0.0f) {       // (as GradAcc::add_sh: a culled record adds +0, and its basis may be NaN)
+            const float* cp = s.views[v].campos;
+            const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
+            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+            float basis[NC];
+            sh_basis<D>(ox / len, oy / len, oz / len, basis);
+            const float dRGB[3] = { q.x, q.y, q.z };
+#pragma unroll
+            for (int k = 0; k < NK; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) a[k][c] += (basis[K0 + k] * dRGB[c]) / samples;
+        }
+    }
+    int plane[3 * NK];
+    float g[3 * NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { plane[3 * k + c] = pl.sh(K0 + k, c); g[3 * k + c] = a[k][c]; grad[pl.sh(K0 + k, c) * st + i] = a[k][c]; }
+    if (last_part)
+        for (int k = NC; k < d.M; k++)
+            for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = 0.0f;
+    if constexpr (UPD) {
+        if (!apply) return;
+        update_planes<3 * NK>(fu, pl, plane, g, st, i);
+        if (last_part)
+            for (int k = NC; k < d.M; k++) {
+                const int pz[3] = { pl.sh(k, 0), pl.sh(k, 1), pl.sh(k, 2) };
+                const float gz[3] = { 0.0f, 0.0f, 0.0f };
+                update_planes<3>(fu, pl, pz, gz, st, i);
+            }
+    }
+}
+
+template <int D> constexpr int reduce_parts() { return D == 3 ? 4 : (D == 2 ? 3 : 2); }    // geometry + 1 / 2 / 3 SH coefficient ranges
+
 template <int D, bool UPD>
 __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __restrict__ params_ro, Scratch s, float samples,
                                                          const float4* __restrict__ rec_in, float* __restrict__ grad,
@@ -464,43 +551,50 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __
     if (i >= d.P) return;
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
-    const float* params = UPD ? (const float*)fu.params : params_ro;
-    const float mx = params[pl.loc(0) * st + i], my = params[pl.loc(1) * st + i], mz = params[pl.loc(2) * st + i];
-    GradAcc<D> acc;
-    const int n_rec = n_fused_items > 0 ? n_fused_items : d.V;
-    for (int k = 0; k < n_rec; k++) {
-        const int v = n_fused_items > 0 ? items[3 * k + 1] : k;
-        const float4* r = rec_in + ((size_t)v * st + i) * 4;
-        acc.add(r[0], r[1], r[2], r[3], samples, mx, my, mz, s.views[v].campos);
-    }
-    acc.store(grad, pl, st, i, d.M, n_fused_items > 0);
+    const int part = blockIdx.y;
+    bool apply = false;
     if constexpr (UPD) {
         // an attempt whose binning arena overflowed is replayed by the host with a larger one: it must not move the model
         uint32_t overflow = 0;
         for (int g = 0; g < d.VG; g++) overflow |= s.flags[g * 4 + 0] & 1u;
-        if (overflow) return;
-        constexpr int NC = GradAcc<D>::NC;
-        auto upd = [&](int p, float g) {
-            float lr; int kind;
-            update_plane_rule(fu.u, pl, p, lr, kind);
-            const size_t idx = (size_t)p * st + i;
-            const float x = update_element(fu.u, lr, kind, fu.params[idx], g, fu.am, fu.av, idx);
-            fu.params[idx] = x;
-            if (fu.sh16 && p >= 3 && p < pl.scale(0)) reinterpret_cast<__half*>(fu.sh16)[(size_t)(p - 3) * st + i] = __float2half_rn(x);
-        };
+        apply = overflow == 0;
+    }
+    if (part == 0) {
+        GradAcc<0> acc;      // (its one SH coefficient stays unused here)
+        const int n_rec = n_fused_items > 0 ? n_fused_items : d.V;
+        for (int k = 0; k < n_rec; k++) {
+            const int v = n_fused_items > 0 ? items[3 * k + 1] : k;
+            const float4* r = rec_in + ((size_t)v * st + i) * 4;
+            acc.add_geometry(r[0], r[1], r[2], samples);
+        }
+        const bool zero_var = n_fused_items > 0;
+        int plane[11];
+        float g[11];
 #pragma unroll
-        for (int c = 0; c < 3; c++) upd(pl.loc(c), acc.aLoc[c]);
+        for (int c = 0; c < 3; c++) { plane[c] = pl.loc(c); g[c] = acc.aLoc[c]; plane[3 + c] = pl.scale(c); g[3 + c] = acc.aScale[c]; }
+        plane[6] = pl.opac(); g[6] = acc.aOpac;
 #pragma unroll
-        for (int k = 0; k < NC; k++)
+        for (int c = 0; c < 4; c++) { plane[7 + c] = pl.rot(c); g[7 + c] = acc.aRot[c]; }
 #pragma unroll
-            for (int c = 0; c < 3; c++) upd(pl.sh(k, c), acc.aSh[k][c]);
-        for (int k = NC; k < d.M; k++)
-            for (int c = 0; c < 3; c++) upd(pl.sh(k, c), 0.0f);
-#pragma unroll
-        for (int c = 0; c < 3; c++) upd(pl.scale(c), acc.aScale[c]);
-        upd(pl.opac(), acc.aOpac);
-#pragma unroll
-        for (int c = 0; c < 4; c++) upd(pl.rot(c), acc.aRot[c]);
+        for (int k = 0; k < 11; k++) grad[(size_t)plane[k] * st + i] = g[k];
+        grad[pl.var() * st + i] = zero_var ? 0.0f : acc.var;
+        if constexpr (UPD) { if (apply) update_planes<11>(fu, pl, plane, g, st, i); }
+        return;
+    }
+    // The SH parts read the splat's position: in the fused form the geometry part of the SAME splat may have moved it already (another
+    // workgroup), so the position the gradients were formed at is taken from where nobody writes — the projection's record of it.
+    float mx, my, mz;
+    if constexpr (UPD) { mx = s.mean_copy[i]; my = s.mean_copy[st + i]; mz = s.mean_copy[2 * st + i]; }
+    else { mx = params_ro[pl.loc(0) * st + i]; my = params_ro[pl.loc(1) * st + i]; mz = params_ro[pl.loc(2) * st + i]; }
+    if constexpr (D == 0) reduce_sh_part<0, 0, 1, UPD>(d, s, samples, rec_in, grad, items, n_fused_items, fu, apply, true, mx, my, mz, i);
+    else if constexpr (D == 1) reduce_sh_part<1, 0, 4, UPD>(d, s, samples, rec_in, grad, items, n_fused_items, fu, apply, true, mx, my, mz, i);
+    else if constexpr (D == 2) {
+        if (part == 1) reduce_sh_part<2, 0, 5, UPD>(d, s, samples, rec_in, grad, items, n_fused_items, fu, apply, false, mx, my, mz, i);
+        else reduce_sh_part<2, 5, 9, UPD>(d, s, samples, rec_in, grad, items, n_fused_items, fu, apply, true, mx, my, mz, i);
+    } else {
+        if (part == 1) reduce_sh_part<3, 0, 6, UPD>(d, s, samples, rec_in, grad, items, n_fused_items, fu, apply, false, mx, my, mz, i);
+        else if (part == 2) reduce_sh_part<3, 6, 11, UPD>(d, s, samples, rec_in, grad, items, n_fused_items, fu, apply, false, mx, my, mz, i);
+        else reduce_sh_part<3, 11, 16, UPD>(d, s, samples, rec_in, grad, items, n_fused_items, fu, apply, true, mx, my, mz, i);
     }
 }
 
@@ -527,7 +621,7 @@ __global__ __launch_bounds__(WG) void k_exchange_pack(Dims d, Scratch s, float s
         const int g = n_fused_items > 0 ? items[3 * k] : s.view_group[v];
         const int slot = (n_fused_items > 0 || s.group_views[s.group_first[g]] == v) ? g : x.slots / 2 + g;
         float* rgb = exchange_rgb(x, x.rank, slot, st);
-        rgb[i] = r2.w; rgb[st + i] = r3.x; rgb[2 * st + i] = r3.y;
+        rgb[i] = r3.x; rgb[st + i] = r3.y; rgb[2 * st + i] = r3.z;
     }
     // a rank with fewer cameras than the others (cameras % ranks != 0) sends zeros in the slots it has no record for
     const int per_half = n_fused_items > 0 ? x.slots : x.slots / 2;
@@ -598,11 +692,11 @@ static void launch_splat_avg_d(const Dims& d, const float* params, const Scratch
     }
     if (ny > 0) hipLaunchKernelGGL((k_splat_bwd_view<D, false>), dim3(bx, ny), dim3(WG), 0, stream, d, params, s, rec, items, n2, fuse ? 1 : 0, samples, grad, none);
     if (x) hipLaunchKernelGGL(k_exchange_pack, dim3(bx), dim3(WG), 0, stream, d, s, samples, (const float4*)rec, *x, items, fuse ? n2 : 0);
-    else if (fu && fu->params) {
-        hipLaunchKernelGGL((k_splat_bwd_reduce<D, true>), dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
+    else if (fu && fu->params && s.mean_copy) {
+        hipLaunchKernelGGL((k_splat_bwd_reduce<D, true>), dim3(bx, reduce_parts<D>()), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
                            fuse ? n2 + n1 : 0, *fu);
         if (update_applied) *update_applied = true;
-    } else hipLaunchKernelGGL((k_splat_bwd_reduce<D, false>), dim3(bx), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
+    } else hipLaunchKernelGGL((k_splat_bwd_reduce<D, false>), dim3(bx, reduce_parts<D>()), dim3(WG), 0, stream, d, params, s, samples, (const float4*)rec, grad, items,
                               fuse ? n2 + n1 : 0, FusedUpdate{});
 }
 

@@ -1,6 +1,7 @@
 // gsplat_extras.hpp — header-only C++ for the rows either side of the training path, on top
 // of gsplat_shim.hpp's ModelSplatsHost:
 //   * the text `.gobj` splat format of the reference's save / load menu entries (src/ui/UiFrame.cpp:333-358, :373-450)
+//   * `settings.json`, the Project's serialised members (src/Project.h:64-73, src/ui/UiFrame.cpp:323-331, :360-371)
 //   * the three start fields: grid, mono, one splat per OBJ triangle (src/ui/UiFrame.cpp:137-264)
 // No GUI, no progress dialogs.  Same file format, same constants, same error behaviour
 // (std::runtime_error("Inconsistent SH degree!"), "Unexpected vertex count in face list!", the five-vector
@@ -15,6 +16,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -137,6 +139,280 @@ inline std::unique_ptr<ModelSplatsHost> loadSplats(const std::string& path) {
     std::ifstream file(path);
     if (!file) throw std::runtime_error("Failed to load splats file at \"" + path + "\"!");
     return readSplats(file);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// settings.json — UiFrame::saveSettings / loadSettings (src/ui/UiFrame.cpp:323-331, :360-371): the Project through
+// nlohmann's NLOHMANN_DEFINE_TYPE_INTRUSIVE_WITH_DEFAULT (src/Project.h:22,64-73).  What that macro pair fixes and this
+// section reproduces without the library: keys = member names; `file << j` writes ONE compact line whose keys are sorted
+// (nlohmann::json's object is a std::map); floats are stored as double(float) and written with the shortest digits that
+// read back to that double; from_json WITH_DEFAULT gives a key missing from the file the value of a default-constructed
+// Project (not the loaded-into object's current one); unknown keys are ignored; a value of the wrong JSON type throws.
+// The table below is the serialised member list in the reference's order; writer and reader are loops over it
+// (mirrored by gaussian-splatterer_amd/io.py, byte-identical output: tests/test_next_rows.py).
+// ---------------------------------------------------------------------------------------------------------
+struct JsonValue {
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    bool boolean = false;
+    double number = 0.0;
+    bool integral = false;      // the literal had no fraction / exponent
+    std::string text;
+    std::vector<JsonValue> items;
+    std::vector<std::pair<std::string, JsonValue>> members;
+    const JsonValue* find(const std::string& key) const {
+        const JsonValue* hit = nullptr;
+        for (const auto& m : members) if (m.first == key) hit = &m.second;     // a repeated key: the last one wins, as in nlohmann
+        return hit;
+    }
+};
+
+class JsonReader {
+public:
+    explicit JsonReader(const std::string& src) : s(src) {}
+    JsonValue parse() {
+        JsonValue v = value();
+        blanks();
+        if (i != s.size()) fail("trailing characters");
+        return v;
+    }
+private:
+    const std::string& s;
+    size_t i = 0;
+    [[noreturn]] void fail(const char* what) const { throw std::runtime_error(std::string("settings.json: ") + what + " at offset " + std::to_string(i)); }
+    void blanks() { while (i < s.size() && (s[i] == ' ' || s[i] == '\t' || s[i] == '\n' || s[i] == '\r')) i++; }
+    bool eat(const char* word) { const size_t n = std::strlen(word); if (s.compare(i, n, word) == 0) { i += n; return true; } return false; }
+    static void utf8(std::string& out, unsigned cp) {
+        if (cp < 0x80) out += (char)cp;
+        else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+        else if (cp < 0x10000) { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+        else { out += (char)(0xF0 | (cp >> 18)); out += (char)(0x80 | ((cp >> 12) & 0x3F)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+    }
+    unsigned hex4() {
+        if (i + 4 > s.size()) fail("short \\u escape");
+        unsigned v = 0;
+        for (int k = 0; k < 4; k++) {
+            const char c = s[i++];
+            v = v * 16 + (c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : (fail("bad \\u escape"), 0));
+        }
+        return v;
+    }
+    std::string string() {
+        std::string out;
+        i++;  // opening quote
+        while (true) {
+            if (i >= s.size()) fail("unterminated string");
+            const char c = s[i++];
+            if (c == '"') return out;
+            if (c != '\\') { out += c; continue; }
+            if (i >= s.size()) fail("unterminated escape");
+            const char e = s[i++];
+            switch (e) {
+                case '"': out += '"'; break; case '\\': out += '\\'; break; case '/': out += '/'; break;
+                case 'b': out += '\b'; break; case 'f': out += '\f'; break; case 'n': out += '\n'; break;
+                case 'r': out += '\r'; break; case 't': out += '\t'; break;
+                case 'u': {
+                    unsigned cp = hex4();
+                    if (cp >= 0xD800 && cp < 0xDC00 && s.compare(i, 2, "\\u") == 0) { i += 2; const unsigned lo = hex4(); cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); }
+                    utf8(out, cp);
+                    break;
+                }
+                default: fail("unknown escape");
+            }
+        }
+    }
+    JsonValue value() {
+        blanks();
+        if (i >= s.size()) fail("unexpected end");
+        JsonValue v;
+        const char c = s[i];
+        if (c == '{') {
+            v.kind = JsonValue::Object;
+            i++; blanks();
+            if (i < s.size() && s[i] == '}') { i++; return v; }
+            while (true) {
+                blanks();
+                if (i >= s.size() || s[i] != '"') fail("expected a key");
+                std::string key = string();
+                blanks();
+                if (i >= s.size() || s[i] != ':') fail("expected ':'");
+                i++;
+                v.members.emplace_back(std::move(key), value());
+                blanks();
+                if (i < s.size() && s[i] == ',') { i++; continue; }
+                if (i < s.size() && s[i] == '}') { i++; return v; }
+                fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            v.kind = JsonValue::Array;
+            i++; blanks();
+            if (i < s.size() && s[i] == ']') { i++; return v; }
+            while (true) {
+                v.items.push_back(value());
+                blanks();
+                if (i < s.size() && s[i] == ',') { i++; continue; }
+                if (i < s.size() && s[i] == ']') { i++; return v; }
+                fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') { v.kind = JsonValue::String; v.text = string(); return v; }
+        if (eat("true")) { v.kind = JsonValue::Bool; v.boolean = true; return v; }
+        if (eat("false")) { v.kind = JsonValue::Bool; return v; }
+        if (eat("null")) return v;
+        const size_t start = i;
+        while (i < s.size() && std::strchr("+-0123456789.eE", s[i])) i++;
+        if (i == start) fail("unexpected character");
+        const std::string lit = s.substr(start, i - start);
+        char* end = nullptr;
+        v.kind = JsonValue::Number;
+        v.number = std::strtod(lit.c_str(), &end);
+        if (end != lit.c_str() + lit.size()) { i = start; fail("bad number"); }
+        v.integral = lit.find_first_of(".eE") == std::string::npos;
+        return v;
+    }
+};
+
+// A JSON number for a double: the shortest digits that read back to it (what nlohmann's writer and Python's repr produce),
+// laid out by Python's rule — fixed notation for 1e-4 <= |x| < 1e16 with ".0" on integral values, else d.ddde+XX — so that
+// io.py writes the same bytes.  Non-finite values become null, as nlohmann writes them.
+inline std::string jsonNumber(double x) {
+    if (!std::isfinite(x)) return "null";
+    if (x == 0.0) return std::signbit(x) ? "-0.0" : "0.0";
+    char buf[40];
+    int prec = 1;
+    for (; prec <= 17; prec++) {      // shortest precision that round-trips (%.{p}e has p + 1 significant digits)
+        std::snprintf(buf, sizeof buf, "%.*e", prec - 1, x);
+        if (std::strtod(buf, nullptr) == x) break;
+    }
+    std::string digits;
+    const char* p = buf;
+    const bool neg = *p == '-';
+    if (neg) p++;
+    for (; *p && *p != 'e'; p++) if (*p != '.') digits += *p;
+    const int exp10 = std::atoi(p + 1);
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    std::string out = neg ? "-" : "";
+    if (exp10 >= -4 && exp10 < 16) {
+        if (exp10 < 0) out += "0." + std::string((size_t)(-exp10 - 1), '0') + digits;
+        else if ((int)digits.size() <= exp10 + 1) out += digits + std::string((size_t)(exp10 + 1 - (int)digits.size()), '0') + ".0";
+        else out += digits.substr(0, (size_t)exp10 + 1) + "." + digits.substr((size_t)exp10 + 1);
+    } else {
+        out += digits.substr(0, 1);
+        if (digits.size() > 1) out += "." + digits.substr(1);
+        char e[8];
+        std::snprintf(e, sizeof e, "e%c%02d", exp10 < 0 ? '-' : '+', std::abs(exp10));
+        out += e;
+    }
+    return out;
+}
+inline std::string jsonString(const std::string& v) {
+    std::string out = "\"";
+    for (const unsigned char c : v) {
+        switch (c) {
+            case '"': out += "\\\""; break; case '\\': out += "\\\\"; break; case '\b': out += "\\b"; break; case '\f': out += "\\f"; break;
+            case '\n': out += "\\n"; break; case '\r': out += "\\r"; break; case '\t': out += "\\t"; break;
+            default:
+                if (c < 0x20) { char u[8]; std::snprintf(u, sizeof u, "\\u%04x", c); out += u; }
+                else out += (char)c;      // UTF-8 passes through, as nlohmann's dump() leaves it
+        }
+    }
+    return out + "\"";
+}
+
+// One serialised member: how it is written and how it is taken from a parsed value.
+struct SettingsField {
+    std::string key;
+    std::function<std::string(const Project&)> write;
+    std::function<void(Project&, const JsonValue&)> read;
+};
+namespace settings_detail {
+[[noreturn]] inline void wrongType(const std::string& key, const char* want) { throw std::runtime_error("settings.json: \"" + key + "\" must be " + want); }
+inline double numberOf(const std::string& key, const JsonValue& v) { if (v.kind != JsonValue::Number) wrongType(key, "a number"); return v.number; }
+inline SettingsField field(const char* key, float Project::*m) {
+    return { key, [m](const Project& p) { return jsonNumber((double)(p.*m)); }, [m, k = std::string(key)](Project& p, const JsonValue& v) { p.*m = (float)numberOf(k, v); } };
+}
+inline SettingsField field(const char* key, int Project::*m) {
+    return { key, [m](const Project& p) { return std::to_string(p.*m); }, [m, k = std::string(key)](Project& p, const JsonValue& v) { p.*m = (int)numberOf(k, v); } };
+}
+inline SettingsField field(const char* key, bool Project::*m) {
+    return { key, [m](const Project& p) { return std::string(p.*m ? "true" : "false"); },
+             [m, k = std::string(key)](Project& p, const JsonValue& v) { if (v.kind != JsonValue::Bool) wrongType(k, "true or false"); p.*m = v.boolean; } };
+}
+inline SettingsField field(const char* key, std::string Project::*m) {
+    return { key, [m](const Project& p) { return jsonString(p.*m); },
+             [m, k = std::string(key)](Project& p, const JsonValue& v) { if (v.kind != JsonValue::String) wrongType(k, "a string"); p.*m = v.text; } };
+}
+inline SettingsField field(const char* key, CameraSphere Project::*m) {     // NLOHMANN_DEFINE_TYPE_INTRUSIVE_WITH_DEFAULT(CameraSphere, ...), src/Project.h:22
+    return { key,
+             [m](const Project& p) {
+                 const CameraSphere& c = p.*m;     // keys sorted, like the outer object
+                 return "{\"count\":" + std::to_string(c.count) + ",\"distance\":" + jsonNumber((double)c.distance) + ",\"fovDeg\":" + jsonNumber((double)c.fovDeg) +
+                        ",\"rotX\":" + jsonNumber((double)c.rotX) + ",\"rotY\":" + jsonNumber((double)c.rotY) + "}";
+             },
+             [m, k = std::string(key)](Project& p, const JsonValue& v) {
+                 if (v.kind != JsonValue::Object) wrongType(k, "an object");
+                 CameraSphere c;      // members the file lacks: CameraSphere's defaults
+                 if (const JsonValue* x = v.find("count")) c.count = (int)numberOf(k + ".count", *x);
+                 if (const JsonValue* x = v.find("distance")) c.distance = (float)numberOf(k + ".distance", *x);
+                 if (const JsonValue* x = v.find("fovDeg")) c.fovDeg = (float)numberOf(k + ".fovDeg", *x);
+                 if (const JsonValue* x = v.find("rotX")) c.rotX = (float)numberOf(k + ".rotX", *x);
+                 if (const JsonValue* x = v.find("rotY")) c.rotY = (float)numberOf(k + ".rotY", *x);
+                 p.*m = c;
+             } };
+}
+}  // namespace settings_detail
+
+// src/Project.h:64-73, in the macro's order
+inline const std::vector<SettingsField>& settingsSchema() {
+    using settings_detail::field;
+    static const std::vector<SettingsField> schema = {
+        field("perspective", &Project::perspective), field("pathModel", &Project::pathModel), field("pathTextureDiffuse", &Project::pathTextureDiffuse),
+        field("sphere1", &Project::sphere1), field("sphere2", &Project::sphere2), field("rtSamples", &Project::rtSamples),
+        field("lrLocation", &Project::lrLocation), field("lrSh", &Project::lrSh), field("lrScale", &Project::lrScale), field("lrOpacity", &Project::lrOpacity),
+        field("lrRotation", &Project::lrRotation), field("paramScaleMax", &Project::paramScaleMax), field("paramCullOpacity", &Project::paramCullOpacity),
+        field("paramCullSize", &Project::paramCullSize), field("paramDensifyVariance", &Project::paramDensifyVariance), field("paramSplitSize", &Project::paramSplitSize),
+        field("paramSplitDistance", &Project::paramSplitDistance), field("paramSplitScale", &Project::paramSplitScale), field("paramCloneDistance", &Project::paramCloneDistance),
+        field("iterations", &Project::iterations), field("intervalCapture", &Project::intervalCapture), field("intervalDensify", &Project::intervalDensify),
+        field("previewTimer", &Project::previewTimer), field("previewRtSamples", &Project::previewRtSamples), field("previewSplatScale", &Project::previewSplatScale),
+        field("previewTruth", &Project::previewTruth), field("previewTruthIndex", &Project::previewTruthIndex), field("previewFreeOrbit", &Project::previewFreeOrbit),
+        field("previewFreeOrbitSpeed", &Project::previewFreeOrbitSpeed), field("previewFreeDistance", &Project::previewFreeDistance),
+        field("previewFreeFovDeg", &Project::previewFreeFovDeg), field("previewFreeRotX", &Project::previewFreeRotX), field("previewFreeRotY", &Project::previewFreeRotY),
+        field("renderResX", &Project::renderResX), field("renderResY", &Project::renderResY),
+    };
+    return schema;
+}
+
+// nlohmann::to_json(j, project); file << j   — one compact line, keys in std::map order
+inline void writeSettings(std::ostream& os, const Project& project) {
+    std::vector<const SettingsField*> sorted;
+    for (const SettingsField& f : settingsSchema()) sorted.push_back(&f);
+    std::sort(sorted.begin(), sorted.end(), [](const SettingsField* a, const SettingsField* b) { return a->key < b->key; });
+    os << '{';
+    for (size_t k = 0; k < sorted.size(); k++) os << (k ? "," : "") << jsonString(sorted[k]->key) << ':' << sorted[k]->write(project);
+    os << '}';
+}
+inline void saveSettings(const std::string& path, const Project& project) {
+    std::ofstream file(path);
+    if (!file) throw std::runtime_error("Failed to open settings file \"" + path + "\" for writing!");
+    writeSettings(file, project);
+}
+// file >> j; nlohmann::from_json(j, project)   — WITH_DEFAULT: every member the file lacks gets a fresh Project's value
+inline void readSettings(std::istream& is, Project& project) {
+    std::stringstream all;
+    all << is.rdbuf();
+    const std::string text = all.str();
+    const JsonValue root = JsonReader(text).parse();
+    if (root.kind != JsonValue::Object) throw std::runtime_error("settings.json: the top level must be an object");
+    Project loaded;
+    for (const SettingsField& f : settingsSchema())
+        if (const JsonValue* v = root.find(f.key)) f.read(loaded, *v);
+    project = loaded;
+}
+// The reference shows a dialog and returns when the file is missing (src/ui/UiFrame.cpp:361-365); without a GUI that is an exception.
+inline void loadSettings(const std::string& path, Project& project) {
+    std::ifstream file(path);
+    if (!file) throw std::runtime_error("Failed to load settings file at \"" + path + "\"!");
+    readSettings(file, project);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -271,8 +271,11 @@ struct CameraSphere {  // Project::CameraSphere, src/Project.h:14-22
     int count = 16;
     float distance = 10.0f, fovDeg = 60.0f, rotX = 0.0f, rotY = 0.0f;
 };
-struct Project {
+struct Project {   // src/Project.h:6-75: every serialised member, the reference's names and defaults (gsplat_extras.hpp reads / writes its settings.json)
+    std::string perspective;                      // (the GUI's window layout; carried through save / load untouched)
+    std::string pathModel, pathTextureDiffuse;
     CameraSphere sphere1, sphere2;  // (UiFrame::initProject empties the second one: count 0, fovDeg 30, src/ui/UiFrame.cpp:129-134)
+    int rtSamples = 100;
     float lrLocation = 0.00005f, lrSh = 0.0001f, lrScale = 0.00002f, lrOpacity = 0.0001f, lrRotation = 0.000025f;
     float paramScaleMax = 0.3f;
     float paramCullOpacity = 0.005f, paramCullSize = 0.004f, paramDensifyVariance = 2.0f;
@@ -282,11 +285,13 @@ struct Project {
     int intervalDensify = 200;
     // the preview camera's fields (src/Project.h:47-58), read by Camera::getPreviewCamera
     float previewTimer = 0.0f;
+    int previewRtSamples = 50;
     float previewSplatScale = 1.0f;
     bool previewTruth = false;
     int previewTruthIndex = 0;
     bool previewFreeOrbit = true;
     float previewFreeOrbitSpeed = 0.5f, previewFreeDistance = 10.0f, previewFreeFovDeg = 60.0f, previewFreeRotX = 25.0f, previewFreeRotY = 0.0f;
+    int renderResX = 2048, renderResY = 2048;
 };
 
 class Trainer {

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import gsplat_amd as gs
-from util import step_budget, unexplained, view_parts
+from util import step_budget, unexplained, unexplained_bytes, view_parts
 
 pytestmark = pytest.mark.gpu
 
@@ -252,7 +252,7 @@ def test_random_scene_sweep(orc, seed):
         tr.train(dproj, densify=False)      # the trainer keeps stepping on the re-indexed model
         tr.synchronize()
     # the preview render of the same splats (Trainer::render, src/Trainer.cu:103-250) at another size, with a splat scale and the
-    # reference's tan_fovx quirk: RGBA8 equal to the oracle's, a last-place step allowed where the float sits on a rounding boundary
+    # reference's tan_fovx quirk: RGBA8 equal to the oracle's
     import math
     tr.model = gs.ModelSplatsDevice(host)
     rw, rh, mod = int(rng.integers(1, 300)), int(rng.integers(1, 300)), float(rng.uniform(0.3, 2.5))
@@ -263,10 +263,10 @@ def test_random_scene_sweep(orc, seed):
     vp = view_parts(blk)
     rimg, _ = orc.Rasterizer(np.float32).forward(s["D"], M, vp["bg"], rw, rh, s["loc"], s["sh"], s["opac"], s["scale"], mod, s["rot"], vp["view"], vp["proj"],
                                                  vp["campos"], vp["tanx"], vp["tany"])
-    wantb = orc.image_float_to_int(rimg, rw, rh).reshape(rh, rw)
-    shifts = np.arange(0, 32, 8)[:, None, None]
-    diff = np.abs(((fbuf >> shifts) & 0xFF).astype(int) - ((wantb >> shifts) & 0xFF).astype(int))
-    assert diff.max() <= 1 and (diff > 0).sum() <= max(2, 1e-2 * diff.size), (seed, "render", rw, rh, mod, int(diff.max()), float((diff > 0).mean()))
+    # every byte equal to imageFloatToInt(oracle float), or one step off where that float sits within the pixel tolerance of the k / 256
+    # boundary between the two values (util.unexplained_bytes) — zero unexplained bytes (round 4 allowed 1 % of them a step, unexamined)
+    n_off, n_unexplained = unexplained_bytes(fbuf, rimg, rw, rh)
+    assert n_unexplained == 0, (seed, "render", rw, rh, mod, n_off, n_unexplained)
     print(f"[sweep {base + seed}: {kind}, {P} splats, M={M}, {2 * n_cams} passes @{W}x{H}] {st.num_rendered} list entries, longest tile list "
-          f"{st.max_tile_list}: zero unexplained entries in both forms, worst error/budget {worst_all:.2f}; three Adam iterations and densify {P} -> {n2} splats bit-exact; render {rw}x{rh} x{mod:.2f}: {int((diff > 0).sum())} bytes one step off; chain noise allowance up to {noise_share:.2g} x the sums' budget (dL_dscale)")
+          f"{st.max_tile_list}: zero unexplained entries in both forms, worst error/budget {worst_all:.2f}; three Adam iterations and densify {P} -> {n2} splats bit-exact; render {rw}x{rh} x{mod:.2f}: {n_off} bytes one step off, each on a k/256 boundary; chain noise allowance up to {noise_share:.2g} x the sums' budget (dL_dscale)")
     tr.close()

@@ -8,7 +8,7 @@ import pytest
 
 import gsplat_amd as gs
 from gsplat_amd import capi
-from util import assert_close_rel, step_budget, unexplained, view_parts
+from util import assert_close_rel, step_budget, unexplained, unexplained_bytes, view_parts
 
 pytestmark = pytest.mark.gpu
 
@@ -442,9 +442,9 @@ def test_preview_render_matches_oracle(orc):
     r = orc.Rasterizer(np.float32)
     out, _ = r.forward(1, M, vp["bg"], W, H, s["loc"], s["sh"], s["opac"], s["scale"], 1.3, s["rot"], vp["view"], vp["proj"],
                        vp["campos"], vp["tanx"], vp["tany"])
-    want = orc.image_float_to_int(out, W, H).reshape(H, W)
-    diff = np.abs(((fb >> np.arange(0, 32, 8)[:, None, None]) & 0xFF).astype(int) - ((want >> np.arange(0, 32, 8)[:, None, None]) & 0xFF).astype(int))
-    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3  # quantisation of values 1e-7 apart
+    # every byte equals imageFloatToInt(oracle float), or is one step off with that float within the pixel tolerance of the k / 256 boundary
+    n_off, n_unexplained = unexplained_bytes(fb, out, W, H)
+    assert n_unexplained == 0 and n_off <= 1e-3 * fb.size * 3, (n_off, n_unexplained)
     tr.close()
 
 

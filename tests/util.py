@@ -325,3 +325,28 @@ def envelope_verdict(got, want, runs, sumabs, flip, budget, stride=1, widen=ENVE
                  ref_inside=float(np.mean(loo_in)), ref_within4=float(np.mean(loo_4)),
                  by_ulps=int((cls == 2).sum()), by_flip=int((cls == 3).sum()), unexplained=int((cls == 4).sum()))
     return cls, rates
+
+
+def unexplained_bytes(frame, want_img, w, h, rtol=1e-4, floor=1e-3):
+    """An RGBA8 frame (uint32[h * w], imageFloatToInt layout: R in the low byte, src/Trainer.cu:19-29) against the oracle's FLOAT image
+    [3][h][w] of the same render.  A byte may differ from imageFloatToInt(oracle float) only by ONE step and only where the oracle's
+    float v lies within the forward pixel tolerance — rtol * max(|v|, floor), the bar every float pixel is held to — of the boundary
+    k / 256 between the two byte values: (int)(v * 256) steps exactly there, so a float inside the tolerance may land on either side.
+    Returns (bytes that differ, bytes that differ WITHOUT such an explanation); the alpha byte must be 0xFF everywhere."""
+    frame = np.asarray(frame, np.uint32).reshape(-1)
+    v = np.asarray(want_img, np.float32).reshape(3, -1).astype(np.float64)
+    assert frame.size == w * h and v.shape[1] == w * h
+    assert np.all((frame >> 24) == 0xFF)
+    n_diff = n_bad = 0
+    for c in range(3):
+        got = ((frame >> (8 * c)) & 0xFF).astype(np.int64)
+        want = np.clip((v[c].astype(np.float32) * np.float32(256.0)).astype(np.int64), 0, 255)     # (int) truncates towards zero, as the kernel's cast
+        d = got != want
+        if not d.any():
+            continue
+        n_diff += int(d.sum())
+        boundary = np.maximum(got, want)[d] / 256.0
+        tol = rtol * np.maximum(np.abs(v[c][d]), floor)
+        ok = (np.abs(got - want)[d] == 1) & (np.abs(v[c][d] - boundary) <= tol)
+        n_bad += int((~ok).sum())
+    return n_diff, n_bad
