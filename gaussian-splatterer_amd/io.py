@@ -89,33 +89,73 @@ _SERIALISED = ["perspective", "pathModel", "pathTextureDiffuse", "sphere1", "sph
                "previewFreeRotY", "renderResX", "renderResY"]   # src/Project.h:64-73, in order
 
 
-def saveSettings(path, project):
-    """UiFrame::saveSettings, src/ui/UiFrame.cpp:323-331."""
+_FLOAT_MEMBERS = {f.name for f in dataclasses.fields(Project) if f.type in (float, "float")}
+
+
+def _settings_text(project):
+    """What `file << j` writes (src/ui/UiFrame.cpp:326-330): ONE compact line, keys sorted (nlohmann::json's object is a std::map), every
+    float the shortest digits of double(float(member)) — the member is a C++ float.  include/gsplat_extras.hpp writes the same bytes."""
+    f32 = lambda v: float(np.float32(v))
     j = {}
     for k in _SERIALISED:
         v = getattr(project, k)
-        j[k] = dataclasses.asdict(v) if isinstance(v, CameraSphere) else v
-    with open(path, "w") as f:
-        json.dump(j, f)
+        if isinstance(v, CameraSphere):
+            j[k] = dict(count=int(v.count), distance=f32(v.distance), fovDeg=f32(v.fovDeg), rotX=f32(v.rotX), rotY=f32(v.rotY))
+        elif isinstance(v, bool) or isinstance(v, str):
+            j[k] = v
+        elif k in _FLOAT_MEMBERS:
+            j[k] = f32(v)
+        else:
+            j[k] = int(v)
+    return json.dumps(j, sort_keys=True, separators=(",", ":"), ensure_ascii=False)
+
+
+def saveSettings(path, project):
+    """UiFrame::saveSettings, src/ui/UiFrame.cpp:323-331."""
+    with open(path, "w", encoding="utf-8") as f:
+        f.write(_settings_text(project))
 
 
 def loadSettings(path, project=None):
-    """UiFrame::loadSettings, src/ui/UiFrame.cpp:360-371: from_json WITH_DEFAULT — keys absent from the file keep defaults."""
-    project = project or Project()
-    with open(path) as f:
+    """UiFrame::loadSettings, src/ui/UiFrame.cpp:360-371: from_json WITH_DEFAULT (src/Project.h:22,64) — a key absent from the file gets
+    the value of a DEFAULT-CONSTRUCTED Project / CameraSphere (not the loaded-into object's current one), unknown keys are ignored, a value
+    of the wrong JSON type raises.  `project` (optional) is filled in place and returned."""
+    with open(path, encoding="utf-8") as f:
         j = json.load(f)
+    if not isinstance(j, dict):
+        raise RuntimeError("settings.json: the top level must be an object")
+    fresh = Project()
+
+    def number(key, v, as_int):
+        if isinstance(v, bool) or not isinstance(v, (int, float)):
+            raise RuntimeError(f'settings.json: "{key}" must be a number')
+        return int(v) if as_int else float(np.float32(v))
     for k in _SERIALISED:
+        default = getattr(fresh, k)
         if k not in j:
-            continue
-        if k in ("sphere1", "sphere2"):
-            sp = CameraSphere()
-            for kk, vv in j[k].items():
-                if hasattr(sp, kk):
-                    setattr(sp, kk, vv)
-            setattr(project, k, sp)
+            value = default
+        elif isinstance(default, CameraSphere):
+            if not isinstance(j[k], dict):
+                raise RuntimeError(f'settings.json: "{k}" must be an object')
+            value = CameraSphere()
+            for kk in ("count", "distance", "fovDeg", "rotX", "rotY"):
+                if kk in j[k]:
+                    setattr(value, kk, number(f"{k}.{kk}", j[k][kk], kk == "count"))
+        elif isinstance(default, bool):
+            if not isinstance(j[k], bool):
+                raise RuntimeError(f'settings.json: "{k}" must be true or false')
+            value = j[k]
+        elif isinstance(default, str):
+            if not isinstance(j[k], str):
+                raise RuntimeError(f'settings.json: "{k}" must be a string')
+            value = j[k]
         else:
-            setattr(project, k, j[k])
-    return project
+            value = number(k, j[k], k not in _FLOAT_MEMBERS)
+        if project is not None:
+            setattr(project, k, value)
+        else:
+            setattr(fresh, k, value)
+    return project if project is not None else fresh
 
 
 def saveCheckpoint(path, model, moment1=None, moment2=None, adam_steps=0, project=None):

@@ -66,6 +66,36 @@ int main(int argc, char** argv) {
         fclose(f);
         if (!past_end) return 9;
     }
+    {   // settings.json (UiFrame::saveSettings / loadSettings): <dir>/py_settings.json was written by io.py —
+        //   <dir>/cpp_settings.json = load(py_settings.json) saved again   (must equal io.py's own load -> save, byte for byte)
+        //   <dir>/cpp_made.json     = a project built here                   (io.py must read the same values back)
+        Project loaded;
+        loaded.iterations = 77; loaded.pathModel = "stale";       // WITH_DEFAULT: whatever the object held is replaced
+        loadSettings(dir + "/py_settings.json", loaded);
+        saveSettings(dir + "/cpp_settings.json", loaded);
+        Project made;
+        made.sphere2.count = 0; made.sphere2.fovDeg = 30.0f;
+        made.lrSh = 0.1f; made.lrLocation = 1.0e-7f; made.paramScaleMax = 123456.0f; made.previewTimer = 1.0e22f; made.previewFreeRotY = -0.0f;
+        made.iterations = 3491; made.previewTruth = true; made.previewFreeOrbit = false; made.renderResX = 4096;
+        made.pathModel = "C:\\models\\a \"quoted\" \xc3\xa4.obj"; made.perspective = "layout2|name=a;caption=\tb\n|";
+        saveSettings(dir + "/cpp_made.json", made);
+        // a file that holds two keys: everything else takes a fresh Project's defaults; unknown keys are ignored; the last duplicate wins
+        std::istringstream two("{ \"lrScale\": 0.5, \"sphere2\": {\"count\": 3}, \"noSuchKey\": [1, {\"a\": null}], \"lrScale\": 0.25 }");
+        Project part;
+        part.lrSh = 9.0f;
+        readSettings(two, part);
+        if (part.lrScale != 0.25f || part.sphere2.count != 3 || part.sphere2.distance != 10.0f || part.lrSh != 0.0001f || part.intervalDensify != 200) return 11;
+        int refused = 0;
+        for (const char* bad : { "{\"iterations\": \"many\"}", "{\"previewTruth\": 1}", "{\"sphere1\": 4}", "[1, 2]", "{\"lrSh\": 1.0", "{\"pathModel\": 3}" }) {
+            std::istringstream is(bad);
+            Project q;
+            try { readSettings(is, q); } catch (const std::runtime_error&) { refused++; }
+        }
+        try { Project q; loadSettings(dir + "/does_not_exist.json", q); } catch (const std::runtime_error&) { refused++; }
+        if (refused != 7) return 12;
+        if (jsonNumber(0.1) != "0.1" || jsonNumber(2.0) != "2.0" || jsonNumber(1e22) != "1e+22" || jsonNumber(0.0001) != "0.0001" || jsonNumber(0.00001) != "1e-05" ||
+            jsonNumber(1e16) != "1e+16" || jsonNumber(123456789012345.0) != "123456789012345.0" || jsonNumber((double)0.3f) != "0.30000001192092896") return 13;
+    }
     {   // the auto-train loop (UiFrame::update, src/ui/UiFrame.cpp:266-298) against a trainer that only counts
         struct Counting {
             int trains = 0, densifies = 0, captures = 0, cameras = 0;

@@ -23,10 +23,10 @@ pytestmark = pytest.mark.gpu
 K = 8
 
 
-def _assert_rates(label, k, r, statistical):
+def _assert_rates(label, k, r, statistical, flip_share=2e-4):
     n = r["n"]
     assert r["unexplained"] == 0, (label, k, r)
-    assert r["by_flip"] <= max(4, 2e-4 * n), (label, k, r)       # measured at cfg3: 198 of 6.0 M (3e-5)
+    assert r["by_flip"] <= max(4, flip_share * n), (label, k, r)       # measured at cfg3: 89 of 6.0 M (1.5e-5)
     assert r["by_ulps"] <= max(4, 2e-4 * n), (label, k, r)       # measured: 2 of 33 600, 1 of 4.8 M
     if statistical:
         assert r["within4"] >= r["ref_within4"] - 0.03, (label, k, r)
@@ -111,5 +111,7 @@ def test_seam_backward_lies_in_the_references_own_envelope(orc, P, M, D, W, H, s
         _, rates[n] = envelope_verdict(g[n], og[n], [x[n] for x in runs], sa[n], fl[n], 1e-4 * (sa[n] + fl[n]) + fl[n], k)
     label = f"seam {P} splats @{W}x{H}, M={M}"
     _line(label, "gs_rasterize_backward", rates)
+    # (one flipped pixel under a uniform random dL/dpixel moves the sums of every splat blended there: 26 of the 7200 sums of the
+    #  800-splat scene, the one scene of the five with a flipped pixel — tests/test_gpu_raster.py allows the flip allowance on 5 % of the splats)
     for k, rr in rates.items():
-        _assert_rates(label, k, rr, False)
+        _assert_rates(label, k, rr, False, flip_share=0.01)

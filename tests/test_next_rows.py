@@ -58,19 +58,29 @@ def test_gobj_round_trip(tmp_path):
 
 
 def test_settings_json_round_trip(tmp_path):
+    f32 = lambda v: float(np.float32(v))
     p = gs.Project.initProject()
     assert p.sphere2.count == 0 and p.sphere2.fovDeg == 30.0 and p.sphere1.count == 16
     p.lrSh, p.iterations, p.sphere1.rotX, p.pathModel = 0.1, 3491, 123.0, "C:/models/a.obj"
     path = tmp_path / "settings.json"
     gs.io.saveSettings(path, p)
-    j = json.load(open(path))
+    text = path.read_text()
+    j = json.loads(text)
+    # `file << j` (src/ui/UiFrame.cpp:329): one compact line, keys in std::map order, floats as double(float member)
+    assert "\n" not in text and ", " not in text and list(j) == sorted(j) and list(j["sphere1"]) == sorted(j["sphere1"])
     assert j["sphere1"] == {"count": 16, "distance": 10.0, "fovDeg": 60.0, "rotX": 123.0, "rotY": 0.0}
-    assert "updateRule" not in j and j["intervalDensify"] == 200 and len(j) == 35
+    assert "updateRule" not in j and j["intervalDensify"] == 200 and len(j) == 35 and j["lrSh"] == f32(0.1) != 0.1
     q = gs.io.loadSettings(path)
-    assert q.lrSh == 0.1 and q.iterations == 3491 and q.sphere1.rotX == 123.0 and q.sphere2.count == 0 and q.pathModel == p.pathModel
-    path.write_text('{"lrScale": 0.5, "sphere2": {"count": 3}}')               # WITH_DEFAULT: missing keys keep defaults
-    r = gs.io.loadSettings(path)
-    assert r.lrScale == 0.5 and r.sphere2.count == 3 and r.sphere2.distance == 10.0 and r.lrSh == pytest.approx(0.0001)
+    assert q.lrSh == f32(0.1) and q.iterations == 3491 and q.sphere1.rotX == 123.0 and q.sphere2.count == 0 and q.pathModel == p.pathModel
+    # from_json WITH_DEFAULT (src/Project.h:64): a key the file lacks gets a FRESH Project's value — also when loading into a used one
+    path.write_text('{"lrScale": 0.5, "sphere2": {"count": 3}, "noSuchKey": [1, 2]}')
+    used = gs.Project(lrSh=9.0, iterations=5)
+    r = gs.io.loadSettings(path, used)
+    assert r is used and r.lrScale == 0.5 and r.sphere2.count == 3 and r.sphere2.distance == 10.0 and r.lrSh == pytest.approx(0.0001) and r.iterations == 0
+    for bad in ('{"iterations": "many"}', '{"previewTruth": 1}', '{"sphere1": 4}', '[1, 2]', '{"pathModel": 3}'):
+        path.write_text(bad)
+        with pytest.raises(RuntimeError):
+            gs.io.loadSettings(path)
 
 
 def test_two_sphere_camera_rig():
@@ -178,8 +188,20 @@ def test_cpp_extras_header_and_gobj_interop(tmp_path):
     gs.io.saveSplats(tmp_path / "py.gobj", gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"]))
     obj = "v 0 0 0\nv 2 0 0\nv 2 0 -2\nv 0 0 -2\nv 1 3 1\nvt 0.5 0.5\nf 1/1/1 2/1/1 3/1/1 4/1/1\n# comment\nf 1 2 5\nf 3//2 5//2 4//2\n"
     (tmp_path / "mesh.obj").write_text(obj)
+    # settings.json, Python side of the interop: a project with values that exercise the number layout (tiny, huge, integral, negative zero)
+    ps = gs.Project.initProject()
+    ps.lrSh, ps.lrLocation, ps.paramScaleMax, ps.previewTimer, ps.previewFreeRotY, ps.iterations = 0.1, 1.0e-7, 123456.0, 1.0e22, -0.0, 3491
+    ps.previewTruth, ps.previewFreeOrbit, ps.renderResX = True, False, 4096
+    ps.pathModel, ps.perspective = 'C:\\models\\a "quoted" \u00e4.obj', "layout2|name=a;caption=\tb\n|"
+    gs.io.saveSettings(tmp_path / "py_settings.json", ps)
     out = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "extras ok" in out.stdout, (out.returncode, out.stderr)
+    # C++ load -> save of the Python file = the Python file; the same project built in C++ = the same bytes; Python reads both back
+    assert (tmp_path / "cpp_settings.json").read_bytes() == (tmp_path / "py_settings.json").read_bytes()
+    assert (tmp_path / "cpp_made.json").read_bytes() == (tmp_path / "py_settings.json").read_bytes()
+    back = gs.io.loadSettings(tmp_path / "cpp_made.json")
+    assert back.pathModel == ps.pathModel and back.perspective == ps.perspective and back.iterations == 3491 and back.previewTruth and not back.previewFreeOrbit
+    assert back.lrSh == float(np.float32(0.1)) and back.previewTimer == float(np.float32(1e22)) and back.sphere2.fovDeg == 30.0 and back.renderResX == 4096
     # cameras: the C++ rig and preview camera against camera.py (same formulas in fp32; sin / cos of two libms)
     pr = gs.Project.initProject()
     pr.sphere1.count, pr.sphere1.rotX, pr.sphere1.rotY = 5, 40.0, -15.0

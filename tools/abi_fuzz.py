@@ -109,7 +109,10 @@ def cases():
     add("trainer_set_compact_exchange(NULL trainer)")(lambda x: x["L"].gs_trainer_set_compact_exchange(NULL, cb, cb, NULL, 0, 2, 2, buf16))
     add("trainer_set_compact_exchange(rank >= world)")(lambda x: x["L"].gs_trainer_set_compact_exchange(x["t"], cb, cb, NULL, 2, 2, 2, buf16))
     add("trainer_set_compact_exchange(0 cameras)")(lambda x: x["L"].gs_trainer_set_compact_exchange(x["t"], cb, cb, NULL, 0, 2, 0, buf16))
-    add("trainer_set_compact_exchange(NULL campos)")(lambda x: x["L"].gs_trainer_set_compact_exchange(x["t"], cb, cb, NULL, 0, 2, 2, NULL))
+    add("trainer_set_compact_exchange(fewer cameras than ranks)")(lambda x: x["L"].gs_trainer_set_compact_exchange(x["t"], cb, cb, NULL, 0, 2, 1, NULL))
+    add("debug_hbm_copy_rate(NULL out)")(lambda x: x["L"].gs_debug_hbm_copy_rate(1 << 20, 1, None))
+    add("debug_hbm_copy_rate(bytes not a multiple of 16)")(lambda x: x["L"].gs_debug_hbm_copy_rate(1000, 1, C.byref(C.c_double())))
+    add("debug_hbm_copy_rate(0 repeats)")(lambda x: x["L"].gs_debug_hbm_copy_rate(1 << 20, 0, C.byref(C.c_double())))
     add("trainer_get_stream(NULL trainer)")(lambda x: x["L"].gs_trainer_get_stream(NULL, C.byref(outp)))
     add("trainer_get_stream(NULL out)")(lambda x: x["L"].gs_trainer_get_stream(x["t"], NULL))
     add("trainer_synchronize(NULL)")(lambda x: x["L"].gs_trainer_synchronize(NULL))
