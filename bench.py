@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--sh-fp16", action="store_true", help="trainer option sh_fp16: the projection reads a half-precision copy of the SH planes (BASELINE config 5)")
     ap.add_argument("--long-steps", type=int, default=2000, help="steps of the untimed-by-the-metric long run reported as `long_run` (0: skip); the default keeps "
                     "the GPU busy for ~2.5 s at cfg3, long enough for an external utilisation sampler to see the run")
+    ap.add_argument("--list-cut", type=int, default=1, help="diagnostic: 0 switches the depth cut of the tile lists off (trainer option list_cut; it only ever acts in dense scenes)")
     ap.add_argument("--fuse-update", type=int, default=1, help="diagnostic: 0 runs the update as a launch of its own (trainer option fuse_update) instead of inside the per-splat reduction")
     ap.add_argument("--views", type=int, default=0, help="diagnostic only: override the number of views per step (not the metric's config)")
     ap.add_argument("--exchange-overlap", type=int, default=0,
@@ -188,6 +189,8 @@ def main():
         tr.set_option("sh_fp16", 1)
     if not args.fuse_update:
         tr.set_option("fuse_update", 0)
+    if not args.list_cut:
+        tr.set_option("list_cut", 0)
     tr.captureTruths(cams, framesW, framesB)
     tr.shard(rank, world)
     proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM if args.update == "adam" else capi.GS_UPDATE_SGD_CLAMP)
@@ -571,6 +574,8 @@ def main():
                                       "the backward ran once per CAMERA; step_frac_form prices the bytes of the form that ran, every stage: the stricter figure"},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
             "update_fused_into_splat_backward": update_fused,
+            "list_cut": dict(zip(("attempts_with_cut_lists", "replayed_uncut"), tr.list_cut_stats()),
+                             note="depth cut of the tile lists (dense scenes only: from 384 entries per tile on average; the whole run incl. warm-up and untimed legs)"),
             "host": {"enqueue_us_per_step_mean": float(np.mean(host_us)), "enqueue_us_per_step_min": float(np.min(host_us)), "enqueue_us_per_step_max": float(np.max(host_us)),
                      "gpu_us_per_step": ms_per_step * 1e3,
                      "note": "wall time of the gs_trainer_step call on rank 0 (Python wrapper + C enqueue + the one early wait on the arena-overflow flags; a call that "

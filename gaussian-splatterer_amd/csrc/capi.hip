@@ -35,6 +35,9 @@ struct Options {
     int sort_grids = -1; // test hook: >= 0 replaces the device's hint for the sort grids: small_first | mid_grid << 16 (in tiles)
     int fuse_update = 1;  // a step with no collective between gradients and update applies the update inside the per-splat reduction (no update launch)
     int xchg_overlap = 1; // compact exchange: the all-reduce of the geometry planes runs on a second stream beside the all-gather (0: one after the other)
+    int list_cut = 1;     // tile lists cut at the depth the previous step's forward stopped looking (Dims::cut): 0 never, 1 where it pays (dense scenes)
+    int list_cut_min_avg = 384;  // ... i.e. from this many entries per tile on average (the previous step's count); test hook
+    int list_cut_margin = 64;    // entries kept behind the last one the forward looked at; test hook (negative: cuts that must be found wrong)
     int row_marks = -1;   // gradient rows only for evaluated entries (row_epoch marks): -1 per camera by its longest tile list (from 1024 entries), 0 never, 1 always
     int reuse_masks = 1;  // the backward reuses the forward's per-(tile sub-block, wave) block ballots; 0: it runs the block test itself (same bits)
     int roctx = 0;        // roctx range around every stage of a step (rocprofv3 --marker-trace names them); default from the environment: GS_ROCTX=1
@@ -54,6 +57,9 @@ static bool set_option(Options& o, const char* name, int value) {
     if (strcmp(name, "fuse_update") == 0) { o.fuse_update = value != 0; return true; }
     if (strcmp(name, "roctx") == 0) { o.roctx = value != 0; return true; }
     if (strcmp(name, "reuse_hit_masks") == 0) { o.reuse_masks = value != 0; return true; }
+    if (strcmp(name, "list_cut") == 0) { o.list_cut = value != 0; return true; }
+    if (strcmp(name, "list_cut_min_avg") == 0) { o.list_cut_min_avg = value < 0 ? 0 : value; return true; }
+    if (strcmp(name, "list_cut_margin") == 0) { o.list_cut_margin = value; return true; }
     if (strcmp(name, "row_marks") == 0) { o.row_marks = value < 0 ? -1 : (value != 0); return true; }
     return false;
 }
@@ -94,7 +100,7 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
     d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
     d.sgx = (d.gx + STILE - 1) / STILE; d.sgy = (d.gy + STILE - 1) / STILE; d.NST = d.sgx * d.sgy;
     d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = cull < 0 ? g_defaults.cull : cull; d.long_sort = 1; d.mid_sort = 1; d.small_first = 0; d.mid_grid = 0;
-    d.epoch = 1; d.marks_min_list = 0;
+    d.epoch = 1; d.marks_min_list = 0; d.cut = 0; d.cut_margin = 0;
     return d;
 }
 
@@ -150,7 +156,7 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
 }
 
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, rowmark, hmask, color, finalT, ncontrib, scan_tmp, sgrads, shjac, meancopy;
+    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, rowmark, hmask, color, finalT, ncontrib, scan_tmp, sgrads, shjac, meancopy, zcut, dropped;
     uint64_t rowmark_cleared = ~0ull;  // the generation of `rowmark` that has been zeroed (a new allocation holds stale bytes: the caller clears it and restarts the epochs)
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
@@ -197,10 +203,12 @@ struct ScratchSet {
         // [block_sums: v x splat_blocks(Pa)] [partials of the three-phase scan, used only past g_scan_single_max items]
         GS_TRY(scan_tmp.ensure((v * splat_blocks(Pa) + scan_partials_count(std::max(T, NST), (int)v) + 64) * 4));
         s.block_sums = scan_tmp.as<uint32_t>();
-        if (want_splat_grads) { GS_TRY(sgrads.ensure(v * Pa * 64)); GS_TRY(shjac.ensure(v * Pa * 48)); GS_TRY(meancopy.ensure((size_t)3 * Pa * 4)); }
+        if (want_splat_grads) { GS_TRY(sgrads.ensure(v * Pa * 64)); GS_TRY(shjac.ensure(v * Pa * 48)); GS_TRY(meancopy.ensure((size_t)3 * Pa * 4)); GS_TRY(zcut.ensure(v * T * 4)); GS_TRY(dropped.ensure(v * T * 4)); }
         s.splat_grads = sgrads.as<float>();
         s.sh_jac = want_splat_grads ? shjac.as<float>() : nullptr;
         s.mean_copy = want_splat_grads ? meancopy.as<float>() : nullptr;
+        s.tile_zcut = want_splat_grads ? zcut.as<uint32_t>() : nullptr;
+        s.tile_dropped = want_splat_grads ? dropped.as<uint32_t>() : nullptr;
         set_view_block_pointers(s, views.as<char>(), (int)v);
         s.geom = geom.as<GeomRec>();
         s.tiles_touched = tiles.as<uint32_t>();
@@ -234,7 +242,7 @@ struct ScratchSet {
     }
     void release() {
         for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &wghist, &colscan, &coarse_count, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &rowmark, &hmask, &color,
-                           &finalT, &ncontrib, &scan_tmp, &sgrads, &shjac, &meancopy })
+                           &finalT, &ncontrib, &scan_tmp, &sgrads, &shjac, &meancopy, &zcut, &dropped })
             b->release();
     }
 };
@@ -522,6 +530,11 @@ struct gs_trainer {
     uint32_t* h_flags = nullptr;  // pinned, [V][4] + loss[V]
     size_t h_flags_cap = 0;
     hipEvent_t ev_flags = nullptr;   // recorded behind the early copy of the overflow flags
+    uint32_t* h_cut = nullptr;       // pinned, [G][4]: the flags again, copied behind the forward of a step whose lists were cut
+    size_t h_cut_cap = 0;
+    hipEvent_t ev_cut = nullptr;
+    int cut_holdoff = 0, cut_holdoff_next = 2;   // steps without a cut after a wrong one (doubling up to 64, halving again with every good cut)
+    long long cut_steps = 0, cut_replays = 0;    // gs_trainer_list_cut_stats
     const void* views_on_device = nullptr;  // where the current view block was last uploaded (null: must upload)
     bool stats_stale = false;        // `last` lacks the device-side numbers (loss, list lengths) of the newest step
     uint32_t Rcap = 0;
@@ -666,6 +679,8 @@ extern "C" int gs_trainer_destroy(gs_trainer* t) {
     t->train.release(); t->preview.release();
     if (t->h_flags) (void)hipHostFree(t->h_flags);
     if (t->ev_flags) (void)hipEventDestroy(t->ev_flags);
+    if (t->h_cut) (void)hipHostFree(t->h_cut);
+    if (t->ev_cut) (void)hipEventDestroy(t->ev_cut);
     prof_resolve(t);
     for (hipEvent_t e : t->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(t->stream);
@@ -802,11 +817,41 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
         t->h_flags_cap = (size_t)V * 20;
     }
     if (!t->ev_flags) GS_HIP(hipEventCreateWithFlags(&t->ev_flags, hipEventDisableTiming));
+    // Depth cut of the tile lists (Dims::cut).  In a dense scene a tile's pixels finish long before its list ends (1M splats @2048^2:
+    // 170 of 1100 entries looked at), and from one training step to the next the model barely moves: the forward leaves, per tile, the
+    // depth behind which nothing was read, and the NEXT step's binning lists only what lies in front of it (+ a margin) — the scatter
+    // and the sort then handle a third of the entries.  The forward checks its own premise (every pixel of a shortened list must
+    // finish inside it); if it does not hold the camera's backward, per-splat stage and fused update skip themselves on the device,
+    // the host — which waits for that verdict behind the forward of a cut step, the rest of the step already queued — replays the
+    // step uncut and holds off for a few steps.  A cut step that stands is the uncut step bit for bit: same blend, same rows, same sums.
+    // Used where it pays (previous step: list_cut_min_avg entries per tile and more), with row marks (a dropped entry owns no row), on
+    // lists that saw at least one forward in this configuration (model, views, arena unchanged).
+    bool cut = false;
+    if (t->opt.list_cut && t->opt.row_marks != 0 && t->steps_on_these_lists >= 1 && P > 0 && t->VG > 0) {
+        if (t->cut_holdoff > 0) t->cut_holdoff--;
+        else {
+            unsigned long long entries = 0;
+            for (int g = 0; g < t->VG; g++) entries += t->h_flags[g * 4 + 2];
+            const unsigned long long tiles = (unsigned long long)t->VG * (unsigned long long)(((t->W + TILE - 1) / TILE) * ((t->H + TILE - 1) / TILE));
+            cut = entries >= (unsigned long long)t->opt.list_cut_min_avg * tiles;
+        }
+    }
+    if (cut) {
+        if (t->h_cut_cap < (size_t)t->VG * 16) {
+            if (t->h_cut) (void)hipHostFree(t->h_cut);
+            t->h_cut = nullptr;
+            GS_HIP(hipHostMalloc((void**)&t->h_cut, (size_t)t->VG * 16));
+            t->h_cut_cap = (size_t)t->VG * 16;
+        }
+        if (!t->ev_cut) GS_HIP(hipEventCreateWithFlags(&t->ev_cut, hipEventDisableTiming));
+    }
     for (;;) {
         Dims d;
         GS_TRY(trainer_dims(t, &d));
         GS_TRY(t->train.ensure(P, V, t->W, t->H, t->Rcap, true));
         d.Rcap = t->train.Rcap;
+        d.cut = cut ? 1 : 0;
+        d.cut_margin = t->opt.list_cut_margin;
         // The long-list sort launch is empty in most scenes (no tile list reaches SORT_SMALL_CAP entries) and still costs a
         // dependent launch — 7 us of a 255 us step at the 8-GPU load.  The host knows the longest list of two steps ago (the
         // device writes it after the early flag copy, which therefore carries the previous step's value): with a quarter of
@@ -847,7 +892,7 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
         // longest tile list of THIS step (the tile scan writes it before the backward runs; uses_row_marks): marks from 1024
         // entries on.  Either way the gradients are the same bits.  The host only supplies a fresh epoch per attempt and clears
         // all marks when the epochs wrap or the buffer is new.
-        d.epoch = 0; d.marks_min_list = t->opt.row_marks < 0 ? 1024u : 0u;
+        d.epoch = 0; d.marks_min_list = (t->opt.row_marks < 0 && !d.cut) ? 1024u : 0u;   // (an entry the cut dropped owns no gradient row: marks always)
         if (t->opt.row_marks != 0) {
             if (t->row_epoch >= 255 || t->train.rowmark_cleared != t->train.rowmark.generation) {
                 GS_HIP(hipMemsetAsync(t->train.rowmark.p, 0, t->train.rowmark.cap, t->stream));
@@ -893,6 +938,10 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
         GS_TRY(debug_check(t, 3));
         prof_stage_begin(t, 4, 3);
         GS_TRY(launch_render_forward(d, s, t->stream));
+        if (d.cut) {   // the forward's verdict on the cut, for the host (below)
+            GS_HIP(hipMemcpyAsync(t->h_cut, s.flags, (size_t)t->VG * 16, hipMemcpyDeviceToHost, t->stream));
+            GS_HIP(hipEventRecord(t->ev_cut, t->stream));
+        }
         prof_stage_end(t, 4);
         GS_TRY(debug_check(t, 4));
         if (P > 0) {  // an empty model has no gradients: its image is the background, its loss the residual against it
@@ -925,6 +974,20 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
             if (t->h_flags[g * 4 + 0] & 1u) overflow = true;
             need = std::max(need, t->h_flags[g * 4 + 2]);
         }
+        if (!overflow && d.cut) {
+            GS_HIP(hipEventSynchronize(t->ev_cut));
+            bool wrong = false;
+            for (int g = 0; g < t->VG; g++) wrong = wrong || (t->h_cut[g * 4 + 0] & 2u);
+            t->cut_steps++;
+            if (wrong) {   // replay uncut (nothing of this attempt was applied); no cut for a while
+                t->cut_replays++;
+                t->cut_holdoff = t->cut_holdoff_next;
+                t->cut_holdoff_next = std::min(64, t->cut_holdoff_next * 2);
+                cut = false;
+                continue;
+            }
+            t->cut_holdoff_next = std::max(2, t->cut_holdoff_next / 2);
+        }
         if (!overflow) break;
         GS_HIP(hipStreamSynchronize(t->stream));  // the overflowed groups' later stages are no-ops; drain them before regrowing
         prof_resolve(t);
@@ -950,6 +1013,13 @@ extern "C" int gs_trainer_accumulate(gs_trainer* t, gs_step_stats* stats) {
     GS_TRY(accumulate_async(t, true));
     GS_TRY(resolve_stats(t));  // callers of the split API read the gradient buffer next: hand it over complete
     if (stats) *stats = t->last;
+    return GS_OK;
+}
+
+extern "C" int gs_trainer_list_cut_stats(gs_trainer* t, long long* steps_cut, long long* replays) {
+    if (!t) return GS_ERR_INVALID_ARGUMENT;
+    if (steps_cut) *steps_cut = t->cut_steps;
+    if (replays) *replays = t->cut_replays;
     return GS_OK;
 }
 

@@ -96,6 +96,10 @@ struct Dims {
                       //    are few: the order is longest first) are sorted by k_tile_sort_mid.  0: its grid covers the whole order
     int mid_grid;     // workgroups per camera of k_tile_sort_mid (0: a default); it walks on in strides when the head is longer
     int epoch;        // 1 .. 255: the mark of this launch's gradient rows in Scratch::row_epoch; 0: no row marks (every entry owns a row)
+    int cut;          // 1: this step's tile lists hold only the entries up to the depth bound the previous step's forward left per tile
+                      //    (Scratch::tile_zcut) — the entries behind it were never looked at by any pixel of the tile then; the forward
+                      //    checks that they still are not (flags[g * 4 + 0] bit 1 = the cut was wrong: the host replays the step uncut)
+    int cut_margin;   // entries kept behind the last one the forward looked at when it writes the next bound
     uint32_t marks_min_list;  // with epoch != 0: a camera uses row marks iff its longest tile list (flags[g * 4 + 1], written by the tile
                               // scan of the same step) has at least this many entries — the backward and the per-splat kernel read the same
                               // word, so they agree; 0: always
@@ -123,6 +127,10 @@ struct Scratch {
     uint32_t* tile_count;      // [V][T]
     uint32_t* tile_end;        // [V][T]   inclusive scan of tile_count
     uint32_t* tile_order;      // [V][T]   tiles by descending entry count: the order workgroups take them in
+    uint32_t* tile_zcut;       // [G][T]   depth bits: every pixel of the tile finished in front of this depth in the newest forward (0xFFFFFFFF: no
+                               //          bound — some pixel looked at the whole list); trainer only, else null.  Written by k_render_fwd,
+                               //          read by the NEXT step's k_tile_count / k_tile_scatter when Dims::cut
+    uint32_t* tile_dropped;    // [G][T]   entries the cut kept out of the tile's list this step (k_tile_count; read by k_render_fwd's check)
     uint32_t* sort_marks;      // [G][2]   lengths of the order's heads that hold every list of SORT_SMALL_CAP / SORT_TINY_CAP entries and more
     uint32_t* id_of_slot;      // [V][Rcap] (only tiles longer than the rank-sort limit use it)
     uint32_t* point_list;      // [V][Rcap]  sorted splat ids
@@ -144,7 +152,7 @@ struct Scratch {
     uint32_t* n_contrib;       // [V][N]
     const uint32_t* truth;     // [V][N] or null
     const float* dL_dpix;      // [V][3][N] or null (then loss = truth/255 - colour is fused)
-    uint32_t* flags;           // [V][4]: 0 overflow, 1 max tile list
+    uint32_t* flags;           // [V][4]: 0 bit 0 arena overflow, bit 1 the depth cut of this step was wrong (k_render_fwd); 1 max tile list; 2 entries; 3 sort hints
     float* loss;               // [V][T] per-tile sum of residual^2 (only when truth != null); launch_loss_sum folds it
     float* loss_total;         // [V]
 };

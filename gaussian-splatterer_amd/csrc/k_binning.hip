@@ -313,10 +313,10 @@ int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
 // hundred workgroups of such a launch do not fill the chip, and its time is the latency of one workgroup's candidate walk)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_tile_count(Dims d, Scratch s) {
-    __shared__ uint32_t cnt[STILE * STILE];
+    __shared__ uint32_t cnt[STILE * STILE], drp[STILE * STILE];
     const int st = blockIdx.x, v = blockIdx.y;
     const int stx = st % d.sgx, sty = st / d.sgx;
-    if (threadIdx.x < STILE * STILE) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < STILE * STILE) { cnt[threadIdx.x] = 0; drp[threadIdx.x] = 0; }
     __syncthreads();
     if (!(s.flags[v * 4 + 0] & 1u)) {
         const size_t c0 = (size_t)v * d.NST + st;
@@ -329,6 +329,38 @@ __global__ __launch_bounds__(NT) void k_tile_count(Dims d, Scratch s) {
         // same-address LDS atomic per (candidate, tile) pair (which serialised: 27 M conflict cycles per launch at 1M splats).
         const int lane = threadIdx.x & 63;
         uint32_t mine = 0;  // lane tl < 16 accumulates the wave's count of tile tl
+        if (d.cut) {
+            // Depth cut (Dims::cut): an entry behind the bound the previous step's forward left for the tile is not listed.  Kept and
+            // dropped entries are counted apart; k_tile_scatter applies the same test.
+            const uint32_t* dl = s.coarse_depth + (size_t)v * d.Rcap + cstart;
+            uint32_t zc = 0xFFFFFFFFu, dropped = 0;
+            if (lane < STILE * STILE) {
+                const int tx = tx0 + (lane % STILE), ty = ty0 + (lane / STILE);
+                if (tx < d.gx && ty < d.gy) zc = s.tile_zcut[(size_t)v * d.T + ty * d.gx + tx];
+            }
+            for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < nc; c0 += NT) {
+                const uint32_t c = c0 + lane;
+                int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+                uint32_t dz = 0;
+                if (c < nc) {
+                    const uint4 e = list[c];
+                    dz = dl[c];
+                    x0 = max((int)(e.y & 0xffff), tx0); x1 = min((int)(e.z & 0xffff), tx0 + STILE);
+                    y0 = max((int)(e.y >> 16), ty0); y1 = min((int)(e.z >> 16), ty0 + STILE);
+                }
+#pragma unroll
+                for (int tl = 0; tl < STILE * STILE; tl++) {
+                    const int x = tx0 + (tl % STILE), y = ty0 + (tl / STILE);
+                    const bool in = x >= x0 && x < x1 && y >= y0 && y < y1;
+                    const bool keep = dz <= (uint32_t)__builtin_amdgcn_readlane((int)zc, tl);
+                    const unsigned long long mk = __ballot(in && keep), md = __ballot(in && !keep);
+                    mine += (lane == tl) ? (uint32_t)__popcll(mk) : 0u;
+                    dropped += (lane == tl) ? (uint32_t)__popcll(md) : 0u;
+                }
+            }
+            if (lane < STILE * STILE && mine) atomicAdd(&cnt[lane], mine);
+            if (lane < STILE * STILE && dropped) atomicAdd(&drp[lane], dropped);
+        } else {
         for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < nc; c0 += NT) {
             const uint32_t c = c0 + lane;
             int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
@@ -345,11 +377,15 @@ __global__ __launch_bounds__(NT) void k_tile_count(Dims d, Scratch s) {
             }
         }
         if (lane < STILE * STILE && mine) atomicAdd(&cnt[lane], mine);
+        }
     }
     __syncthreads();
     if (threadIdx.x < STILE * STILE) {
         const int tx = stx * STILE + (threadIdx.x % STILE), ty = sty * STILE + (threadIdx.x / STILE);
-        if (tx < d.gx && ty < d.gy) s.tile_count[(size_t)v * d.T + ty * d.gx + tx] = cnt[threadIdx.x];
+        if (tx < d.gx && ty < d.gy) {
+            s.tile_count[(size_t)v * d.T + ty * d.gx + tx] = cnt[threadIdx.x];
+            if (d.cut) s.tile_dropped[(size_t)v * d.T + ty * d.gx + tx] = drp[threadIdx.x];
+        }
     }
 }
 
@@ -558,15 +594,22 @@ __global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
     // waiting for scattered 8-byte stores and same-address LDS atomics.)
     const int lane = threadIdx.x & 63;
     const uint32_t seg_first = lane < STILE * STILE ? first[lane] : 0u;  // lane tl: start of tile tl's segment
+    uint32_t zc = 0xFFFFFFFFu;   // lane tl: the depth bound of tile tl (Dims::cut; k_tile_count counted with the same test)
+    if (d.cut && lane < STILE * STILE) {
+        const int tx = tx0 + (lane % STILE), ty = ty0 + (lane / STILE);
+        if (tx < d.gx && ty < d.gy) zc = s.tile_zcut[(size_t)v * d.T + ty * d.gx + tx];
+    }
     const unsigned long long big_mask = __ballot(lane < STILE * STILE && big[lane] != 0u);
     for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < nc; c0 += NT) {
         const uint32_t c = c0 + lane;
         uint4 e = make_uint4(0, 0, 0, 0);
         uint64_t dz = 0;
+        uint32_t dbits = 0;
         int rx0 = 0, ry0 = 0, rx1 = 0, x0 = 0, x1 = 0, y0 = 0, y1 = 0;
         if (c < nc) {
             e = list[c];
-            dz = (uint64_t)dlist[c] << 32;
+            dbits = dlist[c];
+            dz = (uint64_t)dbits << 32;
             rx0 = e.y & 0xffff; ry0 = e.y >> 16; rx1 = e.z & 0xffff;
             const int ry1 = e.z >> 16;
             x0 = max(rx0, tx0); x1 = min(rx1, tx0 + STILE);
@@ -577,7 +620,7 @@ __global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
 #pragma unroll
         for (int tl = 0; tl < STILE * STILE; tl++) {
             const int x = tx0 + (tl % STILE), y = ty0 + (tl / STILE);
-            const uint32_t k = (uint32_t)__popcll(__ballot(x >= x0 && x < x1 && y >= y0 && y < y1));
+            const uint32_t k = (uint32_t)__popcll(__ballot(x >= x0 && x < x1 && y >= y0 && y < y1 && dbits <= (uint32_t)__builtin_amdgcn_readlane((int)zc, tl)));
             mine = lane == tl ? k : mine;
         }
         // ... ONE LDS atomic instruction reserves the runs of all 16 tiles (a returning atomic per tile round was 16 dependent
@@ -589,7 +632,7 @@ __global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
 #pragma unroll
         for (int tl = 0; tl < STILE * STILE; tl++) {
             const int x = tx0 + (tl % STILE), y = ty0 + (tl / STILE);
-            const bool in = x >= x0 && x < x1 && y >= y0 && y < y1;
+            const bool in = x >= x0 && x < x1 && y >= y0 && y < y1 && dbits <= (uint32_t)__builtin_amdgcn_readlane((int)zc, tl);
             const unsigned long long m = __ballot(in);
             if (m == 0ull) continue;
             const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)seg_first, tl);

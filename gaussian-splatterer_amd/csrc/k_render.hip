@@ -123,6 +123,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
     // loop is the scalar walk over the ballot bits.
     float Tw = inside ? 1.0f : -1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
+    int walked = 0;   // list positions this wave looked at (uniform per wave): what the next step's depth cut must keep
 #ifdef GS_DIAG_COUNT_ACTIVE
     unsigned long long diag_hits = 0, diag_active = 0, diag_staged = 0;
 #endif
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
         const int cnt = min(WG, n - base);
         for (int sub = 0; sub < cnt; sub += 64) {
             if (__ballot(Tw > 0.0f) == 0ull) break;
+            walked = base + min(sub + 64, cnt);
             const int j = sub + lane;
             bool hit = false;
             if (j < cnt) {
@@ -179,6 +181,26 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
 #ifdef GS_DIAG_COUNT_ACTIVE
     if (lane == 0) { atomicAdd(&g_diag_counters[0], diag_hits); atomicAdd(&g_diag_counters[1], diag_active); atomicAdd(&g_diag_counters[4], diag_staged); }
 #endif
+    if (s.tile_zcut) {
+        // The depth bound for the NEXT step's lists (Dims::cut, k_tile_count / k_tile_scatter): if every pixel of the tile finished
+        // (T below 1e-4, or outside the image), nothing behind the last position a wave looked at was read — the bound is the depth of
+        // the entry cut_margin positions further on (the model moves a little between steps); else there is no bound.  And the check
+        // of THIS step's cut: a pixel that is still blending at the end of a list the cut shortened would have gone on into the
+        // dropped entries — the step is wrong from here on, everything behind the forward skips the camera and the host replays it.
+        __shared__ int s_walked;
+        __syncthreads();     // (the loop's last LDS reads are done: s_walked may share the staging area's bank, not its bytes)
+        if (tid == 0) s_walked = 0;
+        const int any_alive = __syncthreads_or(Tw > 0.0f);
+        if (lane == 0) atomicMax(&s_walked, walked);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t bound = 0xFFFFFFFFu;
+            const int keep = s_walked + d.cut_margin;
+            if (!any_alive && keep > 0 && keep < n) bound = __float_as_uint(geom[plist[keep - 1]].depth);
+            s.tile_zcut[(size_t)v * d.T + tile] = bound;
+            if (d.cut && any_alive && s.tile_dropped[(size_t)v * d.T + tile] != 0u) atomicOr(&s.flags[v * 4 + 0], 2u);
+        }
+    }
     const float T = fabsf(Tw);
     if (inside) {
         const size_t pix = (size_t)py * d.W + px;
@@ -375,7 +397,7 @@ __device__ __forceinline__ void render_bwd(const Dims& d, const Scratch& s, cons
     int vin[F];  // the passes whose residual images are summed; the rows go to the slice of the first one
 #pragma unroll
     for (int q = 0; q < F; q++) vin[q] = item[1 + q];
-    if (s.flags[g * 4 + 0] & 1u) return;
+    if (s.flags[g * 4 + 0] & 3u) return;   // arena overflow, or a depth cut the forward found wrong: the host replays the step
     if ((unsigned)tile >= (unsigned)d.T) return;  // see k_render_fwd
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, lane = tid & 63;

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(WG) GS_SBV_ATTR void k_splat_bwd_view(Dims d, const
     // culled splats touch no tile (k_preprocess); everything this kernel needs of the projection is in tiles_touched,
     // point_offsets and the 48-byte sh_jac record — the 64-byte GeomRec is not read here
     const uint32_t tiles = s.tiles_touched[(size_t)g * st + i];
-    if ((s.flags[g * 4 + 0] & 1u) || tiles == 0) {  // culled: the reference's nine buffers stay zero
+    if ((s.flags[g * 4 + 0] & 3u) || tiles == 0) {  // culled (or a group the host will replay): the reference's nine buffers stay zero
         const float4 z = make_float4(0, 0, 0, 0);
         if constexpr (SINGLE) {
             GradAcc<D> acc;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(WG) void k_splat_bwd_reduce(Dims d, const float* __
     if constexpr (UPD) {
         // an attempt whose binning arena overflowed is replayed by the host with a larger one: it must not move the model
         uint32_t overflow = 0;
-        for (int g = 0; g < d.VG; g++) overflow |= s.flags[g * 4 + 0] & 1u;
+        for (int g = 0; g < d.VG; g++) overflow |= s.flags[g * 4 + 0] & 3u;     // (bit 1: a depth cut the forward found wrong)
         apply = overflow == 0;
     }
     if (part == 0) {

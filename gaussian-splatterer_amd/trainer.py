@@ -193,6 +193,12 @@ class Trainer:
         """gs_trainer_set_option: this trainer's switches (include/gsplat.h), e.g. "fuse_camera_passes", "sh_fp16"."""
         capi.check(capi.lib().gs_trainer_set_option(self.handle, name.encode(), int(value)))
 
+    def list_cut_stats(self):
+        """gs_trainer_list_cut_stats: (accumulate attempts that ran with depth-cut tile lists, those of them that were replayed uncut)."""
+        a, b = C.c_longlong(), C.c_longlong()
+        capi.check(capi.lib().gs_trainer_list_cut_stats(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def synchronize(self):
         capi.check(capi.lib().gs_trainer_synchronize(self.handle))
 

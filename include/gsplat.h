@@ -307,6 +307,13 @@ int gs_trainer_set_sharded_update(gs_trainer* trainer, gs_collective_fn reduce_s
  * Trainer option "exchange_overlap" (default 1): 0 issues the two collectives one after the other on the trainer's stream. */
 int gs_trainer_set_compact_exchange(gs_trainer* trainer, gs_collective_fn all_gather, gs_allreduce_fn all_reduce, void* user, int rank,
                                     int world, int n_cameras, const float* campos);
+/* Depth cut of the tile lists (trainer option "list_cut", default 1): in a dense scene a training step lists, per tile,
+ * only the entries in front of the depth at which the PREVIOUS step's forward stopped reading that tile (+ a margin); the forward checks
+ * that every pixel of a shortened list still finishes inside it, and a step whose cut was wrong is replayed uncut before anything of it is
+ * applied — a cut step that stands equals the uncut step bit for bit.  steps_cut: accumulate attempts that ran with cut lists; replays:
+ * those of them the forward found wrong.  Related options (test hooks): "list_cut_min_avg" (entries per tile from which the cut is used,
+ * default 384), "list_cut_margin" (entries kept behind the last one read, default 64). */
+int gs_trainer_list_cut_stats(gs_trainer* trainer, long long* steps_cut, long long* replays);
 /* The HIP stream (hipStream_t) all of this trainer's work is enqueued on. */
 int gs_trainer_get_stream(gs_trainer* trainer, void** hip_stream);
 int gs_trainer_synchronize(gs_trainer* trainer);

@@ -238,6 +238,68 @@ def test_fused_update_equals_the_update_launch(orc, rule, sh_fp16, arena):
         assert np.abs(m1a).max() > 0
 
 
+def _heap_scene(P, M, seed):
+    """Thousands of splats heaped in a small volume: tile lists of many hundred entries whose pixels finish early — the scene the depth cut is for."""
+    rng = np.random.default_rng(seed)
+    s = gs.synth.random_splats(P, M, seed)
+    s["loc"] = np.ascontiguousarray(rng.normal(0.0, 0.6, (P, 3)), np.float32).reshape(-1)
+    s["scale"] = np.ascontiguousarray(rng.uniform(0.02, 0.09, (P, 3)), np.float32).reshape(-1)
+    s["opac"] = np.ascontiguousarray(rng.uniform(0.3, 1.0, P), np.float32)
+    return s
+
+
+@pytest.mark.parametrize("margin,fp16", [(64, 0), (8, 0), (-48, 0), (64, 1)])
+def test_depth_cut_lists_leave_every_bit_unchanged(orc, margin, fp16):
+    """Trainer option "list_cut" (csrc/capi.hip accumulate_async, Dims::cut): from its second step on a trainer lists, per tile, only the entries
+    in front of the depth at which the previous step's forward stopped reading (+ `margin` entries), and replays a step whose cut the forward
+    finds wrong.  Against the same run with the option off: statistics, gradient buffer, parameters and Adam moments bit for bit through
+    Adam steps with a densify in the middle (which restarts the cut) — with the default margin (cuts stand), a tight one, and a NEGATIVE one
+    (the cut falls inside what was read: steps must be found wrong and replayed, and the results still be the same bits)."""
+    P, M, n_cams, W, H = 24000, 4, 2, 160, 128
+    res = []
+    for cut in (1, 0):
+        s = _heap_scene(P, M, 515)
+        if fp16:
+            s["sh"] = s["sh"].astype(np.float16).astype(np.float32)
+        cams = gs.camera.get_cameras(n_cams, 6.0, 50.0)
+        fw, fb = _truths(orc, 400, M, 9, cams, W, H)
+        host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+        host.shDegree = s["D"]
+        host.capacity = P + P // 4
+        tr = gs.Trainer(W, H)
+        tr.set_option("list_cut", cut)
+        tr.set_option("list_cut_min_avg", 0)
+        tr.set_option("list_cut_margin", margin)
+        if fp16:
+            tr.set_option("sh_fp16", 1)
+        tr.model = gs.ModelSplatsDevice(host)
+        tr.captureTruths(cams, fw, fb)
+        proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=2e-3, lrSh=4e-3, lrScale=1e-3, lrOpacity=4e-3, lrRotation=2e-3,
+                          paramDensifyVariance=0.3, paramCullOpacity=0.31, paramSplitSize=0.085)
+        trail = []
+        for k in range(9):
+            st = tr.train(proj, densify=(k == 4), stats=True)
+            n = st.count_after
+            trail.append((st.num_rendered, st.loss, n, _read_grads(tr, n, M), _download(tr)))
+        m1, m2, steps = tr.adam_state()
+        res.append((trail, m1, m2, steps, tr.list_cut_stats(), st.max_tile_list))
+        tr.close()
+    (ta, m1a, m2a, sa, cut_a, longest_a), (tb, m1b, m2b, sb, cut_b, longest_b) = res
+    print(f"[depth cut, margin {margin}] {cut_a[0]} attempts with cut lists, {cut_a[1]} of them replayed uncut; longest list {longest_a} cut / {longest_b} uncut; "
+          f"{ta[0][0] // (2 * n_cams * ((W + 15) // 16) * ((H + 15) // 16))} entries per tile on average")
+    assert cut_b == (0, 0) and cut_a[0] >= 4                      # the cut ran (steps 2-4 and 6-9 at most: the first step of a configuration never cuts)
+    assert (cut_a[1] > 0) == (margin < 0), cut_a                  # wrong cuts exactly where they were provoked
+    assert longest_a < longest_b or margin < 0                    # and it shortened the lists
+    assert ta[4][2] != P and sa == sb == 9
+    for k, (a, b) in enumerate(zip(ta, tb)):
+        assert a[:3] == b[:3], (k, a[:3], b[:3])
+        for name in a[3]:
+            assert np.array_equal(a[3][name].view(np.uint32), b[3][name].view(np.uint32)), (k, name)
+        for name in ("loc", "sh", "scale", "opac", "rot"):
+            assert np.array_equal(a[4][name].view(np.uint32), b[4][name].view(np.uint32)), (k, name)
+    assert np.array_equal(m1a.view(np.uint32), m1b.view(np.uint32)) and np.array_equal(m2a.view(np.uint32), m2b.view(np.uint32))
+
+
 def test_training_reduces_loss(orc):
     P, M, n_cams, W, H = 2000, 4, 2, 128, 128
     s, cams, fw, fb, tr = _setup(orc, P, M, n_cams, W, H, 5)

@@ -293,7 +293,8 @@ def envelope_verdict(got, want, runs, sumabs, flip, budget, stride=1, widen=ENVE
       1  inside the envelope widened `widen` x about its middle (a held-out reference run is inside the 4 x widened one 99.7 % of the time);
       2  within `ulps` x 2^-24 of sum|term| carried through the chain (`sumabs`): the terms themselves are fp32 values whose exp and
          operation order differ from the oracle's in the last bits — what is left when all K runs agree bit for bit (a splat with one
-         or two terms has NO order noise) or nearly so; this replaces the former 1e-4 of sum|term|, at a sixth of its size;
+         or two terms has NO order noise) or nearly so; this replaces the former 1e-4 of sum|term|, at a sixth of its size (callers scale
+         it with the number of factors in the transmittance product where pixels blend thousands of entries: one ulp per factor);
       3  a NAMED decision flip: the oracle's flip analysis moved this entry (`flip` > 0) and the entry lies inside the accounted
          budget (`budget`, util.step_budget) — the one place the old budget survives;
       4  unexplained.
@@ -324,6 +325,13 @@ def envelope_verdict(got, want, runs, sumabs, flip, budget, stride=1, widen=ENVE
                  within4=float((np.abs(got - mid) <= 4 * hw).mean()), within16=float((np.abs(got - mid) <= widen * hw).mean()),
                  ref_inside=float(np.mean(loo_in)), ref_within4=float(np.mean(loo_4)),
                  by_ulps=int((cls == 2).sum()), by_flip=int((cls == 3).sum()), unexplained=int((cls == 4).sum()))
+    bad = cls == 4
+    if bad.any():     # what an unexplained entry looks like, for the assertion message
+        sa = np.asarray(sumabs, np.float64).reshape(-1)
+        i = int(np.flatnonzero(bad)[np.argmax((err / np.maximum(sa, 1e-300))[bad])])
+        rates["worst_unexplained"] = dict(index=i, got=float(got[i]), want=float(want[i]), lo=float(lo[i]), hi=float(hi[i]),
+                                          ulps_of_sumabs=float(err[i] / max(2.0 ** -24 * sa[i], 1e-300)), flip=float(np.asarray(flip).reshape(-1)[i]),
+                                          budget=float(np.asarray(budget).reshape(-1)[i]))
     return cls, rates
 
 

@@ -8,6 +8,26 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 lines = [l.lstrip(".") for l in open(src, errors="replace").read().splitlines()]   # pytest's progress dots share the line with the first print of a test
+def envelope_table(lines):
+    """The `[envelope, ...]` lines of tests/test_gpu_envelope.py as a table: per configuration, form and array the two pass-rates the
+    round-4 review asked for — strict 1e-4 of the value itself, inside the reference's own run-to-run envelope (beside a held-out run
+    of the reference) — and how every remaining entry is accounted for."""
+    rows = ["| configuration | form | array | entries | within 1e-4 of the value | inside the reference's envelope (a held-out reference run) | inside it widened 4x (reference) | widened 16x | by the ulps class | by a named decision flip | unexplained |",
+            "|---|---|---|---|---|---|---|---|---|---|---|"]
+    rx = re.compile(r"^\[envelope, (.*), (per-pass form|fused-pair step|gs_rasterize_backward)\] (.*)$")
+    item = re.compile(r"([A-Za-z_0-9 ]+): strict ([0-9.]+), inside ([0-9.]+) \(ref ([0-9.]+)\), 4x ([0-9.]+) \(ref ([0-9.]+)\), 16x ([0-9.]+), ulps (\d+), flips (\d+), unexplained (\d+) of (\d+)")
+    for l in lines:
+        m = rx.match(l)
+        if not m:
+            continue
+        for part in m.group(3).split("; "):
+            k = item.match(part.strip())
+            if k:
+                a, strict, ins, rins, w4, r4, w16, ul, fl, un, n = k.groups()
+                rows.append(f"| {m.group(1)} | {m.group(2)} | {a} | {n} | {strict} | {ins} ({rins}) | {w4} ({r4}) | {w16} | {ul} | {fl} | {un} |")
+    return rows if len(rows) > 2 else ["(no such line in this log)"]
+
+
 groups = [
     ("Whole step against the oracle (tests/test_gpu_trainer.py::test_step_sgd_matches_oracle, tests/test_gpu_fullsize.py::test_cfg5_per_rank_load_with_fp16_sh): "
      "every averaged-gradient entry — unexplained = outside `1e-4 of sum|term| carried through the chain + decision-flip allowance`; "
@@ -27,6 +47,15 @@ groups = [
 out = ["# Parity accounting as printed by the GPU test run", "",
        f"Source: `{src}` (`python -m pytest tests -m gpu -s` on the MI355X box).  Every line below is followed in its test by an assert; "
        "the oracle is a CPU restatement of the reference semantics — parity unpinned (DESIGN.md section 3).", ""]
+out += ["## The HIP path against the reference's own run-to-run envelope (tests/test_gpu_envelope.py)", "",
+        "K = 8 runs of the reference's arithmetic — the same fp32 terms, added in fp32 in seeded orders as upstream's atomicAdd does (oracle/gs_oracle.cpp, "
+        "atomic_prepare / atomic_sums), then the unchanged chain and accumulateGradients — give every entry an envelope [min, max].  Classes (util.envelope_verdict), "
+        "first that holds: within 1e-4 of the value; inside the envelope widened 16x; within 256 x 2^-24 of sum|term| (entries whose runs agree bit for bit); a NAMED "
+        "decision flip inside the old accounted budget; unexplained (asserted zero).  No conditioning / chain-noise / A-noise term takes part.", ""]
+out += envelope_table(lines) + [""]
+ref_noise = [l.rstrip() for l in lines if l.startswith("[reference noise")]
+if ref_noise:
+    out += ["## The reference's run-to-run noise against the 1e-4 budget (tests/test_reference_noise.py, CPU)", "", "```"] + ref_noise + ["```", ""]
 for title, rx in groups:
     hit = [l.rstrip() for l in lines if rx.match(l)]
     out += [f"## {title}", ""]
