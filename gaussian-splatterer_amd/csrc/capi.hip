@@ -156,7 +156,7 @@ static int build_view_block(const gs_view* views, int V, bool share, std::vector
 }
 
 struct ScratchSet {
-    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, rowmark, hmask, color, finalT, ncontrib, scan_tmp, sgrads, shjac, meancopy, zcut, dropped;
+    DevBuf views, geom, tiles, offsets, tloss, torder, zero_block, wghist, colscan, coarse_count, coarse_end, tile_count, tile_end, clist, cdepth, ids, plist, slist, G, rowmark, hmask, color, finalT, ncontrib, scan_tmp, sgrads, shjac, meancopy, zcut, szcut;
     uint64_t rowmark_cleared = ~0ull;  // the generation of `rowmark` that has been zeroed (a new allocation holds stale bytes: the caller clears it and restarts the epochs)
     int V = 0, Pa = 0, T = 0, N = 0, NST = 0;
     uint32_t Rcap = 0;
@@ -203,12 +203,12 @@ struct ScratchSet {
         // [block_sums: v x splat_blocks(Pa)] [partials of the three-phase scan, used only past g_scan_single_max items]
         GS_TRY(scan_tmp.ensure((v * splat_blocks(Pa) + scan_partials_count(std::max(T, NST), (int)v) + 64) * 4));
         s.block_sums = scan_tmp.as<uint32_t>();
-        if (want_splat_grads) { GS_TRY(sgrads.ensure(v * Pa * 64)); GS_TRY(shjac.ensure(v * Pa * 48)); GS_TRY(meancopy.ensure((size_t)3 * Pa * 4)); GS_TRY(zcut.ensure(v * T * 4)); GS_TRY(dropped.ensure(v * T * 4)); }
+        if (want_splat_grads) { GS_TRY(sgrads.ensure(v * Pa * 64)); GS_TRY(shjac.ensure(v * Pa * 48)); GS_TRY(meancopy.ensure((size_t)3 * Pa * 4)); GS_TRY(zcut.ensure(v * T * 4)); GS_TRY(szcut.ensure(v * NST * 4)); }
         s.splat_grads = sgrads.as<float>();
         s.sh_jac = want_splat_grads ? shjac.as<float>() : nullptr;
         s.mean_copy = want_splat_grads ? meancopy.as<float>() : nullptr;
         s.tile_zcut = want_splat_grads ? zcut.as<uint32_t>() : nullptr;
-        s.tile_dropped = want_splat_grads ? dropped.as<uint32_t>() : nullptr;
+        s.stile_zcut = want_splat_grads ? szcut.as<uint32_t>() : nullptr;
         set_view_block_pointers(s, views.as<char>(), (int)v);
         s.geom = geom.as<GeomRec>();
         s.tiles_touched = tiles.as<uint32_t>();
@@ -242,7 +242,7 @@ struct ScratchSet {
     }
     void release() {
         for (DevBuf* b : { &views, &geom, &tiles, &offsets, &tloss, &torder, &zero_block, &wghist, &colscan, &coarse_count, &coarse_end, &tile_count, &tile_end, &clist, &cdepth, &ids, &plist, &slist, &G, &rowmark, &hmask, &color,
-                           &finalT, &ncontrib, &scan_tmp, &sgrads, &shjac, &meancopy, &zcut, &dropped })
+                           &finalT, &ncontrib, &scan_tmp, &sgrads, &shjac, &meancopy, &zcut, &szcut })
             b->release();
     }
 };
@@ -919,6 +919,7 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
             t->views_on_device = (const void*)s.views;
         }
         prof_stage_begin(t, 0, -1);
+        if (d.cut) GS_TRY(launch_stile_zcut(d, s, t->stream));
         GS_TRY(launch_preprocess(d, m->planes, s, t->stream));
         prof_stage_end(t, 0);
         GS_TRY(debug_check(t, 0));

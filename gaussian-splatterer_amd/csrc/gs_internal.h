@@ -130,7 +130,8 @@ struct Scratch {
     uint32_t* tile_zcut;       // [G][T]   depth bits: every pixel of the tile finished in front of this depth in the newest forward (0xFFFFFFFF: no
                                //          bound — some pixel looked at the whole list); trainer only, else null.  Written by k_render_fwd,
                                //          read by the NEXT step's k_tile_count / k_tile_scatter when Dims::cut
-    uint32_t* tile_dropped;    // [G][T]   entries the cut kept out of the tile's list this step (k_tile_count; read by k_render_fwd's check)
+    uint32_t* stile_zcut;      // [G][NST] the largest bound of a super-tile's tiles (k_stile_zcut, first launch of a cut step): a candidate behind
+                               //          it is behind every tile's bound — the projection does not count it and the coarse scatter does not emit it
     uint32_t* sort_marks;      // [G][2]   lengths of the order's heads that hold every list of SORT_SMALL_CAP / SORT_TINY_CAP entries and more
     uint32_t* id_of_slot;      // [V][Rcap] (only tiles longer than the rank-sort limit use it)
     uint32_t* point_list;      // [V][Rcap]  sorted splat ids
@@ -164,6 +165,7 @@ __device__ inline bool uses_row_marks(const Dims& d, const Scratch& s, int g) { 
 // kernel launchers (one translation unit each)
 // ---------------------------------------------------------------------------------------------
 int launch_preprocess(const Dims& d, const float* params, const Scratch& s, hipStream_t st);
+int launch_stile_zcut(const Dims& d, const Scratch& s, hipStream_t st);   // Dims::cut: per super-tile, the largest depth bound of its tiles
 // after preprocess, one launch: column scan of the (block x super-tile) count matrix + the prefix of the per-block tile
 // sums (-> flags: num_rendered, arena overflow); the scan of the super-tile totals happens inside k_coarse_scatter
 int launch_coarse_colscan(const Dims& d, const Scratch& s, hipStream_t st);

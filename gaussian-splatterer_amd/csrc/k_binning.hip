@@ -288,6 +288,7 @@ __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
     for (int sy = sy0; sy < sy1; sy++)
         for (int sx = sx0; sx < sx1; sx++) {
             const int st = sy * d.sgx + sx;
+            if (d.cut && depth > s.stile_zcut[(size_t)v * d.NST + st]) continue;   // not counted by the projection either (k_preprocess)
             const uint32_t pos = atomicAdd(&cur[st], 1u);  // LDS: the block owns [its first position, + its count) of the list
             list[pos] = make_uint4((uint32_t)i, rmin, rmax, slot_base);
             dl[pos] = depth;
@@ -313,10 +314,10 @@ int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
 // hundred workgroups of such a launch do not fill the chip, and its time is the latency of one workgroup's candidate walk)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_tile_count(Dims d, Scratch s) {
-    __shared__ uint32_t cnt[STILE * STILE], drp[STILE * STILE];
+    __shared__ uint32_t cnt[STILE * STILE];
     const int st = blockIdx.x, v = blockIdx.y;
     const int stx = st % d.sgx, sty = st / d.sgx;
-    if (threadIdx.x < STILE * STILE) { cnt[threadIdx.x] = 0; drp[threadIdx.x] = 0; }
+    if (threadIdx.x < STILE * STILE) cnt[threadIdx.x] = 0;
     __syncthreads();
     if (!(s.flags[v * 4 + 0] & 1u)) {
         const size_t c0 = (size_t)v * d.NST + st;
@@ -330,10 +331,10 @@ __global__ __launch_bounds__(NT) void k_tile_count(Dims d, Scratch s) {
         const int lane = threadIdx.x & 63;
         uint32_t mine = 0;  // lane tl < 16 accumulates the wave's count of tile tl
         if (d.cut) {
-            // Depth cut (Dims::cut): an entry behind the bound the previous step's forward left for the tile is not listed.  Kept and
-            // dropped entries are counted apart; k_tile_scatter applies the same test.
+            // Depth cut (Dims::cut): an entry behind the bound the previous step's forward left for the tile is not listed;
+            // k_tile_scatter applies the same test.
             const uint32_t* dl = s.coarse_depth + (size_t)v * d.Rcap + cstart;
-            uint32_t zc = 0xFFFFFFFFu, dropped = 0;
+            uint32_t zc = 0xFFFFFFFFu;
             if (lane < STILE * STILE) {
                 const int tx = tx0 + (lane % STILE), ty = ty0 + (lane / STILE);
                 if (tx < d.gx && ty < d.gy) zc = s.tile_zcut[(size_t)v * d.T + ty * d.gx + tx];
@@ -352,14 +353,11 @@ __global__ __launch_bounds__(NT) void k_tile_count(Dims d, Scratch s) {
                 for (int tl = 0; tl < STILE * STILE; tl++) {
                     const int x = tx0 + (tl % STILE), y = ty0 + (tl / STILE);
                     const bool in = x >= x0 && x < x1 && y >= y0 && y < y1;
-                    const bool keep = dz <= (uint32_t)__builtin_amdgcn_readlane((int)zc, tl);
-                    const unsigned long long mk = __ballot(in && keep), md = __ballot(in && !keep);
+                    const unsigned long long mk = __ballot(in && dz <= (uint32_t)__builtin_amdgcn_readlane((int)zc, tl));
                     mine += (lane == tl) ? (uint32_t)__popcll(mk) : 0u;
-                    dropped += (lane == tl) ? (uint32_t)__popcll(md) : 0u;
                 }
             }
             if (lane < STILE * STILE && mine) atomicAdd(&cnt[lane], mine);
-            if (lane < STILE * STILE && dropped) atomicAdd(&drp[lane], dropped);
         } else {
         for (uint32_t c0 = (threadIdx.x >> 6) * 64; c0 < nc; c0 += NT) {
             const uint32_t c = c0 + lane;
@@ -382,11 +380,28 @@ __global__ __launch_bounds__(NT) void k_tile_count(Dims d, Scratch s) {
     __syncthreads();
     if (threadIdx.x < STILE * STILE) {
         const int tx = stx * STILE + (threadIdx.x % STILE), ty = sty * STILE + (threadIdx.x / STILE);
-        if (tx < d.gx && ty < d.gy) {
-            s.tile_count[(size_t)v * d.T + ty * d.gx + tx] = cnt[threadIdx.x];
-            if (d.cut) s.tile_dropped[(size_t)v * d.T + ty * d.gx + tx] = drp[threadIdx.x];
-        }
+        if (tx < d.gx && ty < d.gy) s.tile_count[(size_t)v * d.T + ty * d.gx + tx] = cnt[threadIdx.x];
     }
+}
+
+// Dims::cut, first launch of the step: the largest depth bound among a super-tile's tiles.  A candidate behind it lies behind the bound of
+// every tile it could be listed in, so the projection's count matrix and the coarse scatter leave it out (a super-tile with one unbounded
+// tile keeps everything).
+__global__ __launch_bounds__(WG) void k_stile_zcut(Dims d, Scratch s) {
+    const int st = blockIdx.x * WG + threadIdx.x, v = blockIdx.y;
+    if (st >= d.NST) return;
+    const int tx0 = (st % d.sgx) * STILE, ty0 = (st / d.sgx) * STILE;
+    uint32_t z = 0;
+    for (int ly = 0; ly < STILE; ly++)
+        for (int lx = 0; lx < STILE; lx++)
+            if (tx0 + lx < d.gx && ty0 + ly < d.gy) z = max(z, s.tile_zcut[(size_t)v * d.T + (ty0 + ly) * d.gx + tx0 + lx]);
+    s.stile_zcut[(size_t)v * d.NST + st] = z;
+}
+int launch_stile_zcut(const Dims& d, const Scratch& s, hipStream_t st) {
+    if (d.NST == 0 || d.VG == 0) return GS_OK;
+    hipLaunchKernelGGL(k_stile_zcut, dim3((d.NST + WG - 1) / WG, d.VG), dim3(WG), 0, st, d, s);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
 }
 
 int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st) {

@@ -211,8 +211,12 @@ __device__ inline uint32_t preprocess_one(const Dims& d, const SplatIn<D>& in, c
     // coarse binning: count the splat once per 64x64-px super-tile it touches, in the workgroup's LDS histogram.
     // (Global atomics for this cost 125 us of a 165 us launch: MI355X retires only ~10 G scattered atomics/s.)
     const int sx0 = rminx / STILE, sx1 = (rmaxx - 1) / STILE + 1, sy0 = rminy / STILE, sy1 = (rmaxy - 1) / STILE + 1;
+    // (Dims::cut: a candidate behind the depth bound of every tile of the super-tile is not counted — k_coarse_scatter applies the same test)
+    const uint32_t* zc = d.cut ? s.stile_zcut + (size_t)v * d.NST : nullptr;
+    const uint32_t dbits = __float_as_uint(pvz);
     for (int sy = sy0; sy < sy1; sy++)
-        for (int sx = sx0; sx < sx1; sx++) atomicAdd(&hist[sy * d.sgx + sx], 1u);
+        for (int sx = sx0; sx < sx1; sx++)
+            if (!zc || dbits <= zc[sy * d.sgx + sx]) atomicAdd(&hist[sy * d.sgx + sx], 1u);
     return ntiles;
 }
 

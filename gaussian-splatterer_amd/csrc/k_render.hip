@@ -123,6 +123,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
     // loop is the scalar walk over the ballot bits.
     float Tw = inside ? 1.0f : -1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
+    const uint32_t bound_used = (d.cut && tid == 0) ? s.tile_zcut[(size_t)v * d.T + tile] : 0xFFFFFFFFu;   // this step's list was built under it
     int walked = 0;   // list positions this wave looked at (uniform per wave): what the next step's depth cut must keep
 #ifdef GS_DIAG_COUNT_ACTIVE
     unsigned long long diag_hits = 0, diag_active = 0, diag_staged = 0;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
         // the entry cut_margin positions further on (the model moves a little between steps); else there is no bound.  And the check
         // of THIS step's cut: a pixel that is still blending at the end of a list the cut shortened would have gone on into the
         // dropped entries — the step is wrong from here on, everything behind the forward skips the camera and the host replays it.
+        // (A tile with a finite bound counts as shortened whether or not an entry actually lay behind the bound.)
         __shared__ int s_walked;
         __syncthreads();     // (the loop's last LDS reads are done: s_walked may share the staging area's bank, not its bytes)
         if (tid == 0) s_walked = 0;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
             const int keep = s_walked + d.cut_margin;
             if (!any_alive && keep > 0 && keep < n) bound = __float_as_uint(geom[plist[keep - 1]].depth);
             s.tile_zcut[(size_t)v * d.T + tile] = bound;
-            if (d.cut && any_alive && s.tile_dropped[(size_t)v * d.T + tile] != 0u) atomicOr(&s.flags[v * 4 + 0], 2u);
+            if (d.cut && any_alive && bound_used != 0xFFFFFFFFu) atomicOr(&s.flags[v * 4 + 0], 2u);
         }
     }
     const float T = fabsf(Tw);
