@@ -413,6 +413,9 @@ def main():
     capi.check(L.gs_trainer_stage_times(tr.handle, ms, launches))
     capi.check(L.gs_trainer_set_profiling(tr.handle, 0))
     st = tr.train(proj, densify=False, stats=True) if st is None else st
+    list_totals = (C.c_longlong * 4)()
+    capi.check(L.gs_trainer_debug_list_totals(tr.handle, list_totals))
+    list_totals = [int(x) for x in list_totals]
     # untimed, reported separately: the same steps in the per-pass form (option "fuse_camera_passes" off: one backward per
     # PASS, `var` produced on every step like the reference's accumulateGradients does), so that the cost of the dead
     # value the default step does not compute is on record
@@ -574,6 +577,7 @@ def main():
                                       "the backward ran once per CAMERA; step_frac_form prices the bytes of the form that ran, every stage: the stricter figure"},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
             "update_fused_into_splat_backward": update_fused,
+            "list_totals_last_step": dict(zip(("coarse_candidates", "tile_list_entries", "tiles_with_a_depth_bound", "tiles"), list_totals)),
             "list_cut": dict(zip(("attempts_with_cut_lists", "replayed_uncut"), tr.list_cut_stats()),
                              note="depth cut of the tile lists (dense scenes only: from 384 entries per tile on average; the whole run incl. warm-up and untimed legs)"),
             "host": {"enqueue_us_per_step_mean": float(np.mean(host_us)), "enqueue_us_per_step_min": float(np.min(host_us)), "enqueue_us_per_step_max": float(np.max(host_us)),

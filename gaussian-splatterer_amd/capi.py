@@ -57,7 +57,7 @@ SYMBOLS = [
     "gs_trainer_destroy", "gs_trainer_set_model", "gs_trainer_get_model", "gs_trainer_set_views", "gs_trainer_step",
     "gs_trainer_accumulate", "gs_trainer_grad_buffer", "gs_trainer_apply", "gs_trainer_set_allreduce",
     "gs_trainer_get_stream", "gs_trainer_synchronize", "gs_trainer_render", "gs_trainer_read_image",
-    "gs_trainer_set_option", "gs_trainer_list_cut_stats", "gs_trainer_set_sharded_update", "gs_trainer_attach_comm_sharded", "gs_trainer_set_compact_exchange", "gs_trainer_attach_comm_compact", "gs_trainer_set_profiling", "gs_trainer_stage_times", "gs_stage_name", "gs_trainer_adam_state", "gs_trainer_set_adam_state",
+    "gs_trainer_set_option", "gs_trainer_list_cut_stats", "gs_trainer_debug_list_totals", "gs_trainer_set_sharded_update", "gs_trainer_attach_comm_sharded", "gs_trainer_set_compact_exchange", "gs_trainer_attach_comm_compact", "gs_trainer_set_profiling", "gs_trainer_stage_times", "gs_stage_name", "gs_trainer_adam_state", "gs_trainer_set_adam_state",
     "gs_comm_unique_id", "gs_comm_create", "gs_comm_destroy", "gs_trainer_attach_comm", "gs_rasterize_forward",
     "gs_rasterize_backward", "gs_raster_chunk_field", "gs_image_float_to_int", "gs_image_int_to_loss",
 ]
@@ -101,6 +101,7 @@ def lib():
     L.gs_trainer_set_views.argtypes = [vp, i, vp, vp, i, i]
     L.gs_trainer_set_option.argtypes = [vp, C.c_char_p, i]
     L.gs_trainer_list_cut_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.gs_trainer_debug_list_totals.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.gs_trainer_step.argtypes = [vp, C.POINTER(gs_hyper), i, C.POINTER(gs_step_stats)]
     L.gs_trainer_accumulate.argtypes = [vp, C.POINTER(gs_step_stats)]
     L.gs_trainer_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]

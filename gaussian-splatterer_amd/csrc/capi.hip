@@ -1023,6 +1023,24 @@ extern "C" int gs_trainer_list_cut_stats(gs_trainer* t, long long* steps_cut, lo
     if (replays) *replays = t->cut_replays;
     return GS_OK;
 }
+// Diagnostic (synchronises): what the newest step's binning actually listed — out[0] candidates (splat, super-tile) emitted by the coarse
+// scatter, out[1] tile-list entries, out[2] tiles with a finite depth bound for the NEXT step, out[3] tiles — summed over the cameras.
+extern "C" int gs_trainer_debug_list_totals(gs_trainer* t, long long out[4]) {
+    if (!t || !out) return GS_ERR_INVALID_ARGUMENT;
+    GS_HIP(hipSetDevice(t->device));
+    GS_HIP(hipStreamSynchronize(t->stream));
+    const ScratchSet& ss = t->train;
+    const size_t G = (size_t)std::max(t->VG, 0);
+    std::vector<uint32_t> cc(G * ss.NST), tc(G * ss.T), zc(G * ss.T);
+    if (G && ss.s.coarse_count) GS_HIP(hipMemcpy(cc.data(), ss.s.coarse_count, cc.size() * 4, hipMemcpyDeviceToHost));
+    if (G && ss.s.tile_count) GS_HIP(hipMemcpy(tc.data(), ss.s.tile_count, tc.size() * 4, hipMemcpyDeviceToHost));
+    if (G && ss.s.tile_zcut) GS_HIP(hipMemcpy(zc.data(), ss.s.tile_zcut, zc.size() * 4, hipMemcpyDeviceToHost));
+    out[0] = out[1] = out[2] = 0; out[3] = (long long)tc.size();
+    for (uint32_t x : cc) out[0] += x;
+    for (uint32_t x : tc) out[1] += x;
+    if (ss.s.tile_zcut) for (uint32_t x : zc) out[2] += x != 0xFFFFFFFFu;
+    return GS_OK;
+}
 
 extern "C" int gs_trainer_grad_buffer(gs_trainer* t, float** p, size_t* n) {
     if (!t || !t->model) return GS_ERR_INVALID_ARGUMENT;

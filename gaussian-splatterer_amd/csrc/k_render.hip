@@ -196,9 +196,14 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
         if (lane == 0) atomicMax(&s_walked, walked);
         __syncthreads();
         if (tid == 0) {
+            // (a list that is already cut and was needed nearly to its end keeps its bound: asking for the depth of a position behind
+            //  the cut list would mean "no bound", and the tile would alternate between cut and uncut steps)
             uint32_t bound = 0xFFFFFFFFu;
             const int keep = s_walked + d.cut_margin;
-            if (!any_alive && keep > 0 && keep < n) bound = __float_as_uint(geom[plist[keep - 1]].depth);
+            //  — unless the pixels have come within a quarter of the margin of the cut list's end: then the tile asks for a full list once
+            //  ("no bound") and takes a fresh bound from it, instead of waiting for the cut to be found wrong, which costs the whole step)
+            if (!any_alive && keep > 0)
+                bound = keep < n ? __float_as_uint(geom[plist[keep - 1]].depth) : (s_walked + d.cut_margin / 4 < n ? bound_used : 0xFFFFFFFFu);
             s.tile_zcut[(size_t)v * d.T + tile] = bound;
             if (d.cut && any_alive && bound_used != 0xFFFFFFFFu) atomicOr(&s.flags[v * 4 + 0], 2u);
         }

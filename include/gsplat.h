@@ -314,6 +314,9 @@ int gs_trainer_set_compact_exchange(gs_trainer* trainer, gs_collective_fn all_ga
  * those of them the forward found wrong.  Related options (test hooks): "list_cut_min_avg" (entries per tile from which the cut is used,
  * default 384), "list_cut_margin" (entries kept behind the last one read, default 64). */
 int gs_trainer_list_cut_stats(gs_trainer* trainer, long long* steps_cut, long long* replays);
+/* Diagnostic (synchronises): what the newest step's binning listed, summed over the cameras — out[0] (splat, super-tile) candidates the coarse
+ * scatter emitted, out[1] tile-list entries, out[2] tiles that carry a finite depth bound for the next step, out[3] tiles. */
+int gs_trainer_debug_list_totals(gs_trainer* trainer, long long out[4]);
 /* The HIP stream (hipStream_t) all of this trainer's work is enqueued on. */
 int gs_trainer_get_stream(gs_trainer* trainer, void** hip_stream);
 int gs_trainer_synchronize(gs_trainer* trainer);
