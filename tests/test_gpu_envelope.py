@@ -23,11 +23,11 @@ pytestmark = pytest.mark.gpu
 K = 8
 
 
-def _assert_rates(label, k, r, statistical, flip_share=2e-4):
+def _assert_rates(label, k, r, statistical, flip_share=2e-4, ulps_share=2e-4):
     n = r["n"]
-    assert r["unexplained"] == 0, (label, k, r)
+    assert r["unexplained"] == 0, f"{label} / {k}: {r['unexplained']} unexplained of {n}; the worst: {r.get('worst_unexplained')}"
     assert r["by_flip"] <= max(4, flip_share * n), (label, k, r)       # measured at cfg3: 89 of 6.0 M (1.5e-5)
-    assert r["by_ulps"] <= max(4, 2e-4 * n), (label, k, r)       # measured: 2 of 33 600, 1 of 4.8 M
+    assert r["by_ulps"] <= max(4, ulps_share * n), (label, k, r)       # measured: 2 of 33 600, 1 of 4.8 M; 84 of 180 000 where pixels blend 3204 entries
     if statistical:
         assert r["within4"] >= r["ref_within4"] - 0.03, (label, k, r)
 
@@ -118,4 +118,4 @@ def test_seam_backward_lies_in_the_references_own_envelope(orc, P, M, D, W, H, s
     # (one flipped pixel under a uniform random dL/dpixel moves the sums of every splat blended there: 26 of the 7200 sums of the
     #  800-splat scene, the one scene of the five with a flipped pixel — tests/test_gpu_raster.py allows the flip allowance on 5 % of the splats)
     for k, rr in rates.items():
-        _assert_rates(label, k, rr, False, flip_share=0.01)
+        _assert_rates(label, k, rr, False, flip_share=0.01, ulps_share=2e-4 * ulps / util.ENVELOPE_ULPS)
