@@ -218,7 +218,8 @@ def test_fused_update_equals_the_update_launch(orc, rule, sh_fp16, arena):
         for k in range(5):
             st = tr.train(proj, densify=(k == 2), stats=True)
             n = st.count_after
-            trail.append((st.num_rendered, st.loss, st.arena_regrows, n, _read_grads(tr, n, M), _download(tr)))
+            # (a densify step re-strides the model: its gradient buffer is no longer addressable by the new count — the step before and after are)
+            trail.append((st.num_rendered, st.loss, st.arena_regrows, n, _read_grads(tr, n, M) if k != 2 else {}, _download(tr)))
         m1, m2, steps = tr.adam_state()
         res.append((trail, m1, m2, steps))
         tr.close()
@@ -281,7 +282,7 @@ def test_depth_cut_lists_leave_every_bit_unchanged(orc, margin, fp16):
         for k in range(9):
             st = tr.train(proj, densify=(k == 4), stats=True)
             n = st.count_after
-            trail.append((st.num_rendered, st.loss, n, _read_grads(tr, n, M), _download(tr)))
+            trail.append((st.num_rendered, st.loss, n, _read_grads(tr, n, M) if k != 4 else {}, _download(tr)))   # (no gradient read-back across the re-striding of a densify)
         m1, m2, steps = tr.adam_state()
         res.append((trail, m1, m2, steps, tr.list_cut_stats(), st.max_tile_list))
         tr.close()

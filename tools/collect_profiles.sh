@@ -18,6 +18,7 @@ python bench.py --steps 30 --no-cpu-baseline --force-dist --collective torch-com
 # host side of a data-parallel step at the per-rank load of a 4- / 8-GPU run (round-4 review, item 2a): the same one-rank step through the torch.distributed
 # hooks (a ctypes -> Python callback per collective and step) and through the library's own RCCL communicators (no Python in the step): `host` object of the line
 for v in 2 4; do for c in torch rccl torch-compact rccl-compact; do python bench.py --views $v --steps 300 --no-cpu-baseline --force-dist --collective $c --long-steps 0 > $out/diag_host_views${v}_$c.json 2>> $out/diag.err; done; done
+python bench.py --steps 30 --no-cpu-baseline --force-dist --collective auto --long-steps 0 > $out/diag_forcedist_auto.json 2>> $out/diag.err
 python bench.py --config 5 --views 8 --steps 20 --warmup 3 --no-cpu-baseline --sh-fp16 --list-cut 0 > $out/diag_config5views8_shfp16_nocut.json 2>> $out/diag.err
 python bench.py --no-cpu-baseline --fuse-update 0 --long-steps 0 > $out/diag_config3_update_launch.json 2>> $out/diag.err
 python tools/diag_envelope.py 1 s1 s2 2 3 > $out/envelope_diag.txt 2>&1; cp gpurun_out/r5_envelope_diag.json $out/envelope_diag.json
