@@ -971,6 +971,52 @@ inline bool pixel_run(const ViewState<R>& g, uint32_t beg, uint32_t end, R pixfx
     return true;
 }
 
+// Every pixel against its admissible blends: matches(pix, leaf) says whether a foreign result equals the blend `leaf`.  status[pix]: 0 the
+// nominal blend matched, 1 another admissible blend did, 2 none, 3 undecided (more than max_leaves blends); returns the count of status >= 2.
+template <class Match>
+int check_admissible(const ViewState<float>& g, float alpha_margin, float T_margin, int max_leaves, float exp_cond, int32_t* status, int32_t* leaves,
+                     Match matches) {
+    const int W = g.W, H = g.H;
+    const int T = g.gx * g.gy;
+    int n_bad = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : n_bad)
+    for (int tile = 0; tile < T; tile++) {
+        const int tx = tile % g.gx, ty = tile / g.gx;
+        const uint32_t beg = g.ranges[2 * (size_t)tile], end = g.ranges[2 * (size_t)tile + 1];
+        std::vector<std::vector<ForcedDecision>> stack;
+        for (int py = ty * TILE; py < std::min(H, (ty + 1) * TILE); py++)
+            for (int px = tx * TILE; px < std::min(W, (tx + 1) * TILE); px++) {
+                const size_t pix = (size_t)py * W + px;
+                stack.clear();
+                stack.push_back({});
+                int n_leaves = 0, st = 2;
+                bool first = true;
+                while (!stack.empty()) {
+                    std::vector<ForcedDecision> forced = std::move(stack.back());
+                    stack.pop_back();
+                    PixelLeaf<float> leaf;
+                    ForcedDecision br;
+                    if (pixel_run<float>(g, beg, end, (float)px, (float)py, forced, alpha_margin, T_margin, leaf, &br, exp_cond)) {
+                        n_leaves++;
+                        // the nominal blend is the leaf reached by taking the nominal value at every branch: explored first
+                        if (matches(pix, leaf)) { st = first ? 0 : 1; break; }
+                        first = false;
+                        if (n_leaves >= max_leaves) { st = 3; break; }
+                    } else {
+                        std::vector<ForcedDecision> other = forced;
+                        other.push_back({ br.k, br.kind, !br.value });
+                        forced.push_back(br);
+                        stack.push_back(std::move(other));   // explored after ...
+                        stack.push_back(std::move(forced));  // ... the nominal value (LIFO)
+                    }
+                }
+                status[pix] = st; leaves[pix] = n_leaves;
+                if (st >= 2) n_bad++;
+            }
+    }
+    return n_bad;
+}
+
 template <class R> struct State { ViewState<R> v; };
 
 template <class R>
@@ -1125,55 +1171,36 @@ int orc_check_pixels_f32(orc_state* s, const float* bg, const float* got_color, 
                          float alpha_margin, float T_margin, float rtol, float floor_T, float floor_C, int max_leaves,
                          int32_t* status, int32_t* leaves, float exp_cond) {
     const ViewState<float>& g = s->f.v;
-    const int W = g.W, H = g.H;
-    const size_t N = (size_t)W * H;
-    const int T = g.gx * g.gy;
-    int n_bad = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : n_bad)
-    for (int tile = 0; tile < T; tile++) {
-        const int tx = tile % g.gx, ty = tile / g.gx;
-        const uint32_t beg = g.ranges[2 * (size_t)tile], end = g.ranges[2 * (size_t)tile + 1];
-        std::vector<std::vector<ForcedDecision>> stack;
-        for (int py = ty * TILE; py < std::min(H, (ty + 1) * TILE); py++)
-            for (int px = tx * TILE; px < std::min(W, (tx + 1) * TILE); px++) {
-                const size_t pix = (size_t)py * W + px;
-                auto matches = [&](const PixelLeaf<float>& l) {
-                    if (l.last != got_last[pix]) return false;
-                    if (!(std::fabs(got_T[pix] - l.T) <= rtol * std::max(std::fabs(l.T), floor_T) + l.tolT)) return false;
-                    for (int c = 0; c < 3; c++) {
-                        const float want = l.C[c] + l.T * bg[c];
-                        if (!(std::fabs(got_color[c * N + pix] - want) <= rtol * std::max(std::fabs(want), floor_C) + l.tolC[c] + l.tolT * std::fabs(bg[c]))) return false;
-                    }
-                    return true;
-                };
-                stack.clear();
-                stack.push_back({});
-                int n_leaves = 0, st = 2;
-                bool first = true;
-                while (!stack.empty()) {
-                    std::vector<ForcedDecision> forced = std::move(stack.back());
-                    stack.pop_back();
-                    PixelLeaf<float> leaf;
-                    ForcedDecision br;
-                    if (pixel_run<float>(g, beg, end, (float)px, (float)py, forced, alpha_margin, T_margin, leaf, &br, exp_cond)) {
-                        n_leaves++;
-                        // the nominal blend is the leaf reached by taking the nominal value at every branch: explored first
-                        if (matches(leaf)) { st = first ? 0 : 1; break; }
-                        first = false;
-                        if (n_leaves >= max_leaves) { st = 3; break; }
-                    } else {
-                        std::vector<ForcedDecision> other = forced;
-                        other.push_back({ br.k, br.kind, !br.value });
-                        forced.push_back(br);
-                        stack.push_back(std::move(other));   // explored after ...
-                        stack.push_back(std::move(forced));  // ... the nominal value (LIFO)
-                    }
-                }
-                status[pix] = st; leaves[pix] = n_leaves;
-                if (st >= 2) n_bad++;
-            }
-    }
-    return n_bad;
+    const size_t N = (size_t)g.W * g.H;
+    return check_admissible(g, alpha_margin, T_margin, max_leaves, exp_cond, status, leaves, [&](size_t pix, const PixelLeaf<float>& l) {
+        if (l.last != got_last[pix]) return false;
+        if (!(std::fabs(got_T[pix] - l.T) <= rtol * std::max(std::fabs(l.T), floor_T) + l.tolT)) return false;
+        for (int c = 0; c < 3; c++) {
+            const float want = l.C[c] + l.T * bg[c];
+            if (!(std::fabs(got_color[c * N + pix] - want) <= rtol * std::max(std::fabs(want), floor_C) + l.tolC[c] + l.tolT * std::fabs(bg[c]))) return false;
+        }
+        return true;
+    });
+}
+// The same for an RGBA8 frame (imageFloatToInt, src/Trainer.cu:19-29: byte = clamp((int)(v * 256), 0, 255), R in the low byte) — what
+// Trainer::render hands out: a pixel is accepted when, for SOME admissible blend of it, every channel's float — anywhere within the
+// pixel tolerance (rtol max(|v|, floor_C) + the leaf's conditioning tolerance) of that blend's value — quantises to the byte the frame holds,
+// i.e. the tolerance interval meets the byte's float interval [b / 256, (b + 1) / 256) (open-ended at 0 and 255).  Same status codes.
+int orc_check_frame_f32(orc_state* s, const float* bg, const uint32_t* frame, float alpha_margin, float T_margin, float rtol, float floor_C,
+                        int max_leaves, int32_t* status, int32_t* leaves, float exp_cond) {
+    const ViewState<float>& g = s->f.v;
+    return check_admissible(g, alpha_margin, T_margin, max_leaves, exp_cond, status, leaves, [&](size_t pix, const PixelLeaf<float>& l) {
+        const uint32_t px = frame[pix];
+        if ((px >> 24) != 0xFFu) return false;
+        for (int c = 0; c < 3; c++) {
+            const int b = (int)((px >> (8 * c)) & 0xFFu);
+            const double want = (double)l.C[c] + (double)l.T * bg[c];
+            const double tol = (double)rtol * std::max(std::fabs(want), (double)floor_C) + l.tolC[c] + l.tolT * std::fabs(bg[c]);
+            const double lo = b == 0 ? -1e300 : b / 256.0, hi = b == 255 ? 1e300 : (b + 1) / 256.0;   // floats v with clamp((int)(v * 256)) == b
+            if (!(want + tol >= lo && want - tol < hi)) return false;
+        }
+        return true;
+    });
 }
 void orc_backward_f64(orc_state* s, int D, int M, const double* bg, const double* means, const double* shs,
                       const double* scales, double mod, const double* rots, const double* view, const double* proj,

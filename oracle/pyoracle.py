@@ -240,6 +240,22 @@ def check_pixels(r, got_color, got_T, got_last, alpha_margin=1e-4, T_margin=1e-4
     return status, leaves
 
 
+def check_frame(r, frame, alpha_margin=1e-4, T_margin=1e-4, rtol=1e-4, floor_C=1e-3, max_leaves=4096, exp_cond=0.0):
+    """An RGBA8 frame (uint32[N], imageFloatToInt layout) of the scene Rasterizer `r` last blended — Trainer::render's output — against
+    the admissible blends of every pixel (gs_oracle.cpp, orc_check_frame_f32): accepted when some admissible blend's colour, within the pixel
+    tolerance, quantises to the bytes the frame holds.  Returns (status int32[N]: 0 nominal, 1 another admissible blend, 2 none, 3 undecided; leaves)."""
+    a = r.args
+    assert r.dt == np.float32
+    N = a["W"] * a["H"]
+    fr = _c(frame, np.uint32).reshape(-1)
+    assert fr.size == N
+    status = np.zeros(N, np.int32)
+    leaves = np.zeros(N, np.int32)
+    lib().orc_check_frame_f32(r.h, _p(a["bg"], f32p), _p(fr, u32p), C.c_float(alpha_margin), C.c_float(T_margin), C.c_float(rtol), C.c_float(floor_C),
+                              C.c_int(max_leaves), _p(status, i32p), _p(leaves, i32p), C.c_float(exp_cond))
+    return status, leaves
+
+
 def chain(r, sums9):
     """The per-splat half of the backward (linear in the nine pixel-stage sums) of Rasterizer `r`'s last forward on
     caller-supplied sums9[P, 9]; returns dL_dmean3D / dL_dcov3D / dL_dsh / dL_dscale / dL_drot (fp32)."""

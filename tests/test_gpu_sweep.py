@@ -267,11 +267,14 @@ def test_random_scene_sweep(orc, seed):
     # boundary between the two values (util.unexplained_bytes) — zero unexplained bytes (round 4 allowed 1 % of them a step, unexamined)
     n_off, n_unexplained = unexplained_bytes(fbuf, rimg, rw, rh)
     if n_unexplained:
-        # needle splats seen along their long axis: the exponent's products cancel by orders of magnitude and alpha carries 2^-24 x that
-        # magnitude of relative error in ANY fp32 evaluation order (the float pixels of these scenes are compared with exp_cond = KAPPA,
-        # gs_oracle.cpp pixel_run) — such a byte must still sit on its boundary at ten times the plain pixel tolerance, and there are few
-        n_wide = unexplained_bytes(fbuf, rimg, rw, rh, rtol=1e-3)[1]
-        assert n_wide == 0 and n_unexplained <= 4, (seed, "render", rw, rh, mod, n_off, n_unexplained, n_wide)
+        # Not the quantisation of the NOMINAL blend within the plain pixel tolerance: then of some ADMISSIBLE blend of the pixel within the
+        # tolerance the float pixels of these scenes are held to — threshold decisions within 1e-4 taken the other way, and the conditioning of the
+        # exponent (needle splats seen along their long axis: alpha carries KAPPA x 2^-24 x the magnitude its power's products cancel from);
+        # oracle/gs_oracle.cpp orc_check_frame_f32.  Scene 12: one byte whose float lies 1.7e-3 from its k/256 boundary, explained this way.
+        rr = orc.Rasterizer(np.float32)
+        rr.forward(s["D"], M, vp["bg"], rw, rh, s["loc"], s["sh"], s["opac"], s["scale"], mod, s["rot"], vp["view"], vp["proj"], vp["campos"], vp["tanx"], vp["tany"])
+        status, _ = orc.check_frame(rr, fbuf, exp_cond=KAPPA)
+        assert int((status >= 2).sum()) == 0 and n_unexplained <= 4, (seed, "render", rw, rh, mod, n_off, n_unexplained, np.flatnonzero(status >= 2)[:4])
     print(f"[sweep {base + seed}: {kind}, {P} splats, M={M}, {2 * n_cams} passes @{W}x{H}] {st.num_rendered} list entries, longest tile list "
           f"{st.max_tile_list}: zero unexplained entries in both forms, worst error/budget {worst_all:.2f}; three Adam iterations and densify {P} -> {n2} splats bit-exact; render {rw}x{rh} x{mod:.2f}: {n_off} bytes one step off, each on a k/256 boundary; chain noise allowance up to {noise_share:.2g} x the sums' budget (dL_dscale)")
     tr.close()

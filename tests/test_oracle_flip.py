@@ -237,3 +237,38 @@ def test_power_sign_decision_on_the_ridge_of_a_needle(orc):
     g0 = r.backward(dpix.reshape(-1), want_abs=True, flip_margin=1e-6, want_cond=True, power_ulps=0.0)
     g1 = r.backward(dpix.reshape(-1), want_abs=True, flip_margin=1e-6, want_cond=True, power_ulps=d * 2.0 + 1.0)
     assert g0["flip9"].sum() == 0 and g1["flip9"][0, :3].min() > 0
+
+
+def test_frame_check_accepts_quantised_admissible_blends_only(orc):
+    """orc.check_frame (orc_check_frame_f32), the byte-level sibling of check_pixels used on Trainer::render's RGBA8 output: the oracle's own
+    image quantised with imageFloatToInt is the nominal blend everywhere; a byte moved one step is accepted only where the float sits within the
+    pixel tolerance of the k / 256 boundary between the two values; a byte moved two steps, or a wrong alpha byte, never."""
+    import util
+    P, M, D, W, H = 900, 4, 1, 96, 80
+    s, cams, views = util.make_scene(P, M, 31, W, H)
+    vp = util.view_parts(views[0])
+    r, img, _ = util.oracle_forward(orc, s, D, M, vp, W, H)
+    frame = orc.image_float_to_int(img, W, H)
+    status, _ = orc.check_frame(r, frame)
+    assert not status.any()
+    v = img.reshape(3, -1).astype(np.float64)
+    # pixels whose red channel lies far from a byte boundary (> 20 x the tolerance) and is not clamped
+    frac = v[0] * 256.0 - np.floor(v[0] * 256.0)
+    far = np.flatnonzero((frac > 0.3) & (frac < 0.7) & (v[0] > 0.05) & (v[0] < 0.9))[:50]
+    assert far.size >= 10
+    moved = frame.copy()
+    moved[far] += 1                                    # red + 1
+    status, _ = orc.check_frame(r, moved)
+    assert (status[far] == 2).all() and int((status >= 2).sum()) == far.size
+    # a float ON a boundary (within tolerance): both neighbouring bytes are accepted
+    near = np.flatnonzero((np.minimum(frac, 1.0 - frac) / 256.0 < 0.5e-4 * np.maximum(v[0], 1e-3)) & (v[0] > 0.05) & (v[0] < 0.9))
+    if near.size:
+        other = frame.copy()
+        up = frac[near] < 0.5                          # just above the boundary: the byte below is the alternative
+        other[near] = np.where(up, frame[near] - 1, frame[near] + 1)
+        status, _ = orc.check_frame(r, other)
+        assert not (status[near] >= 2).any()
+    two = frame.copy(); two[far[:5]] += 2
+    assert (orc.check_frame(r, two)[0][far[:5]] == 2).all()
+    alpha = frame.copy(); alpha[far[0]] &= 0x00FFFFFF
+    assert orc.check_frame(r, alpha)[0][far[0]] == 2

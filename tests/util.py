@@ -335,7 +335,7 @@ def envelope_verdict(got, want, runs, sumabs, flip, budget, stride=1, widen=ENVE
     return cls, rates
 
 
-def unexplained_bytes(frame, want_img, w, h, rtol=1e-4, floor=1e-3):
+def unexplained_bytes(frame, want_img, w, h, rtol=1e-4, floor=1e-3, details=None):
     """An RGBA8 frame (uint32[h * w], imageFloatToInt layout: R in the low byte, src/Trainer.cu:19-29) against the oracle's FLOAT image
     [3][h][w] of the same render.  A byte may differ from imageFloatToInt(oracle float) only by ONE step and only where the oracle's
     float v lies within the forward pixel tolerance — rtol * max(|v|, floor), the bar every float pixel is held to — of the boundary
@@ -357,4 +357,9 @@ def unexplained_bytes(frame, want_img, w, h, rtol=1e-4, floor=1e-3):
         tol = rtol * np.maximum(np.abs(v[c][d]), floor)
         ok = (np.abs(got - want)[d] == 1) & (np.abs(v[c][d] - boundary) <= tol)
         n_bad += int((~ok).sum())
+        if details is not None:     # (channel, pixel, oracle float, byte got, byte wanted, distance to the boundary / max(|v|, floor))
+            idx = np.flatnonzero(d)
+            for j in np.flatnonzero(~ok):
+                details.append((c, int(idx[j]), float(v[c][idx[j]]), int(got[idx[j]]), int(want[idx[j]]),
+                                float(abs(v[c][idx[j]] - boundary[j]) / max(abs(v[c][idx[j]]), floor))))
     return n_diff, n_bad
