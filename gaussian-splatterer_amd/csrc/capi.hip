@@ -100,7 +100,7 @@ static Dims make_dims(int P, int Pa, int D, int M, int W, int H, int V, uint32_t
     d.gx = (W + TILE - 1) / TILE; d.gy = (H + TILE - 1) / TILE; d.T = d.gx * d.gy;
     d.sgx = (d.gx + STILE - 1) / STILE; d.sgy = (d.gy + STILE - 1) / STILE; d.NST = d.sgx * d.sgy;
     d.V = V; d.VG = VG < 0 ? V : VG; d.Rcap = Rcap; d.mod = mod; d.cull = cull < 0 ? g_defaults.cull : cull; d.long_sort = 1; d.mid_sort = 1; d.small_first = 0; d.mid_grid = 0;
-    d.epoch = 1; d.marks_min_list = 0; d.cut = 0; d.cut_margin = 0;
+    d.epoch = 1; d.marks_min_list = 0; d.cut = 0; d.cut_track = 0; d.cut_margin = 0;
     return d;
 }
 
@@ -533,6 +533,7 @@ struct gs_trainer {
     uint32_t* h_cut = nullptr;       // pinned, [G][4]: the flags again, copied behind the forward of a step whose lists were cut
     size_t h_cut_cap = 0;
     hipEvent_t ev_cut = nullptr;
+    bool zcut_tracked = false;       // the newest forward of this configuration left the tiles' depth bounds
     int cut_holdoff = 0, cut_holdoff_next = 2;   // steps without a cut after a wrong one (doubling up to 64, halving again with every good cut)
     long long cut_steps = 0, cut_replays = 0;    // gs_trainer_list_cut_stats
     const void* views_on_device = nullptr;  // where the current view block was last uploaded (null: must upload)
@@ -826,16 +827,21 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
     // step uncut and holds off for a few steps.  A cut step that stands is the uncut step bit for bit: same blend, same rows, same sums.
     // Used where it pays (previous step: list_cut_min_avg entries per tile and more), with row marks (a dropped entry owns no row), on
     // lists that saw at least one forward in this configuration (model, views, arena unchanged).
-    bool cut = false;
+    // The forward of a step TRACKS the bounds (k_render_fwd<true>) only where the next step may use them — a scene that is dense by the previous
+    // step's entry count — and a step cuts only lists whose bounds the step before it tracked in this configuration; everywhere else (cfg1-cfg4)
+    // every kernel is the form without any of this.
+    bool cut = false, track = false;
     if (t->opt.list_cut && t->opt.row_marks != 0 && t->steps_on_these_lists >= 1 && P > 0 && t->VG > 0) {
-        if (t->cut_holdoff > 0) t->cut_holdoff--;
-        else {
-            unsigned long long entries = 0;
-            for (int g = 0; g < t->VG; g++) entries += t->h_flags[g * 4 + 2];
-            const unsigned long long tiles = (unsigned long long)t->VG * (unsigned long long)(((t->W + TILE - 1) / TILE) * ((t->H + TILE - 1) / TILE));
-            cut = entries >= (unsigned long long)t->opt.list_cut_min_avg * tiles;
+        unsigned long long entries = 0;
+        for (int g = 0; g < t->VG; g++) entries += t->h_flags[g * 4 + 2];
+        const unsigned long long tiles = (unsigned long long)t->VG * (unsigned long long)(((t->W + TILE - 1) / TILE) * ((t->H + TILE - 1) / TILE));
+        track = entries >= (unsigned long long)t->opt.list_cut_min_avg * tiles;
+        if (track && t->zcut_tracked) {
+            if (t->cut_holdoff > 0) t->cut_holdoff--;
+            else cut = true;
         }
     }
+    if (t->steps_on_these_lists == 0) t->zcut_tracked = false;
     if (cut) {
         if (t->h_cut_cap < (size_t)t->VG * 16) {
             if (t->h_cut) (void)hipHostFree(t->h_cut);
@@ -851,6 +857,7 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
         GS_TRY(t->train.ensure(P, V, t->W, t->H, t->Rcap, true));
         d.Rcap = t->train.Rcap;
         d.cut = cut ? 1 : 0;
+        d.cut_track = track ? 1 : 0;
         d.cut_margin = t->opt.list_cut_margin;
         // The long-list sort launch is empty in most scenes (no tile list reaches SORT_SMALL_CAP entries) and still costs a
         // dependent launch — 7 us of a 255 us step at the 8-GPU load.  The host knows the longest list of two steps ago (the
@@ -1001,6 +1008,7 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
     t->stats_stale = true;
     t->accumulated = true;
     t->steps_on_these_lists++;
+    t->zcut_tracked = track;      // the attempt that stands wrote every tile's bound (or none did)
     if (update_applied && *update_applied) {   // the attempt that went through applied the update (an overflowed one applies nothing: k_splat_bwd_reduce)
         if (fuse_h->update_rule == GS_UPDATE_ADAM) t->adam_t++;
         if (!(t->opt.sh_fp16 && t->sh16_of == (const void*)m->planes)) t->sh16_of = nullptr;
@@ -1204,6 +1212,7 @@ static int step_compact_exchange(gs_trainer* t, const gs_hyper* h, int densify, 
     x.geo = t->xgeo.as<float>(); x.rgb = t->xrgb.as<float>(); x.rank = t->xchg_rank; x.world = G; x.hdr = hdr;
     GS_TRY(accumulate_async(t, densify != 0, &x));   // sets x.slots for the form this step takes
     const bool per_pass = x.slots == 2 * cmax;
+    bool update_done = false;
     if (m->count > 0) {
         if (!t->stream2) GS_HIP(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
         if (!t->ev_packed) { GS_HIP(hipEventCreateWithFlags(&t->ev_packed, hipEventDisableTiming)); GS_HIP(hipEventCreateWithFlags(&t->ev_reduced, hipEventDisableTiming)); }
@@ -1245,22 +1254,39 @@ static int step_compact_exchange(gs_trainer* t, const gs_hyper* h, int densify, 
         GS_TRY(debug_check(t, 8));
         Dims d;
         GS_TRY(trainer_dims(t, &d));
+        // the update rides in the rebuild (every part updates the planes it has just written): no update launch, no gradient read-back
+        FusedUpdate fu;
+        const bool fuse = t->opt.fuse_update != 0 && t->train.s.mean_copy != nullptr;
+        if (fuse) {
+            GS_TRY(prepare_adam(t, h));
+            fu.u = make_update_args(Planes{ m->sh_coeffs }, *h, t->adam_t + 1);
+            fu.params = m->planes; fu.am = t->adam_m.as<float>(); fu.av = t->adam_v.as<float>();
+            fu.sh16 = (t->opt.sh_fp16 && t->sh16_of == (const void*)m->planes) ? t->sh16.as<uint16_t>() : nullptr;
+        }
+        const FusedUpdate* fup = fuse ? &fu : nullptr;
+        const float* mc = t->train.s.mean_copy;
         {
             StageScope stage(t, 6, 8);
             if (overlap) {
                 // the SH planes need the gathered records only: they are rebuilt while the all-reduce is still under way on the second
                 // stream; the twelve other planes follow behind its event
-                GS_TRY(launch_sh_rebuild(d, m->planes, x, C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 1, t->stream));
+                GS_TRY(launch_sh_rebuild(d, m->planes, mc, x, C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 1, t->stream, fup));
                 GS_HIP(hipStreamWaitEvent(t->stream, t->ev_reduced, 0));
                 second.armed = false;   // the main stream now waits for the all-reduce itself
-                GS_TRY(launch_sh_rebuild(d, m->planes, x, C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 2, t->stream));
+                GS_TRY(launch_sh_rebuild(d, m->planes, mc, x, C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 2, t->stream, fup));
             } else {
-                GS_TRY(launch_sh_rebuild(d, m->planes, x, C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 3, t->stream));
+                GS_TRY(launch_sh_rebuild(d, m->planes, mc, x, C_, per_pass, (float)t->total_samples, t->grad.as<float>(), 3, t->stream, fup));
             }
         }
         GS_TRY(debug_check(t, 6));
+        if (fuse) {
+            if (h->update_rule == GS_UPDATE_ADAM) t->adam_t++;
+            if (!fu.sh16) t->sh16_of = nullptr;
+            t->accumulated = false;
+            update_done = true;
+        }
     }
-    GS_TRY(apply_update(t, h, 6));
+    if (!update_done) GS_TRY(apply_update(t, h, 6));
     if (densify) {   // var and the averaged location gradient are complete on every rank: densify identically, no further exchange
         GS_TRY(resolve_stats(t));
         GS_TRY(trainer_densify(t, h, &t->last));

@@ -99,6 +99,7 @@ struct Dims {
     int cut;          // 1: this step's tile lists hold only the entries up to the depth bound the previous step's forward left per tile
                       //    (Scratch::tile_zcut) — the entries behind it were never looked at by any pixel of the tile then; the forward
                       //    checks that they still are not (flags[g * 4 + 0] bit 1 = the cut was wrong: the host replays the step uncut)
+    int cut_track;    // 1: this step's forward leaves the bounds for the next step (k_render_fwd<true>); a cut step always tracks
     int cut_margin;   // entries kept behind the last one the forward looked at when it writes the next bound
     uint32_t marks_min_list;  // with epoch != 0: a camera uses row marks iff its longest tile list (flags[g * 4 + 1], written by the tile
                               // scan of the same step) has at least this many entries — the backward and the per-splat kernel read the same
@@ -208,8 +209,9 @@ int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch&
                               const FusedUpdate* fu = nullptr, bool* update_applied = nullptr);
 // after the exchange: every averaged-gradient plane from the reduced geometry planes and the gathered dL_dRGB + camera positions
 // parts: 1 = the SH planes (from the gathered records), 2 = the twelve other planes (from the reduced sums), 3 = both
-int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, int n_cameras, bool per_pass, float samples,
-                      float* grad_planes, int parts, hipStream_t st);
+// fu (optional): the update fused into the rebuild (every part updates the planes it has just written); mean_copy: the projection's copy of the positions
+int launch_sh_rebuild(const Dims& d, const float* params, const float* mean_copy, const Exchange& x, int n_cameras, bool per_pass, float samples,
+                      float* grad_planes, int parts, hipStream_t st, const FusedUpdate* fu = nullptr);
 // Seam form: one view, reference-shaped AoS outputs with the reference's += / = discipline.
 struct SeamGrads { float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot; };
 int launch_splat_backward_seam(const Dims& d, const float* params, const Scratch& s, const SeamGrads& g, hipStream_t st);

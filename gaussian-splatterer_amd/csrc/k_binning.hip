@@ -245,6 +245,7 @@ size_t colscan_partial_words(int Pa, int NST, int V) {
 // coarse scatter: one thread per (view, splat); finishes the offsets scan, then one candidate record per super-tile
 // the splat touches
 // ---------------------------------------------------------------------------------------------
+template <bool CUT>
 __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
     extern __shared__ uint32_t sm[];
     uint32_t* cur = sm;             // [NST] next output position of this block in every super-tile's list: starts at the block's
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
     for (int sy = sy0; sy < sy1; sy++)
         for (int sx = sx0; sx < sx1; sx++) {
             const int st = sy * d.sgx + sx;
-            if (d.cut && depth > s.stile_zcut[(size_t)v * d.NST + st]) continue;   // not counted by the projection either (k_preprocess)
+            if (CUT && depth > s.stile_zcut[(size_t)v * d.NST + st]) continue;   // not counted by the projection either (k_preprocess)
             const uint32_t pos = atomicAdd(&cur[st], 1u);  // LDS: the block owns [its first position, + its count) of the list
             list[pos] = make_uint4((uint32_t)i, rmin, rmax, slot_base);
             dl[pos] = depth;
@@ -298,8 +299,13 @@ __global__ __launch_bounds__(WG) void k_coarse_scatter(Dims d, Scratch s) {
 int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.P == 0 || d.VG == 0) return GS_OK;
     const size_t lds = (size_t)d.NST * sizeof(uint32_t);
-    GS_TRY(allow_dynamic_lds((const void*)k_coarse_scatter, lds));
-    hipLaunchKernelGGL(k_coarse_scatter, dim3((d.P + WG - 1) / WG, d.VG), dim3(WG), lds, st, d, s);
+    if (d.cut) {
+        GS_TRY(allow_dynamic_lds((const void*)k_coarse_scatter<true>, lds));
+        hipLaunchKernelGGL(k_coarse_scatter<true>, dim3((d.P + WG - 1) / WG, d.VG), dim3(WG), lds, st, d, s);
+    } else {
+        GS_TRY(allow_dynamic_lds((const void*)k_coarse_scatter<false>, lds));
+        hipLaunchKernelGGL(k_coarse_scatter<false>, dim3((d.P + WG - 1) / WG, d.VG), dim3(WG), lds, st, d, s);
+    }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -312,7 +318,7 @@ int launch_coarse_scatter(const Dims& d, const Scratch& s, hipStream_t st) {
 #endif
 // NT threads per workgroup: 256, or 1024 for launches of up to four cameras (a super-tile's workgroup is then 16 waves wide: the few
 // hundred workgroups of such a launch do not fill the chip, and its time is the latency of one workgroup's candidate walk)
-template <int NT>
+template <int NT, bool CUT>
 __global__ __launch_bounds__(NT) void k_tile_count(Dims d, Scratch s) {
     __shared__ uint32_t cnt[STILE * STILE];
     const int st = blockIdx.x, v = blockIdx.y;
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(NT) void k_tile_count(Dims d, Scratch s) {
         // same-address LDS atomic per (candidate, tile) pair (which serialised: 27 M conflict cycles per launch at 1M splats).
         const int lane = threadIdx.x & 63;
         uint32_t mine = 0;  // lane tl < 16 accumulates the wave's count of tile tl
-        if (d.cut) {
+        if constexpr (CUT) {
             // Depth cut (Dims::cut): an entry behind the bound the previous step's forward left for the tile is not listed;
             // k_tile_scatter applies the same test.
             const uint32_t* dl = s.coarse_depth + (size_t)v * d.Rcap + cstart;
@@ -406,8 +412,13 @@ int launch_stile_zcut(const Dims& d, const Scratch& s, hipStream_t st) {
 
 int launch_tile_count(const Dims& d, const Scratch& s, hipStream_t st) {
     if (d.NST == 0 || d.VG == 0) return GS_OK;
-    if (d.VG <= GS_WIDE_BIN_MAX_GROUPS) hipLaunchKernelGGL(k_tile_count<1024>, dim3(d.NST, d.VG), dim3(1024), 0, st, d, s);
-    else hipLaunchKernelGGL(k_tile_count<WG>, dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+    if (d.cut) {
+        if (d.VG <= GS_WIDE_BIN_MAX_GROUPS) hipLaunchKernelGGL((k_tile_count<1024, true>), dim3(d.NST, d.VG), dim3(1024), 0, st, d, s);
+        else hipLaunchKernelGGL((k_tile_count<WG, true>), dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+    } else {
+        if (d.VG <= GS_WIDE_BIN_MAX_GROUPS) hipLaunchKernelGGL((k_tile_count<1024, false>), dim3(d.NST, d.VG), dim3(1024), 0, st, d, s);
+        else hipLaunchKernelGGL((k_tile_count<WG, false>), dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+    }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(WG) void k_tile_scan_order_scan(Dims d, Scratch s) 
 // the single-workgroup scan (14 us) disappears behind the scatter.  !SELF (images with more tiles than one workgroup
 // scans, or the "scan_single_max" test switch): tile_end comes from the separate scan launches in front.
 // ---------------------------------------------------------------------------------------------
-template <bool SELF, int NT>
+template <bool SELF, int NT, bool CUT>
 __global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
     __shared__ uint32_t cur[STILE * STILE], first[STILE * STILE], big[STILE * STILE];
     __shared__ uint32_t rowsum[STILE][NT / 64];
@@ -610,7 +621,7 @@ __global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
     const int lane = threadIdx.x & 63;
     const uint32_t seg_first = lane < STILE * STILE ? first[lane] : 0u;  // lane tl: start of tile tl's segment
     uint32_t zc = 0xFFFFFFFFu;   // lane tl: the depth bound of tile tl (Dims::cut; k_tile_count counted with the same test)
-    if (d.cut && lane < STILE * STILE) {
+    if (CUT && lane < STILE * STILE) {
         const int tx = tx0 + (lane % STILE), ty = ty0 + (lane / STILE);
         if (tx < d.gx && ty < d.gy) zc = s.tile_zcut[(size_t)v * d.T + ty * d.gx + tx];
     }
@@ -635,7 +646,7 @@ __global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
 #pragma unroll
         for (int tl = 0; tl < STILE * STILE; tl++) {
             const int x = tx0 + (tl % STILE), y = ty0 + (tl / STILE);
-            const uint32_t k = (uint32_t)__popcll(__ballot(x >= x0 && x < x1 && y >= y0 && y < y1 && dbits <= (uint32_t)__builtin_amdgcn_readlane((int)zc, tl)));
+            const uint32_t k = (uint32_t)__popcll(__ballot(x >= x0 && x < x1 && y >= y0 && y < y1 && (!CUT || dbits <= (uint32_t)__builtin_amdgcn_readlane((int)zc, tl))));
             mine = lane == tl ? k : mine;
         }
         // ... ONE LDS atomic instruction reserves the runs of all 16 tiles (a returning atomic per tile round was 16 dependent
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(NT) void k_tile_scatter(Dims d, Scratch s) {
 #pragma unroll
         for (int tl = 0; tl < STILE * STILE; tl++) {
             const int x = tx0 + (tl % STILE), y = ty0 + (tl / STILE);
-            const bool in = x >= x0 && x < x1 && y >= y0 && y < y1 && dbits <= (uint32_t)__builtin_amdgcn_readlane((int)zc, tl);
+            const bool in = x >= x0 && x < x1 && y >= y0 && y < y1 && (!CUT || dbits <= (uint32_t)__builtin_amdgcn_readlane((int)zc, tl));
             const unsigned long long m = __ballot(in);
             if (m == 0ull) continue;
             const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)seg_first, tl);
@@ -679,15 +690,22 @@ int launch_tile_scatter(const Dims& d, const Scratch& s, uint32_t* partials, hip
 #else
     if (d.T <= g_scan_single_max && d.T <= 16384) {
 #endif
-        if (d.VG <= GS_WIDE_BIN_MAX_GROUPS) hipLaunchKernelGGL((k_tile_scatter<true, 1024>), dim3(d.NST + 1, d.VG), dim3(1024), 0, st, d, s);
-        else hipLaunchKernelGGL((k_tile_scatter<true, WG>), dim3(d.NST + 1, d.VG), dim3(WG), 0, st, d, s);
+        if (d.cut) {
+            if (d.VG <= GS_WIDE_BIN_MAX_GROUPS) hipLaunchKernelGGL((k_tile_scatter<true, 1024, true>), dim3(d.NST + 1, d.VG), dim3(1024), 0, st, d, s);
+            else hipLaunchKernelGGL((k_tile_scatter<true, WG, true>), dim3(d.NST + 1, d.VG), dim3(WG), 0, st, d, s);
+        } else {
+            if (d.VG <= GS_WIDE_BIN_MAX_GROUPS) hipLaunchKernelGGL((k_tile_scatter<true, 1024, false>), dim3(d.NST + 1, d.VG), dim3(1024), 0, st, d, s);
+            else hipLaunchKernelGGL((k_tile_scatter<true, WG, false>), dim3(d.NST + 1, d.VG), dim3(WG), 0, st, d, s);
+        }
     } else if (d.T <= g_scan_single_max) {
         hipLaunchKernelGGL(k_tile_scan_order_scan, dim3(d.VG), dim3(WG), 0, st, d, s);
-        hipLaunchKernelGGL((k_tile_scatter<false, WG>), dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+        if (d.cut) hipLaunchKernelGGL((k_tile_scatter<false, WG, true>), dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+        else hipLaunchKernelGGL((k_tile_scatter<false, WG, false>), dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
     } else {
         GS_TRY(launch_scan_u32(s.tile_count, s.tile_end, d.T, d.T, d.VG, partials, st));
         hipLaunchKernelGGL(k_tile_scan_order_noscan, dim3(d.VG), dim3(WG), 0, st, d, s);
-        hipLaunchKernelGGL((k_tile_scatter<false, WG>), dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+        if (d.cut) hipLaunchKernelGGL((k_tile_scatter<false, WG, true>), dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
+        else hipLaunchKernelGGL((k_tile_scatter<false, WG, false>), dim3(d.NST, d.VG), dim3(WG), 0, st, d, s);
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

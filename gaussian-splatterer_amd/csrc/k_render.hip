@@ -91,6 +91,8 @@ int debug_counters(unsigned long long out[8], bool reset) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+// TRACK (a step whose NEXT step may cut its lists, Dims::cut_track): the forward also leaves every tile's depth bound and checks this step's cut
+template <bool TRACK>
 __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
 #pragma clang fp contract(fast)
     __shared__ StagedTile<WG> st;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
     // loop is the scalar walk over the ballot bits.
     float Tw = inside ? 1.0f : -1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
-    const uint32_t bound_used = (d.cut && tid == 0) ? s.tile_zcut[(size_t)v * d.T + tile] : 0xFFFFFFFFu;   // this step's list was built under it
+    const uint32_t bound_used = (TRACK && d.cut && tid == 0) ? s.tile_zcut[(size_t)v * d.T + tile] : 0xFFFFFFFFu;   // this step's list was built under it
     int walked = 0;   // list positions this wave looked at (uniform per wave): what the next step's depth cut must keep
 #ifdef GS_DIAG_COUNT_ACTIVE
     unsigned long long diag_hits = 0, diag_active = 0, diag_staged = 0;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
         const int cnt = min(WG, n - base);
         for (int sub = 0; sub < cnt; sub += 64) {
             if (__ballot(Tw > 0.0f) == 0ull) break;
-            walked = base + min(sub + 64, cnt);
+            if constexpr (TRACK) walked = base + min(sub + 64, cnt);
             const int j = sub + lane;
             bool hit = false;
             if (j < cnt) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
 #ifdef GS_DIAG_COUNT_ACTIVE
     if (lane == 0) { atomicAdd(&g_diag_counters[0], diag_hits); atomicAdd(&g_diag_counters[1], diag_active); atomicAdd(&g_diag_counters[4], diag_staged); }
 #endif
-    if (s.tile_zcut) {
+    if constexpr (TRACK) {
         // The depth bound for the NEXT step's lists (Dims::cut, k_tile_count / k_tile_scatter): if every pixel of the tile finished
         // (T below 1e-4, or outside the image), nothing behind the last position a wave looked at was read — the bound is the depth of
         // the entry cut_margin positions further on (the model moves a little between steps); else there is no bound.  And the check
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(WG) void k_render_fwd(Dims d, Scratch s) {
 
 int launch_render_forward(const Dims& d, const Scratch& s, hipStream_t stream) {
     if (d.T == 0 || d.VG == 0) return GS_OK;
-    hipLaunchKernelGGL(k_render_fwd, dim3(d.T, d.VG), dim3(WG), 0, stream, d, s);
+    if (d.cut_track && s.tile_zcut) hipLaunchKernelGGL(k_render_fwd<true>, dim3(d.T, d.VG), dim3(WG), 0, stream, d, s);
+    else hipLaunchKernelGGL(k_render_fwd<false>, dim3(d.T, d.VG), dim3(WG), 0, stream, d, s);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -641,39 +641,91 @@ __global__ __launch_bounds__(WG) void k_exchange_pack(Dims d, Scratch s, float s
 // Camera c of the iteration lives on rank c % world as that rank's local camera c / world.
 // parts: bit 0 = the SH planes (needs the gathered records only), bit 1 = the twelve other planes (needs the all-reduce only):
 // with the two collectives side by side the SH planes are rebuilt while the all-reduce is still under way.
-template <int D>
-__global__ __launch_bounds__(WG) void k_sh_rebuild(Dims d, const float* __restrict__ params, Exchange x,
-                                                   int n_cameras, int per_pass, float samples, float* __restrict__ grad, int parts) {
+// In PARTS like k_splat_bwd_reduce (blockIdx.y + first_part: 0 = the twelve other planes, 1 .. = SH coefficient ranges), and with UPD the
+// thread applies the update of its planes itself (FusedUpdate; the host only asks for it once the step's attempt stands, so there is no
+// flag to look at here): the data-parallel step then has no update launch either, and the gradient planes are not read back.
+template <int D, int K0, int K1, bool UPD>
+__device__ inline void rebuild_sh_part(const Dims& d, const Exchange& x, int n_cameras, int per_pass, float samples, float* __restrict__ grad,
+                                       const FusedUpdate& fu, bool last_part, float mx, float my, float mz, int i) {
+    constexpr int NC = (D + 1) * (D + 1), NK = K1 - K0;
+    const Planes pl{ d.M };
+    const size_t st = (size_t)d.Pa;
+    float a[NK][3];
+#pragma unroll
+    for (int k = 0; k < NK; k++) a[k][0] = a[k][1] = a[k][2] = 0.0f;
+    const int n_rec = per_pass ? 2 * n_cameras : n_cameras;
+    for (int r = 0; r < n_rec; r++) {
+        const int c = r < n_cameras ? r : r - n_cameras;
+        const int slot = (r < n_cameras ? 0 : x.slots / 2) + c / x.world;
+        const float* rgb = exchange_rgb(x, c % x.world, slot, st);
+        const float dRGB[3] = { rgb[i], rgb[st + i], rgb[2 * st + i] };
+        if (dRGB[0] != 0.0f || dRGB[1] != 0.0f || dRGB[2] != 0.0f) {        // (GradAcc::add_sh)
+            const float* cp = exchange_chunk(x, c % x.world, st) + 3 * (c / x.world);   // the position that came with the record
+            const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
+            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+            float basis[NC];
+            sh_basis<D>(ox / len, oy / len, oz / len, basis);
+#pragma unroll
+            for (int k = 0; k < NK; k++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) a[k][ch] += (basis[K0 + k] * dRGB[ch]) / samples;
+        }
+    }
+    int plane[3 * NK];
+    float g[3 * NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++)
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) { plane[3 * k + ch] = pl.sh(K0 + k, ch); g[3 * k + ch] = a[k][ch]; grad[pl.sh(K0 + k, ch) * st + i] = a[k][ch]; }
+    if (last_part)
+        for (int k = NC; k < d.M; k++)
+            for (int ch = 0; ch < 3; ch++) grad[pl.sh(k, ch) * st + i] = 0.0f;
+    if constexpr (UPD) {
+        update_planes<3 * NK>(fu, pl, plane, g, st, i);
+        if (last_part)
+            for (int k = NC; k < d.M; k++) {
+                const int pz[3] = { pl.sh(k, 0), pl.sh(k, 1), pl.sh(k, 2) };
+                const float gz[3] = { 0.0f, 0.0f, 0.0f };
+                update_planes<3>(fu, pl, pz, gz, st, i);
+            }
+    }
+}
+
+template <int D, bool UPD>
+__global__ __launch_bounds__(WG) void k_sh_rebuild(Dims d, const float* __restrict__ params_ro, const float* __restrict__ mean_copy, Exchange x,
+                                                   int n_cameras, int per_pass, float samples, float* __restrict__ grad, int first_part, FusedUpdate fu) {
     const int i = blockIdx.x * WG + threadIdx.x;
     if (i >= d.P) return;
     const Planes pl{ d.M };
     const size_t st = (size_t)d.Pa;
-    if (parts & 1) {
-        const float mx = params[pl.loc(0) * st + i], my = params[pl.loc(1) * st + i], mz = params[pl.loc(2) * st + i];
-        GradAcc<D> acc;
-        const int n_rec = per_pass ? 2 * n_cameras : n_cameras;
-        for (int k = 0; k < n_rec; k++) {
-            const int c = k < n_cameras ? k : k - n_cameras;
-            const int slot = (k < n_cameras ? 0 : x.slots / 2) + c / x.world;
-            const float* rgb = exchange_rgb(x, c % x.world, slot, st);
-            const float dRGB[3] = { rgb[i], rgb[st + i], rgb[2 * st + i] };
-            acc.add_sh(dRGB, samples, mx, my, mz, exchange_chunk(x, c % x.world, st) + 3 * (c / x.world));   // the position that came with the record
-        }
-        constexpr int NC = GradAcc<D>::NC;
+    const int part = first_part + blockIdx.y;
+    if (part == 0) {
+        int plane[11];
+        float g[11];
 #pragma unroll
-        for (int k = 0; k < NC; k++)
+        for (int c = 0; c < 3; c++) { plane[c] = pl.loc(c); g[c] = x.geo[c * st + i]; plane[3 + c] = pl.scale(c); g[3 + c] = x.geo[(3 + c) * st + i]; }
+        plane[6] = pl.opac(); g[6] = x.geo[6 * st + i];
 #pragma unroll
-            for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = acc.aSh[k][c];
-        for (int k = NC; k < d.M; k++)
-            for (int c = 0; c < 3; c++) grad[pl.sh(k, c) * st + i] = 0.0f;
-    }
-    if (parts & 2) {
+        for (int c = 0; c < 4; c++) { plane[7 + c] = pl.rot(c); g[7 + c] = x.geo[(7 + c) * st + i]; }
 #pragma unroll
-        for (int c = 0; c < 3; c++) { grad[pl.loc(c) * st + i] = x.geo[c * st + i]; grad[pl.scale(c) * st + i] = x.geo[(3 + c) * st + i]; }
-        grad[pl.opac() * st + i] = x.geo[6 * st + i];
-#pragma unroll
-        for (int c = 0; c < 4; c++) grad[pl.rot(c) * st + i] = x.geo[(7 + c) * st + i];
+        for (int k = 0; k < 11; k++) grad[(size_t)plane[k] * st + i] = g[k];
         grad[pl.var() * st + i] = x.geo[11 * st + i];
+        if constexpr (UPD) update_planes<11>(fu, pl, plane, g, st, i);
+        return;
+    }
+    // (UPD: the geometry part of the same splat may already have moved the position plane: the SH parts take it from the projection's copy)
+    float mx, my, mz;
+    if constexpr (UPD) { mx = mean_copy[i]; my = mean_copy[st + i]; mz = mean_copy[2 * st + i]; }
+    else { mx = params_ro[pl.loc(0) * st + i]; my = params_ro[pl.loc(1) * st + i]; mz = params_ro[pl.loc(2) * st + i]; }
+    if constexpr (D == 0) rebuild_sh_part<0, 0, 1, UPD>(d, x, n_cameras, per_pass, samples, grad, fu, true, mx, my, mz, i);
+    else if constexpr (D == 1) rebuild_sh_part<1, 0, 4, UPD>(d, x, n_cameras, per_pass, samples, grad, fu, true, mx, my, mz, i);
+    else if constexpr (D == 2) {
+        if (part == 1) rebuild_sh_part<2, 0, 5, UPD>(d, x, n_cameras, per_pass, samples, grad, fu, false, mx, my, mz, i);
+        else rebuild_sh_part<2, 5, 9, UPD>(d, x, n_cameras, per_pass, samples, grad, fu, true, mx, my, mz, i);
+    } else {
+        if (part == 1) rebuild_sh_part<3, 0, 6, UPD>(d, x, n_cameras, per_pass, samples, grad, fu, false, mx, my, mz, i);
+        else if (part == 2) rebuild_sh_part<3, 6, 11, UPD>(d, x, n_cameras, per_pass, samples, grad, fu, false, mx, my, mz, i);
+        else rebuild_sh_part<3, 11, 16, UPD>(d, x, n_cameras, per_pass, samples, grad, fu, true, mx, my, mz, i);
     }
 }
 
@@ -715,16 +767,26 @@ int launch_splat_backward_avg(const Dims& d, const float* params, const Scratch&
     return GS_OK;
 }
 
-int launch_sh_rebuild(const Dims& d, const float* params, const Exchange& x, int n_cameras, bool per_pass, float samples,
-                      float* grad, int parts, hipStream_t stream) {
-    if (d.P == 0) return GS_OK;
-    const dim3 grid((d.P + WG - 1) / WG);
+template <int D>
+static void launch_sh_rebuild_d(const Dims& d, const float* params, const float* mean_copy, const Exchange& x, int n_cameras, int pp, float samples, float* grad,
+                                int parts, const FusedUpdate* fu, hipStream_t stream) {
+    const int first = (parts & 2) ? 0 : 1;
+    const int count = ((parts & 2) ? 1 : 0) + ((parts & 1) ? reduce_parts<D>() - 1 : 0);
+    const dim3 grid((d.P + WG - 1) / WG, count);
+    if (fu && fu->params && mean_copy)
+        hipLaunchKernelGGL((k_sh_rebuild<D, true>), grid, dim3(WG), 0, stream, d, params, mean_copy, x, n_cameras, pp, samples, grad, first, *fu);
+    else
+        hipLaunchKernelGGL((k_sh_rebuild<D, false>), grid, dim3(WG), 0, stream, d, params, mean_copy, x, n_cameras, pp, samples, grad, first, FusedUpdate{});
+}
+int launch_sh_rebuild(const Dims& d, const float* params, const float* mean_copy, const Exchange& x, int n_cameras, bool per_pass, float samples,
+                      float* grad, int parts, hipStream_t stream, const FusedUpdate* fu) {
+    if (d.P == 0 || !(parts & 3)) return GS_OK;
     const int pp = per_pass ? 1 : 0;
     switch (d.D) {
-        case 0: hipLaunchKernelGGL(k_sh_rebuild<0>, grid, dim3(WG), 0, stream, d, params, x, n_cameras, pp, samples, grad, parts); break;
-        case 1: hipLaunchKernelGGL(k_sh_rebuild<1>, grid, dim3(WG), 0, stream, d, params, x, n_cameras, pp, samples, grad, parts); break;
-        case 2: hipLaunchKernelGGL(k_sh_rebuild<2>, grid, dim3(WG), 0, stream, d, params, x, n_cameras, pp, samples, grad, parts); break;
-        default: hipLaunchKernelGGL(k_sh_rebuild<3>, grid, dim3(WG), 0, stream, d, params, x, n_cameras, pp, samples, grad, parts); break;
+        case 0: launch_sh_rebuild_d<0>(d, params, mean_copy, x, n_cameras, pp, samples, grad, parts, fu, stream); break;
+        case 1: launch_sh_rebuild_d<1>(d, params, mean_copy, x, n_cameras, pp, samples, grad, parts, fu, stream); break;
+        case 2: launch_sh_rebuild_d<2>(d, params, mean_copy, x, n_cameras, pp, samples, grad, parts, fu, stream); break;
+        default: launch_sh_rebuild_d<3>(d, params, mean_copy, x, n_cameras, pp, samples, grad, parts, fu, stream); break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

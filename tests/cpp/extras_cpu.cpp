@@ -96,6 +96,14 @@ int main(int argc, char** argv) {
         if (jsonNumber(0.1) != "0.1" || jsonNumber(2.0) != "2.0" || jsonNumber(1e22) != "1e+22" || jsonNumber(0.0001) != "0.0001" || jsonNumber(0.00001) != "1e-05" ||
             jsonNumber(1e16) != "1e+16" || jsonNumber(123456789012345.0) != "123456789012345.0" || jsonNumber((double)0.3f) != "0.30000001192092896") return 13;
     }
+    {   // jsonNumber over <dir>/floats.bin (float32 values chosen by the Python side) -> <dir>/floats.txt, one number per line
+        std::ifstream in(dir + "/floats.bin", std::ios::binary);
+        if (in) {
+            std::ofstream out(dir + "/floats.txt");
+            float f;
+            while (in.read(reinterpret_cast<char*>(&f), sizeof f)) out << jsonNumber((double)f) << '\n';
+        }
+    }
     {   // the auto-train loop (UiFrame::update, src/ui/UiFrame.cpp:266-298) against a trainer that only counts
         struct Counting {
             int trains = 0, densifies = 0, captures = 0, cameras = 0;

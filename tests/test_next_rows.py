@@ -194,6 +194,13 @@ def test_cpp_extras_header_and_gobj_interop(tmp_path):
     ps.previewTruth, ps.previewFreeOrbit, ps.renderResX = True, False, 4096
     ps.pathModel, ps.perspective = 'C:\\models\\a "quoted" \u00e4.obj', "layout2|name=a;caption=\tb\n|"
     gs.io.saveSettings(tmp_path / "py_settings.json", ps)
+    # 4000 float32 values over the whole finite range (random bit patterns, plus decades, integers and boundary cases of the layout rule)
+    frng = np.random.default_rng(11)
+    bits = frng.integers(0, 2 ** 32, 3000, dtype=np.uint64).astype(np.uint32)
+    fl = bits.view(np.float32)
+    fl = np.concatenate([fl[np.isfinite(fl)], np.float32(10.0) ** np.arange(-38, 39, dtype=np.float32), np.arange(-20, 20, dtype=np.float32),
+                         np.array([0.0, -0.0, 1e-4, 9.999e-5, 1e16, 9.9999e15, 123456.0, 0.1, 1.0 / 3.0, 16777216.0, 3.4028235e38, 1.1754944e-38, 1e-45], np.float32)])
+    fl.astype(np.float32).tofile(tmp_path / "floats.bin")
     out = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "extras ok" in out.stdout, (out.returncode, out.stderr)
     # C++ load -> save of the Python file = the Python file; the same project built in C++ = the same bytes; Python reads both back
@@ -202,6 +209,10 @@ def test_cpp_extras_header_and_gobj_interop(tmp_path):
     back = gs.io.loadSettings(tmp_path / "cpp_made.json")
     assert back.pathModel == ps.pathModel and back.perspective == ps.perspective and back.iterations == 3491 and back.previewTruth and not back.previewFreeOrbit
     assert back.lrSh == float(np.float32(0.1)) and back.previewTimer == float(np.float32(1e22)) and back.sphere2.fovDeg == 30.0 and back.renderResX == 4096
+    # the C++ number writer = Python's float repr (what json.dumps writes) for every one of those values
+    got = (tmp_path / "floats.txt").read_text().split("\n")[:-1]
+    want = [json.dumps(float(x)) for x in fl.astype(np.float32)]
+    assert len(got) == len(want) and got == want, [(a, b) for a, b in zip(got, want) if a != b][:5]
     # cameras: the C++ rig and preview camera against camera.py (same formulas in fp32; sin / cos of two libms)
     pr = gs.Project.initProject()
     pr.sphere1.count, pr.sphere1.rotX, pr.sphere1.rotY = 5, 40.0, -15.0
