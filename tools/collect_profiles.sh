@@ -21,6 +21,7 @@ for v in 2 4; do for c in torch rccl torch-compact rccl-compact; do python bench
 python bench.py --steps 30 --no-cpu-baseline --force-dist --collective auto --long-steps 0 > $out/diag_forcedist_auto.json 2>> $out/diag.err
 python bench.py --config 5 --views 8 --steps 20 --warmup 3 --no-cpu-baseline --sh-fp16 --list-cut 0 > $out/diag_config5views8_shfp16_nocut.json 2>> $out/diag.err
 python bench.py --no-cpu-baseline --fuse-update 0 --long-steps 0 > $out/diag_config3_update_launch.json 2>> $out/diag.err
+python tools/local_step_at_world.py > $out/local_step_at_world.json 2>> $out/diag.err
 python tools/diag_envelope.py 1 s1 s2 2 3 > $out/envelope_diag.txt 2>&1; cp gpurun_out/r5_envelope_diag.json $out/envelope_diag.json
 # roctx stage ranges (trainer option "roctx" via GS_ROCTX=1): marker + kernel trace of a short run, no counters in the same run
 ( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && GS_ROCTX=1 rocprofv3 --marker-trace --kernel-trace --stats -d $out/roctx_raw -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --long-steps 0 --prewarm-seconds 0 > $out/roctx_bench.json 2> $out/roctx.err; f=$(find $out/roctx_raw -name "*marker*stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $out/roctx_marker_stats.csv; find $out/roctx_raw -name "*marker_api_trace.csv" | head -1 | xargs -r head -40 > $out/roctx_marker_trace_head.csv; rm -rf $out/roctx_raw )

@@ -12,6 +12,7 @@ cp $src/stats_dense/kernel_stats.csv $dst/${p}_kernel_stats_config5views8_steps2
 cp $src/pmc/summary.json $dst/${p}_pmc_per_kernel.json
 cp $src/pmc_dense/summary.json $dst/${p}_pmc_per_kernel_config5views8.json
 for f in $src/diag_*.json $src/lanes_*.json; do [ -f "$f" ] && tail -1 $f > $dst/${p}_$(basename $f); done
+[ -f $src/local_step_at_world.json ] && cp $src/local_step_at_world.json $dst/${p}_local_step_at_world.json
 [ -f $src/envelope_diag.json ] && cp $src/envelope_diag.json $dst/${p}_envelope_diag.json
 for f in roctx_marker_stats.csv roctx_marker_trace_head.csv; do [ -f $src/$f ] && cp $src/$f $dst/${p}_$f; done
 python3 tools/pmc_to_latest.py $src/pmc/summary.json profiles/pmc_latest.json > /dev/null
