@@ -97,8 +97,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and the collective hook even with one rank (plumbing test)")
     ap.add_argument("--no-stage-events", action="store_true", help="diagnostic only: time the steps without the per-stage HIP events (no roofline object)")
     ap.add_argument("--sh-fp16", action="store_true", help="trainer option sh_fp16: the projection reads a half-precision copy of the SH planes (BASELINE config 5)")
-    ap.add_argument("--long-steps", type=int, default=2000, help="steps of the untimed-by-the-metric long run reported as `long_run` (0: skip); the default keeps "
-                    "the GPU busy for ~2.5 s at cfg3, long enough for an external utilisation sampler to see the run")
+    ap.add_argument("--long-steps", type=int, default=6000, help="steps of the untimed-by-the-metric long run reported as `long_run` (0: skip); the default keeps "
+                    "the GPU busy for ~8 s at cfg3 (capped at ~8 s for every configuration): a run an external utilisation sampler with a period of seconds gets to see")
     ap.add_argument("--list-cut", type=int, default=1, help="diagnostic: 0 switches the depth cut of the tile lists off (trainer option list_cut; it only ever acts in dense scenes)")
     ap.add_argument("--fuse-update", type=int, default=1, help="diagnostic: 0 runs the update as a launch of its own (trainer option fuse_update) instead of inside the per-splat reduction")
     ap.add_argument("--views", type=int, default=0, help="diagnostic only: override the number of views per step (not the metric's config)")
@@ -385,8 +385,8 @@ def main():
     # only figure on record — clocks, caches and the run-ahead host queue have all settled by then
     capi.check(L.gs_trainer_set_profiling(tr.handle, 0))
     n_long = args.long_steps
-    if n_long > 0 and args.steps > 0:   # keep the long run within ~4 s whatever the configuration (cfg5: 7 ms per step)
-        n_long = max(min(n_long, int(4.0 / max(elapsed / args.steps, 1e-6))), min(n_long, 50))
+    if n_long > 0 and args.steps > 0:   # keep the long run within ~8 s whatever the configuration (cfg5: 5 ms per step)
+        n_long = max(min(n_long, int(8.0 / max(elapsed / args.steps, 1e-6))), min(n_long, 50))
     long_run = None
     if n_long > 0:
         # learning rates 0 for these steps: the same kernels and the same bytes (the update runs, the Adam moments move), but the model

@@ -803,9 +803,9 @@ static int accumulate_async(gs_trainer* t, bool need_var, Exchange* xchg = nullp
     st.count_before = st.count_after = P; st.views = V;
     // gradient planes (+ var), sized to the model's plane stride
     {
-        const void* before = t->grad.p;
+        const uint64_t before = t->grad.generation;      // (not the pointer: a regrown buffer may come back at the old address)
         GS_TRY(t->grad.ensure(plane_buffer_floats(M, m->Pa) * 4));
-        if (t->grad.p != before || t->grad_Pa != m->Pa)   // the tail behind the planes takes part in the collectives' chunks: keep it finite
+        if (t->grad.generation != before || t->grad_Pa != m->Pa)   // the tail behind the planes takes part in the collectives' chunks: keep it finite
             GS_HIP(hipMemsetAsync(t->grad.as<float>() + (size_t)(pl.count() + 1) * m->Pa, 0, 64 * 64 * 4, t->stream));
     }
     t->grad_Pa = m->Pa; t->grad_M = M;
