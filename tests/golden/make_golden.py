@@ -128,6 +128,36 @@ def build_budget_case():
     return out
 
 
+def build_reference_noise_case():
+    """The reference's own run-to-run envelope (oracle atomic_prepare / atomic_sums) on BASELINE cfg1's step: per gradient array the envelope
+    [min, max] over eight seeded fp32 atomicAdd orders, the double-summed value and the four order families' sums of the first pass —
+    the yardstick of tests/test_gpu_envelope.py must not move when the oracle is edited."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import oracle_forward, step_budget, view_parts
+    P, M, V, W, H = gs.synth.CONFIGS[1]
+    seed = gs.synth.seed_for(1)
+    s = gs.synth.random_splats(P, M, seed)
+    cams = gs.camera.get_cameras(1)
+    views = gs.camera.train_views(cams, W, H)
+    t = gs.synth.random_splats(P // 2, M, seed + 1000)
+    truth = []
+    for v in range(2):
+        r, img, _ = oracle_forward(orc, t, t["D"], M, view_parts(views[v]), W, H)
+        truth.append(orc.image_float_to_int(img, W, H))
+    bud = step_budget(orc, s, s["D"], M, W, H, views, np.concatenate(truth), 2.0, atomic_seeds=range(8))
+    out = {}
+    for k in ("loc", "sh", "scale", "opac", "rot", "var"):
+        runs = bud["runs"][k]
+        out[k + "_lo"], out[k + "_hi"], out[k + "_want"] = runs.min(0), runs.max(0), bud[k]["want"]
+    r, img, _ = oracle_forward(orc, s, s["D"], M, view_parts(views[0]), W, H)
+    dpix = orc.image_int_to_loss(truth[0], img, W, H)
+    r.atomic_prepare(dpix)
+    for mode in range(4):
+        out[f"sums9_mode{mode}"] = r.atomic_sums(3, mode)
+    r.atomic_release()
+    return out
+
+
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
     out, _ = build()
@@ -139,4 +169,7 @@ if __name__ == "__main__":
     print("wrote", path, os.path.getsize(path), "bytes")
     path = os.path.join(here, "budget_case.npz")
     np.savez_compressed(path, **build_budget_case())
+    print("wrote", path, os.path.getsize(path), "bytes")
+    path = os.path.join(here, "reference_noise_case.npz")
+    np.savez_compressed(path, **build_reference_noise_case())
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -278,3 +278,51 @@ def test_random_scene_sweep(orc, seed):
     print(f"[sweep {base + seed}: {kind}, {P} splats, M={M}, {2 * n_cams} passes @{W}x{H}] {st.num_rendered} list entries, longest tile list "
           f"{st.max_tile_list}: zero unexplained entries in both forms, worst error/budget {worst_all:.2f}; three Adam iterations and densify {P} -> {n2} splats bit-exact; render {rw}x{rh} x{mod:.2f}: {n_off} bytes one step off, each on a k/256 boundary; chain noise allowance up to {noise_share:.2g} x the sums' budget (dL_dscale)")
     tr.close()
+
+
+@pytest.mark.parametrize("seed", [2, 7, 15, 33, 50, 57, 80, 81, 83, 86, 87, 95])
+def test_depth_cut_on_sweep_scenes_changes_no_bit(seed):
+    """The depth cut of the tile lists (trainer option "list_cut") forced onto scenes it was not made for — `list_cut_min_avg`
+    0 applies it wherever a tile's pixels all finished — among them the eight heaps (seeds 80-87: tile lists of thousands of entries,
+    pixels that saturate late), big scenes and needle splats: seven Adam steps with a densify in the middle, cut against uncut: statistics,
+    gradient buffer and parameters bit for bit, whatever was cut, found wrong and replayed on the way."""
+    from test_gpu_trainer import _download, _read_grads
+    from gsplat_amd import capi
+    rng = np.random.default_rng(0x5EED5EED + seed)
+    big, pile = 48 <= seed < 64, 80 <= seed < 88
+    s, kind = wild_scene(rng, big, pile, edge_count=EDGE_COUNTS[seed - 88] if seed >= 88 else None)
+    P, M = s["count"], s["M"]
+    W, H = (int(rng.integers(17, 210)), int(rng.integers(17, 210))) if not big else (int(rng.integers(200, 420)), int(rng.integers(200, 420)))
+    cams = wild_rig(rng)
+    n_cams = len(cams)
+    fw = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(n_cams)]
+    fb = [rng.integers(0, 2 ** 32, W * H, dtype=np.uint32) for _ in range(n_cams)]
+    res = []
+    for cut in (1, 0):
+        host = gs.ModelSplatsHost.fromVectors(s["loc"], s["sh"], s["scale"], s["opac"], s["rot"])
+        host.shDegree = s["D"]
+        host.capacity = P + P // 4 + 8
+        tr = gs.Trainer(W, H)
+        tr.set_option("list_cut", cut)
+        tr.set_option("list_cut_min_avg", 0)
+        tr.model = gs.ModelSplatsDevice(host)
+        tr.captureTruths(cams, fw, fb)
+        proj = gs.Project(updateRule=capi.GS_UPDATE_ADAM, lrLocation=2e-4, lrSh=4e-4, lrScale=1e-4, lrOpacity=4e-4, lrRotation=2e-4,
+                          paramDensifyVariance=0.3, paramCullOpacity=0.05, paramSplitSize=0.2)
+        trail = []
+        for k in range(7):
+            st = tr.train(proj, densify=(k == 3), stats=True)
+            n = st.count_after
+            trail.append((st.num_rendered, st.loss, n, _read_grads(tr, n, M) if k != 3 else {}, _download(tr)))
+        res.append((trail, tr.list_cut_stats(), st.max_tile_list))
+        tr.close()
+    (ta, cut_a, la), (tb, cut_b, lb) = res
+    assert cut_b == (0, 0)
+    for k, (a, b) in enumerate(zip(ta, tb)):
+        assert a[0] == b[0] and a[2] == b[2] and (a[1] == b[1] or (np.isnan(a[1]) and np.isnan(b[1]))), (seed, k, a[:3], b[:3])
+        for name in a[3]:
+            assert np.array_equal(a[3][name].view(np.uint32), b[3][name].view(np.uint32)), (seed, k, name)
+        for name in ("loc", "sh", "scale", "opac", "rot"):
+            assert np.array_equal(a[4][name].view(np.uint32), b[4][name].view(np.uint32)), (seed, k, name)
+    print(f"[depth cut on sweep scene {seed}: {kind}, {P} splats, {2 * n_cams} passes @{W}x{H}] {cut_a[0]} attempts with cut lists, {cut_a[1]} replayed uncut; "
+          f"longest list {la} cut / {lb} uncut: every bit equal")
