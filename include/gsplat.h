@@ -243,6 +243,11 @@ int gs_trainer_apply(gs_trainer* trainer, const gs_hyper* hyper, int densify, gs
  * "reuse_hit_masks" (default 1): the backward reuses the block ballots the forward of the same camera stored (which entries of
  * a tile list can reach which 8x8 pixel block) instead of running the block test again; 0 makes it test itself.  Bit-identical.
  * "exchange_overlap" (default 1): see gs_trainer_set_compact_exchange.
+ * "fuse_update" (default 1): gs_trainer_step applies the update (applyGradients, src/Trainer.cu:81-101, or Adam) inside the kernel that
+ * averages the gradients (the per-splat reduction; under the compact exchange the SH rebuild) whenever no collective sits between the
+ * two, instead of launching an update over the gradient buffer; the gradient buffer is written either way.  0: always the launch.
+ * Bit-identical parameters, moments and gradient buffer.
+ * "list_cut" (default 1), "list_cut_min_avg", "list_cut_margin": the depth cut of the tile lists, see gs_trainer_list_cut_stats.
  * "roctx" (default 0, or 1 when the environment holds GS_ROCTX=1 at gs_trainer_create): a roctx range named like
  * gs_stage_name() is pushed around the launches of every stage of a step (librocprofiler-sdk-roctx is loaded on first use), so
  * that `rocprofv3 --marker-trace --kernel-trace` attributes the kernels to the nine stages.
