@@ -327,6 +327,7 @@ def _run_rank_sweep(rank, world, install, scene, out, errors):
         host.shDegree = s["D"]
         host.capacity = P + P // 5 + 8
         tr = gs.Trainer(W, H)
+        tr.set_option("list_cut_min_avg", 0)      # the depth cut of the tile lists wherever a tile's pixels finish (it changes no bit): its replay loop under every exchange
         tr.model = gs.ModelSplatsDevice(host)
         tr.captureTruths(cams, fw, fb, view_blocks=views)
         tr.shard(rank, world)
