@@ -28,6 +28,10 @@ def main():
     ap.add_argument("--iterations", type=int, default=6000)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--adam", type=int, default=1)
+    ap.add_argument("--list-cut-min-avg", type=int, default=-1, help="trainer option list_cut_min_avg (0: the depth cut of the tile lists wherever a tile's "
+                    "pixels finish; -1: the library's default, dense scenes only).  The cut changes no bit: two soak runs that differ only in this must end "
+                    "with the same `model_sha256`")
+    ap.add_argument("--list-cut", type=int, default=1)
     a = ap.parse_args()
     hip = C.CDLL("libamdhip64.so")
     W = H = a.size
@@ -42,6 +46,9 @@ def main():
         fb = [painter.render(W, H, 1.0, c, background=(0.0, 0.0, 0.0)).reshape(-1) for c in cameras]
         return fw, fb
     tr = gs.Trainer(W, H)
+    tr.set_option("list_cut", a.list_cut)
+    if a.list_cut_min_avg >= 0:
+        tr.set_option("list_cut_min_avg", a.list_cut_min_avg)
     tr.model = gs.ModelSplatsDevice(gs.fields.initFieldGrid())
     p = gs.Project.initProject()            # the reference's defaults (src/Project.h): 25 + 25 cameras, capture / densify intervals
     if a.adam:
@@ -65,7 +72,11 @@ def main():
     tr.synchronize()
     st = tr.train(p, densify=False, stats=True)
     free1 = free_bytes(hip)
-    print(json.dumps(dict(iterations=p.iterations, seconds=round(time.time() - t0, 1), cameras=len(tr.truthCameras), update="adam" if a.adam else "sgd",
+    import hashlib
+    hm = gs.ModelSplatsHost.fromDevice(tr.model)
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(x[:k * hm.count]).tobytes() for x, k in
+                                     ((hm.locations, 3), (hm.shs, 3 * hm.shCoeffs), (hm.scales, 3), (hm.opacities, 1), (hm.rotations, 4)))).hexdigest()
+    print(json.dumps(dict(model_sha256=digest, list_cut=dict(zip(("attempts_with_cut_lists", "replayed_uncut"), tr.list_cut_stats())), iterations=p.iterations, seconds=round(time.time() - t0, 1), cameras=len(tr.truthCameras), update="adam" if a.adam else "sgd",
                           final_count=tr.model.count, capacity=tr.model.capacity, final_loss=float(st.loss), longest_tile_list=int(st.max_tile_list),
                           memory_grown_since_iteration_50_MB=round((free0 - free1) / 2 ** 20, 1) if free0 else None,
                           peak_count=max(x["count"] for x in log), iteration_of_peak=max(log, key=lambda x: x["count"])["iteration"],
