@@ -24,11 +24,13 @@ def _run(extra):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("collective", ["torch", "rccl", "torch-sharded", "rccl-sharded", "torch-compact", "rccl-compact"])
+@pytest.mark.parametrize("collective", ["auto", "torch", "rccl", "torch-sharded", "rccl-sharded", "torch-compact", "rccl-compact"])
 def test_collective_hook_runs_with_one_rank(collective):
     base = _run([])
     got = _run(["--force-dist", "--collective", collective])
     assert "collective" in got["stages_ms_per_launch"], got["stages_ms_per_launch"]
+    if collective == "auto":   # the default of an N-GPU run: the library's own RCCL communicators wherever librccl loads (no Python inside the step)
+        assert got["config"]["collective_note"].startswith("auto -> rccl") and got["config"]["collective"].startswith("rccl"), got["config"]["collective_note"]
     assert got["config"]["mean_num_rendered_per_view"] == base["config"]["mean_num_rendered_per_view"]
     assert got["value"] > 0
 
