@@ -288,7 +288,7 @@ def test_depth_cut_on_sweep_scenes_changes_no_bit(seed):
     gradient buffer and parameters bit for bit, whatever was cut, found wrong and replayed on the way."""
     from test_gpu_trainer import _download, _read_grads
     from gsplat_amd import capi
-    rng = np.random.default_rng(0x5EED5EED + seed)
+    rng = np.random.default_rng(0x5EED5EED + seed + int(os.environ.get("GS_SWEEP_BASE", "0")))     # GS_SWEEP_BASE: other scenes, for hunting
     big, pile = 48 <= seed < 64, 80 <= seed < 88
     s, kind = wild_scene(rng, big, pile, edge_count=EDGE_COUNTS[seed - 88] if seed >= 88 else None)
     P, M = s["count"], s["M"]
