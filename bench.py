@@ -483,9 +483,9 @@ def main():
         if update_fused:     # no update launch: the per-splat reduction applied it (its bytes are part of that stage's time)
             step_bytes += stage_bytes("update", P, M, N, R_mean, V_local)
             step_form_bytes += stage_form_bytes("update", P, M, N, R_mean, V_local, n_groups)
-        # what this box's HBM sustains for a streaming copy ("state both"): 1 GiB, float4 per lane, fastest of 5 launches
+        # what this box's HBM sustains for a streaming copy ("state both"): 1 GiB, float4 per lane, the fastest launch of sixteen forms x 3
         peak_measured = C.c_double(0.0)
-        if L.gs_debug_hbm_copy_rate(1 << 30, 5, C.byref(peak_measured)) != 0:
+        if L.gs_debug_hbm_copy_rate(1 << 30, 3, C.byref(peak_measured)) != 0:
             peak_measured = C.c_double(0.0)
         peak_measured = float(peak_measured.value) or None
         ms_per_step = elapsed / args.steps * 1e3
@@ -567,8 +567,10 @@ def main():
                          "step_form_GB": step_form_bytes / 1e9,
                          "step_frac_form": step_form_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "peak_measured": peak_measured,
-                         "peak_measured_note": "GB/s (read + written) of a 1 GiB float4 streaming copy on this device right after the run (gs_debug_hbm_copy_rate, fastest of 5): "
-                                               "the achievable HBM ceiling; the *_measured fractions below divide by it instead of the 8 TB/s specification",
+                         "peak_measured_note": "GB/s (read + written) of a 1 GiB float4 streaming copy on this device right after the run (gs_debug_hbm_copy_rate: the fastest launch of "
+                                               "sixteen forms — grid size, 1 or 4 loads in flight per lane, plain or non-temporal accesses; form %d won): the achievable HBM "
+                                               "ceiling (a 256 MiB copy reads ~6.8 TB/s: the Infinity Cache helps it); the *_measured fractions divide by it instead of the 8 TB/s "
+                                               "specification" % L.gs_debug_hbm_copy_form(),
                          "frac_measured": None if not peak_measured else achieved / peak_measured,
                          "frac_form_measured": None if not peak_measured else form_bytes / (dom_ms * 1e-3) / 1e9 / peak_measured,
                          "step_frac_measured": None if not peak_measured else step_bytes / (ms_per_step * 1e-3) / 1e9 / peak_measured,

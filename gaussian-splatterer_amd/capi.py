@@ -51,7 +51,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void
 
 # every symbol include/gsplat.h declares (tests/test_capi_symbols.py checks the library exports them all)
 SYMBOLS = [
-    "gs_last_error", "gs_status_string", "gs_version", "gs_device_count", "gs_set_option", "gs_debug_wave_reduce9", "gs_debug_counters", "gs_debug_hbm_copy_rate", "gs_device_malloc", "gs_device_free",
+    "gs_last_error", "gs_status_string", "gs_version", "gs_device_count", "gs_set_option", "gs_debug_wave_reduce9", "gs_debug_counters", "gs_debug_hbm_copy_rate", "gs_debug_hbm_copy_form", "gs_device_malloc", "gs_device_free",
     "gs_memcpy_h2d", "gs_memcpy_d2h", "gs_memset_d", "gs_device_synchronize", "gs_model_create", "gs_model_clone",
     "gs_model_download", "gs_model_info", "gs_model_destroy", "gs_hyper_defaults", "gs_trainer_create",
     "gs_trainer_destroy", "gs_trainer_set_model", "gs_trainer_get_model", "gs_trainer_set_views", "gs_trainer_step",

@@ -358,6 +358,7 @@ extern "C" int gs_debug_counters(unsigned long long out[8], int reset) {
     return debug_counters(out, reset != 0);
 }
 
+static int g_copy_probe_best_form = -1;   // which form won the last gs_debug_hbm_copy_rate (diagnostic; gs_last_error text of a successful call is unchanged)
 extern "C" int gs_debug_hbm_copy_rate(size_t bytes, int repeats, double* gbytes_per_s) {
     if (!gbytes_per_s || bytes < 16 || (bytes & 15) || repeats < 1 || repeats > 1000) { set_error("gs_debug_hbm_copy_rate: bad arguments"); return GS_ERR_INVALID_ARGUMENT; }
     GS_TRY(require_device());
@@ -373,15 +374,18 @@ extern "C" int gs_debug_hbm_copy_rate(size_t bytes, int repeats, double* gbytes_
     if (rc == GS_OK && (e = hipMemset(a, 0x3c, bytes)) != hipSuccess) fail("hipMemset", e);
     if (rc == GS_OK && (e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) fail("hipStreamCreate", e);
     if (rc == GS_OK && ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess)) fail("hipEventCreate", e);
-    for (int k = 0; rc == GS_OK && k <= repeats; k++) {   // k = 0: warm-up (first touch of the destination)
-        (void)hipEventRecord(e0, st);
-        rc = launch_copy_probe(a, b, bytes, st);
-        (void)hipEventRecord(e1, st);
-        if (rc == GS_OK && (e = hipEventSynchronize(e1)) != hipSuccess) fail("hipEventSynchronize", e);
-        float ms = 0.0f;
-        if (rc == GS_OK && (e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) fail("hipEventElapsedTime", e);
-        if (rc == GS_OK && k > 0 && ms > 0.0f && (best_ms == 0.0 || ms < best_ms)) best_ms = ms;
-    }
+    // sixteen forms of the copy (grid of 256 x 8 ... 64 workgroups, one or four float4 in flight per lane, plain or non-temporal accesses),
+    // each launched `repeats` times behind one warm-up: the fastest single launch of all is the figure
+    for (int form = 0; rc == GS_OK && form < 16; form++)
+        for (int k = 0; rc == GS_OK && k <= repeats; k++) {   // k = 0: warm-up (first touch of the destination)
+            (void)hipEventRecord(e0, st);
+            rc = launch_copy_probe(a, b, bytes, form, st);
+            (void)hipEventRecord(e1, st);
+            if (rc == GS_OK && (e = hipEventSynchronize(e1)) != hipSuccess) fail("hipEventSynchronize", e);
+            float ms = 0.0f;
+            if (rc == GS_OK && (e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) fail("hipEventElapsedTime", e);
+            if (rc == GS_OK && k > 0 && ms > 0.0f && (best_ms == 0.0 || ms < best_ms)) { best_ms = ms; g_copy_probe_best_form = form; }
+        }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (st) (void)hipStreamDestroy(st);
@@ -391,6 +395,8 @@ extern "C" int gs_debug_hbm_copy_rate(size_t bytes, int repeats, double* gbytes_
     *gbytes_per_s = best_ms > 0.0 ? 2.0 * (double)bytes / (best_ms * 1e-3) / 1e9 : 0.0;
     return GS_OK;
 }
+
+extern "C" int gs_debug_hbm_copy_form(void) { return g_copy_probe_best_form; }
 
 extern "C" int gs_hyper_defaults(gs_hyper* h) {
     if (!h) return GS_ERR_INVALID_ARGUMENT;

@@ -286,7 +286,7 @@ int launch_aos_to_soa(int P, int Pa, int M, const float* loc, const float* sh, c
                       const float* rot, float* planes, hipStream_t st);
 int launch_soa_to_aos(int P, int Pa, int M, const float* planes, float* loc, float* sh, float* scale, float* opac,
                       float* rot, hipStream_t st);
-int launch_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t st);
+int launch_copy_probe(const void* src, void* dst, size_t bytes, int form, hipStream_t st);   // form 0..15: grid size, unroll, non-temporal
 int launch_image_float_to_int(const float* src, uint32_t* fb, int w, int h, hipStream_t st);
 int launch_image_int_to_loss(const uint32_t* truth, const float* rast, float* loss, int w, int h, hipStream_t st);
 int launch_ranges(const Dims& d, const Scratch& s, uint32_t* ranges, hipStream_t st);

@@ -33,16 +33,44 @@ __global__ __launch_bounds__(WG) void k_update(UpdateArgs u, int P, int Pa, floa
     if (sh16 && p >= 3 && p < pl.scale(0)) sh16[(size_t)(p - 3) * Pa + i] = __float2half_rn(x);
 }
 
-// streaming-copy probe (gs_debug_hbm_copy_rate): one float4 per lane and trip, grid-stride over a grid that fills the chip a few times
+// streaming-copy probe (gs_debug_hbm_copy_rate): float4 per lane, U independent loads in flight per trip, grid-stride; NT: non-temporal
+// (streaming) loads and stores.  The caller times a few (grid, U, NT) forms and reports the fastest: the achievable ceiling, not one guess at it.
+template <int U, bool NT>
 __global__ __launch_bounds__(WG) void k_copy_probe(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
     const size_t stride = (size_t)gridDim.x * WG;
-    for (size_t k = (size_t)blockIdx.x * WG + threadIdx.x; k < n4; k += stride) dst[k] = src[k];
+    size_t k = (size_t)blockIdx.x * WG + threadIdx.x;
+    for (; k + (U - 1) * stride < n4; k += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (NT) {
+                const float* p = reinterpret_cast<const float*>(src + k + u * stride);
+                v[u] = make_float4(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2), __builtin_nontemporal_load(p + 3));
+            } else v[u] = src[k + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (NT) {
+                float* p = reinterpret_cast<float*>(dst + k + u * stride);
+                __builtin_nontemporal_store(v[u].x, p); __builtin_nontemporal_store(v[u].y, p + 1); __builtin_nontemporal_store(v[u].z, p + 2); __builtin_nontemporal_store(v[u].w, p + 3);
+            } else dst[k + u * stride] = v[u];
+        }
+    }
+    for (; k < n4; k += stride) dst[k] = src[k];
 }
-int launch_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t st) {
+int launch_copy_probe(const void* src, void* dst, size_t bytes, int form, hipStream_t st) {
     const size_t n4 = bytes / 16;
     if (!n4) return GS_OK;
-    const unsigned grid = (unsigned)std::min<size_t>((n4 + WG - 1) / WG, 256 * 32);
-    hipLaunchKernelGGL(k_copy_probe, dim3(grid), dim3(WG), 0, st, (const float4*)src, (float4*)dst, n4);
+    // form: bits 0-1 grid (256 x 8 / 16 / 32 / 64 workgroups), bit 2 unroll 4 (else 1), bit 3 non-temporal
+    const unsigned grid = (unsigned)std::min<size_t>((n4 + WG - 1) / WG, (size_t)256 * (8u << (form & 3)));
+    const float4* a = (const float4*)src;
+    float4* b = (float4*)dst;
+    switch ((form >> 2) & 3) {
+        case 0: hipLaunchKernelGGL((k_copy_probe<1, false>), dim3(grid), dim3(WG), 0, st, a, b, n4); break;
+        case 1: hipLaunchKernelGGL((k_copy_probe<4, false>), dim3(grid), dim3(WG), 0, st, a, b, n4); break;
+        case 2: hipLaunchKernelGGL((k_copy_probe<1, true>), dim3(grid), dim3(WG), 0, st, a, b, n4); break;
+        default: hipLaunchKernelGGL((k_copy_probe<4, true>), dim3(grid), dim3(WG), 0, st, a, b, n4); break;
+    }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

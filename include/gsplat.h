@@ -91,9 +91,13 @@ int gs_debug_wave_reduce9(const float* in_host, float* out_host);
 int gs_debug_counters(unsigned long long out[8], int reset);
 /* Diagnostic: what this device's HBM sustains for a plain streaming copy — the achievable ceiling SURVEY 8(d) asks to be stated
  * next to the 8 TB/s specification.  Copies `bytes` (a multiple of 16; two buffers of that size are allocated and freed) with a
- * float4-per-lane kernel `repeats` times after one warm-up launch and returns the FASTEST launch's (read + written bytes) / time in
- * GB/s, from HIP events on a stream of its own.  bench.py reports it as roofline.peak_measured. */
+ * float4-per-lane kernel in sixteen forms (grid size, one or four loads in flight per lane, plain or non-temporal accesses), each
+ * `repeats` times after a warm-up launch, and returns the FASTEST launch's (read + written bytes) / time in GB/s, from HIP events on a
+ * stream of its own.  bench.py reports it as roofline.peak_measured. */
 int gs_debug_hbm_copy_rate(size_t bytes, int repeats, double* gbytes_per_s);
+/* Which of the sixteen forms won the last gs_debug_hbm_copy_rate (-1: none yet): bits 0-1 grid = 256 x (8 << g) workgroups, bit 2 four
+ * loads in flight per lane, bit 3 non-temporal accesses. */
+int gs_debug_hbm_copy_form(void);
 
 /* ------------------------------------------------------------------------------------------
  * Raw device-memory helpers (current HIP device).  They exist so that C / ctypes callers and the
