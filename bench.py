@@ -477,8 +477,16 @@ def main():
         n_groups = max(V_local // 2, 1)
         form_bytes = {"render_backward": n_groups * (40 * R_mean + 44 * P) + V_local * 24 * N,
                       "render_forward": n_groups * 40 * R_mean + V_local * 12 * N + n_groups * 8 * N}.get(dom, dom_bytes)
+        cut_active = tr.list_cut_stats()[0] > 0 and list_totals[1] > 0
+        if cut_active:   # the lists the kernels walked are the cut ones
+            R_listed = list_totals[1] / max(n_groups, 1)
+            form_bytes = {"render_backward": n_groups * (40 * R_listed + 44 * P) + V_local * 24 * N,
+                          "render_forward": n_groups * 40 * R_listed + V_local * 12 * N + n_groups * 8 * N}.get(dom, form_bytes)
         step_bytes = sum(stage_bytes(k, P, M, N, R_mean, V_local) for k in kern) + (48 + 12 * M) * P
-        step_form_bytes = sum(stage_form_bytes(k, P, M, N, R_mean, V_local, n_groups) for k in kern)
+        # (a dense step that cut its tile lists moved the entries it LISTED, not the R of SURVEY's model: the form's bytes are priced with those)
+        cut_active = tr.list_cut_stats()[0] > 0 and list_totals[1] > 0
+        R_form = list_totals[1] / max(n_groups, 1) if cut_active else R_mean
+        step_form_bytes = sum(stage_form_bytes(k, P, M, N, R_form, V_local, n_groups) for k in kern)
         update_fused = "update" not in kern and "splat_backward" in kern
         if update_fused:     # no update launch: the per-splat reduction applied it (its bytes are part of that stage's time)
             step_bytes += stage_bytes("update", P, M, N, R_mean, V_local)
@@ -575,6 +583,9 @@ def main():
                          "frac_form_measured": None if not peak_measured else form_bytes / (dom_ms * 1e-3) / 1e9 / peak_measured,
                          "step_frac_measured": None if not peak_measured else step_bytes / (ms_per_step * 1e-3) / 1e9 / peak_measured,
                          "step_frac_form_measured": None if not peak_measured else step_form_bytes / (ms_per_step * 1e-3) / 1e9 / peak_measured,
+                         "cut_note": None if not cut_active else "this run cut its tile lists by depth (list_cut): achieved / frac / step_frac price SURVEY 8d's bytes for ALL "
+                                     "%d entries per camera although only %d were listed — they are algorithmic rates, not bandwidths, and may exceed the peak; "
+                                     "the *_form figures price the entries listed" % (int(R_mean), int(list_totals[1] / max(n_groups, 1))),
                          "step_note": "step_frac prices SURVEY 8d's per-VIEW bytes x the views of the step although projection, lists, forward blend and "
                                       "the backward ran once per CAMERA; step_frac_form prices the bytes of the form that ran, every stage: the stricter figure"},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
